@@ -1,0 +1,64 @@
+// Shared device/host helpers for libfk (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fk.h"
+
+typedef uint16_t bf16_t;  // raw bf16 storage
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // 8 bf16 = 4 VGPRs (MFMA A/B operand)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define FK_DEV __device__ __forceinline__
+
+FK_DEV float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, like torch's float -> bfloat16 conversion (NaN handling not needed here)
+FK_DEV bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+FK_DEV float round_bf(float f) { return bf2f(f2bf(f)); }
+
+FK_DEV uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+FK_DEV float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+FK_DEV float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+FK_DEV float gelu_tanh_f(float x) {
+  // torch: 0.5 * x * (1 + tanh(sqrt(2/pi) * (x + 0.044715 x^3)))
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float inner = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(inner));
+}
+FK_DEV float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+FK_DEV int64_t fk_row_offset(const fk_rows& r, int64_t m) {
+  if (r.rows_per_batch <= 0) return m * r.ld;
+  int64_t b = m / r.rows_per_batch;
+  return b * r.batch_stride + (m - b * r.rows_per_batch) * r.ld;
+}
+
+// host side ---------------------------------------------------------------------------------------
+void fk_set_error(const char* fmt, ...);
+#define FK_CHECK_ARG(cond, ...)      \
+  do {                               \
+    if (!(cond)) {                   \
+      fk_set_error(__VA_ARGS__);     \
+      return FK_EINVAL;              \
+    }                                \
+  } while (0)
+#define FK_CHECK_LAUNCH(name)                                               \
+  do {                                                                      \
+    hipError_t e_ = hipGetLastError();                                      \
+    if (e_ != hipSuccess) {                                                 \
+      fk_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+      return FK_ELAUNCH;                                                    \
+    }                                                                       \
+  } while (0)

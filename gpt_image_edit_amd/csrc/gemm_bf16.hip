@@ -1,0 +1,289 @@
+// bf16 MFMA GEMM with fused epilogues for the FLUX MMDiT linears (K1 in SURVEY.md section 2.2).
+//
+//   C[M,N] = epi(A[M,K] . W[N,K]^T + bias)        A, W: bf16, K-contiguous;  fp32 accumulate.
+//
+// Tiling (gfx950): 128x128 block tile, BK = 64, 256 threads = 4 waves in a 2(m) x 2(n) grid, each
+// wave owns a 64x64 sub-tile as 2x2 v_mfma_f32_32x32x16_bf16 accumulators.  The product is formed
+// "swapped" (W rows feed the MFMA A operand, activation rows the B operand) so that every lane ends
+// up with 4 consecutive output columns of ONE output row in consecutive accumulator registers --
+// the epilogue packs them to bf16 and writes 8-byte pieces into an LDS staging tile, from which the
+// block streams fully coalesced 16-byte rows (with the residual / gate reads equally coalesced).
+//
+// Staging: global -> VGPR (dwordx4, issued one K-tile ahead) -> LDS (ds_write_b128), two LDS stages,
+// one barrier per K-tile.  LDS rows are 128 B (64 bf16); the 16-byte chunk index is XORed with
+// ((row >> 1) & 7) so that every ds_read_b128 lane group (16 lanes, rows r..r+15) hits 16 distinct
+// 16-byte slots of the 256-byte bank row (conflict-free, see MI355X_MICROARCH LDS table).
+//
+// Tile order: XCD-aware (block b runs on XCD b % 8, so each XCD is given a contiguous chunk of the
+// tile list) and grouped 8 m-tiles deep so the ~64 tiles resident on one XCD form an ~8x8 patch that
+// shares A / W K-slices through that XCD's L2.
+#include "fk_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int NTHREADS = 256;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB
+constexpr int CT_LD = BN + 8;                    // staging-tile row stride in elements (272 B)
+constexpr int SMEM_BYTES = 2 * STAGE_BYTES;      // 64 KiB (C staging tile aliases it)
+constexpr int GROUP_M = 8;
+
+struct TileCoord {
+  int tm, tn;
+};
+
+FK_DEV TileCoord map_tile(int bid, int nwg, int nbm, int nbn) {
+  // bijective XCD chunking (cdna guide T1): XCD x gets a contiguous run of the tile list
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  // grouped ordering: GROUP_M m-tiles deep, m fastest inside a group
+  const int per_group = GROUP_M * nbn;
+  const int g = t / per_group;
+  const int first_m = g * GROUP_M;
+  const int gm = min(nbm - first_m, GROUP_M);
+  const int rem = t - g * per_group;
+  TileCoord c;
+  c.tm = first_m + rem % gm;
+  c.tn = rem / gm;
+  return c;
+}
+
+template <int EPI, bool OUT_F32>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const fk_gemm_args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const TileCoord tc = map_tile(blockIdx.x, gridDim.x, nbm, nbn);
+  const int m0 = tc.tm * BM, n0 = tc.tn * BN;
+
+  // ---- global -> register staging: thread owns chunk kc of rows (tid/8 + 32 i), i = 0..3 ----------
+  const int ld_row = tid >> 3;  // 0..31
+  const int kc = tid & 7;       // 16-byte chunk inside the 128-byte K slice
+  const bf16_t* a_ptr[4];
+  const bf16_t* w_ptr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = min(m0 + ld_row + 32 * i, p.M - 1);
+    int n = min(n0 + ld_row + 32 * i, p.N - 1);
+    a_ptr[i] = (const bf16_t*)p.A + fk_row_offset(p.a, m) + kc * 8;
+    w_ptr[i] = (const bf16_t*)p.W + (int64_t)n * p.ldw + kc * 8;
+  }
+  const int st_off = ld_row * 128 + ((kc ^ ((ld_row >> 1) & 7)) << 4);  // + i*4096 (+ 16 KiB for W)
+
+  u32x4_t a_reg[4], w_reg[4];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a_reg[i] = *(const u32x4_t*)(a_ptr[i] + (int64_t)kt * BK);
+      w_reg[i] = *(const u32x4_t*)(w_ptr[i] + (int64_t)kt * BK);
+    }
+  };
+  auto store_tile = [&](int stage) {
+    char* base = smem + stage * STAGE_BYTES + st_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *(u32x4_t*)(base + i * 4096) = a_reg[i];
+      *(u32x4_t*)(base + BM * BK * 2 + i * 4096) = w_reg[i];
+    }
+  };
+
+  // ---- MFMA operand addressing ----------------------------------------------------------------------
+  // operand row = base + (lane & 31); chunk = 2*kk + (lane >> 5), swizzled by (row >> 1) & 7.
+  const int frow = lane & 31;
+  const int fsw = (frow >> 1) & 7;   // bases are multiples of 32 -> do not disturb the swizzle bits
+  const int fhalf = lane >> 5;
+  const int a_rd = (wm * 64 + frow) * 128;                  // + mf*32*128
+  const int w_rd = BM * BK * 2 + (wn * 64 + frow) * 128;    // + nf*32*128
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const char* sb = smem + cur * STAGE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int coff = (((kk * 2 + fhalf) ^ fsw) << 4);
+      bf16x8_t af[2], wf[2];
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf) af[mf] = *(const bf16x8_t*)(sb + a_rd + mf * 4096 + coff);
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) wf[nf] = *(const bf16x8_t*)(sb + w_rd + nf * 4096 + coff);
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+          acc[nf][mf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nf], af[mf], acc[nf][mf], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------------
+  // lane holds, for (nf, mf, r): row m = wm*64 + mf*32 + (lane & 31),
+  //                              col n = wn*64 + nf*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
+  if constexpr (OUT_F32) {
+    float* C = (float*)p.C;
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+      const int m = m0 + wm * 64 + mf * 32 + frow;
+      if (m >= p.M) continue;
+      const int64_t roff = fk_row_offset(p.c, m);
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + wn * 64 + nf * 32 + 8 * (r >> 2) + 4 * fhalf + (r & 3);
+          if (n < p.N) {
+            float v = acc[nf][mf][r];
+            if constexpr (EPI == FK_EPI_SCALE) v *= p.alpha;
+            else if (p.bias) v += bf2f(((const bf16_t*)p.bias)[n]);
+            C[roff + n] = v;
+          }
+        }
+    }
+    return;
+  } else {
+    // phase 1: bias (+activation), round to bf16, park in the LDS staging tile Ct[128][CT_LD]
+    bf16_t* ct = (bf16_t*)smem;  // safe: the loop's final barrier ordered all operand reads
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nl = wn * 64 + nf * 32 + 8 * q + 4 * fhalf;  // local column of the 4-group
+        const int n = n0 + nl;
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI != FK_EPI_SCALE) {
+          if (p.bias && n < p.N) {
+            const u32x2_t bw = *(const u32x2_t*)((const bf16_t*)p.bias + n);
+            b[0] = bf_lo(bw[0]); b[1] = bf_hi(bw[0]); b[2] = bf_lo(bw[1]); b[3] = bf_hi(bw[1]);
+          }
+        }
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float t = acc[nf][mf][q * 4 + j];
+            if constexpr (EPI == FK_EPI_SCALE) t = t * p.alpha;
+            else t = t + b[j];
+            if constexpr (EPI == FK_EPI_GELU_TANH) t = gelu_tanh_f(round_bf(t));
+            if constexpr (EPI == FK_EPI_SILU) t = silu_f(round_bf(t));
+            v[j] = t;
+          }
+          u32x2_t pk;
+          pk[0] = pack_bf2(v[0], v[1]);
+          pk[1] = pack_bf2(v[2], v[3]);
+          const int ml = wm * 64 + mf * 32 + frow;
+          *(u32x2_t*)(ct + ml * CT_LD + nl) = pk;
+        }
+      }
+    __syncthreads();
+    // phase 2: coalesced 16-byte rows; residual / gate applied on 8-wide vectors
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int id = tid + NTHREADS * j;
+      const int ml = id >> 4, cc = id & 15;
+      const int m = m0 + ml, n = n0 + cc * 8;
+      if (m >= p.M || n >= p.N) continue;
+      u32x4_t y = *(const u32x4_t*)(ct + ml * CT_LD + cc * 8);
+      if constexpr (EPI == FK_EPI_GATE_RES || EPI == FK_EPI_RES) {
+        const u32x4_t rv = *(const u32x4_t*)((const bf16_t*)p.res + fk_row_offset(p.r, m) + n);
+        u32x4_t gv;
+        if constexpr (EPI == FK_EPI_GATE_RES) {
+          const int64_t b = m / p.gate_rows_per_batch;
+          gv = *(const u32x4_t*)((const bf16_t*)p.gate + b * p.gate_batch_stride + n);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float y0 = bf_lo(y[e]), y1 = bf_hi(y[e]);
+          if constexpr (EPI == FK_EPI_GATE_RES) {
+            y0 = round_bf(bf_lo(gv[e]) * y0);
+            y1 = round_bf(bf_hi(gv[e]) * y1);
+          }
+          y[e] = pack_bf2(bf_lo(rv[e]) + y0, bf_hi(rv[e]) + y1);
+        }
+      }
+      *(u32x4_t*)((bf16_t*)p.C + fk_row_offset(p.c, m) + n) = y;
+    }
+  }
+}
+
+template <int EPI, bool OUT_F32>
+int launch(const fk_gemm_args& p, hipStream_t stream) {
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  auto kern = gemm_bf16_kernel<EPI, OUT_F32>;
+  static bool attr_done = false;  // benign race: idempotent
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(NTHREADS), SMEM_BYTES, stream, p);
+  FK_CHECK_LAUNCH("fk_gemm_bf16");
+  return FK_OK;
+}
+
+}  // namespace
+
+extern "C" int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream_) {
+  FK_CHECK_ARG(args != nullptr, "fk_gemm_bf16: null args");
+  const fk_gemm_args& p = *args;
+  hipStream_t stream = (hipStream_t)stream_;
+  FK_CHECK_ARG(p.A && p.W && p.C, "fk_gemm_bf16: null A/W/C");
+  FK_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "fk_gemm_bf16: bad M/N/K %d %d %d", p.M, p.N, p.K);
+  FK_CHECK_ARG(p.K % BK == 0, "fk_gemm_bf16: K=%d must be a multiple of %d", p.K, BK);
+  FK_CHECK_ARG(p.a.ld % 8 == 0 && p.ldw % 8 == 0, "fk_gemm_bf16: lda/ldw must be multiples of 8");
+  FK_CHECK_ARG(((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.W % 16 == 0) && ((uintptr_t)p.C % 16 == 0),
+               "fk_gemm_bf16: A/W/C must be 16-byte aligned");
+  FK_CHECK_ARG(p.a.rows_per_batch <= 0 || p.a.batch_stride % 8 == 0, "fk_gemm_bf16: A batch stride % 8");
+  if (!p.out_fp32) {
+    FK_CHECK_ARG(p.N % 8 == 0, "fk_gemm_bf16: N=%d must be a multiple of 8 for bf16 output", p.N);
+    FK_CHECK_ARG(p.c.ld % 8 == 0 && (p.c.rows_per_batch <= 0 || p.c.batch_stride % 8 == 0),
+                 "fk_gemm_bf16: ldc / C batch stride must be multiples of 8");
+    FK_CHECK_ARG(!p.bias || ((uintptr_t)p.bias % 8 == 0), "fk_gemm_bf16: bias must be 8-byte aligned");
+  }
+  if (p.epilogue == FK_EPI_GATE_RES || p.epilogue == FK_EPI_RES) {
+    FK_CHECK_ARG(p.res != nullptr && ((uintptr_t)p.res % 16 == 0) && p.r.ld % 8 == 0 &&
+                     (p.r.rows_per_batch <= 0 || p.r.batch_stride % 8 == 0),
+                 "fk_gemm_bf16: residual pointer/stride invalid");
+    FK_CHECK_ARG(!p.out_fp32, "fk_gemm_bf16: residual epilogues have no fp32 output");
+  }
+  if (p.epilogue == FK_EPI_GATE_RES) {
+    FK_CHECK_ARG(p.gate != nullptr && ((uintptr_t)p.gate % 16 == 0) && p.gate_batch_stride % 8 == 0 &&
+                     p.gate_rows_per_batch > 0,
+                 "fk_gemm_bf16: gate pointer/stride invalid");
+  }
+  if (p.out_fp32) {
+    switch (p.epilogue) {
+      case FK_EPI_NONE: return launch<FK_EPI_NONE, true>(p, stream);
+      case FK_EPI_SCALE: return launch<FK_EPI_SCALE, true>(p, stream);
+      default: fk_set_error("fk_gemm_bf16: fp32 output supports FK_EPI_NONE / FK_EPI_SCALE only"); return FK_EUNSUPPORTED;
+    }
+  }
+  switch (p.epilogue) {
+    case FK_EPI_NONE: return launch<FK_EPI_NONE, false>(p, stream);
+    case FK_EPI_GELU_TANH: return launch<FK_EPI_GELU_TANH, false>(p, stream);
+    case FK_EPI_SILU: return launch<FK_EPI_SILU, false>(p, stream);
+    case FK_EPI_GATE_RES: return launch<FK_EPI_GATE_RES, false>(p, stream);
+    case FK_EPI_RES: return launch<FK_EPI_RES, false>(p, stream);
+    case FK_EPI_SCALE: return launch<FK_EPI_SCALE, false>(p, stream);
+    default: fk_set_error("fk_gemm_bf16: unknown epilogue %d", p.epilogue); return FK_EUNSUPPORTED;
+  }
+}

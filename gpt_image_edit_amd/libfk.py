@@ -1,0 +1,86 @@
+"""ctypes binding of libfk.so (C ABI declared in include/fk.h).
+
+There is deliberately NO fallback: if the HIP library is missing or does not export a symbol the
+import fails loudly, and every op raises ``RuntimeError`` carrying ``fk_last_error()`` on a non-zero
+return code.  PyTorch is used only for device memory and streams (tensor.data_ptr(), current stream).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfk.so")
+
+c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+FK_EPI_NONE, FK_EPI_GELU_TANH, FK_EPI_SILU, FK_EPI_GATE_RES, FK_EPI_RES, FK_EPI_SCALE = range(6)
+
+
+class Rows(ctypes.Structure):
+    _fields_ = [("ld", c_i64), ("rows_per_batch", c_i64), ("batch_stride", c_i64)]
+
+
+class GemmArgs(ctypes.Structure):
+    _fields_ = [
+        ("A", c_vp), ("a", Rows),
+        ("W", c_vp), ("ldw", c_i64),
+        ("bias", c_vp),
+        ("C", c_vp), ("c", Rows),
+        ("res", c_vp), ("r", Rows),
+        ("gate", c_vp), ("gate_batch_stride", c_i64), ("gate_rows_per_batch", c_i64),
+        ("M", c_i32), ("N", c_i32), ("K", c_i32),
+        ("epilogue", c_i32), ("out_fp32", c_i32), ("alpha", c_f32),
+    ]
+
+
+class ConvArgs(ctypes.Structure):
+    _fields_ = [
+        ("x", c_vp), ("w", c_vp), ("bias", c_vp), ("y", c_vp), ("res", c_vp),
+        ("B", c_i32), ("Hin", c_i32), ("Win", c_i32), ("Cin", c_i32), ("Cout", c_i32),
+        ("ksize", c_i32), ("stride", c_i32), ("pad", c_i32), ("upsample2x", c_i32),
+        ("Hout", c_i32), ("Wout", c_i32),
+    ]
+
+
+# symbol -> (restype, argtypes); must list every entry point of include/fk.h
+SIGNATURES = {
+    "fk_gemm_bf16": (c_i32, [ctypes.POINTER(GemmArgs), c_vp]),
+    "fk_ln_modulate_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
+    "fk_qkv_post_bf16": (c_i32, [c_vp] * 10 + [c_i32] * 5 + [c_f32, c_vp]),
+    "fk_attention_fwd_bf16": (c_i32, [c_vp] * 4 + [c_i32] * 4 + [c_i64, c_i64, c_f32, c_vp]),
+    "fk_silu_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "fk_timestep_proj": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp]),
+    "fk_add3_bf16": (c_i32, [c_vp] * 4 + [c_i64, c_vp]),
+    "fk_euler_step_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp]),
+    "fk_transpose_bf16": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "fk_softmax_rows": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp]),
+    # VAE_SIGNATURES_PLACEHOLDER
+    "fk_last_error": (ctypes.c_char_p, []),
+    "fk_version": (ctypes.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libfk.so once; raises (never falls back) when it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import "
+            f"__graft_entry__ as g; g.build()'` (or `make -C gpt_image_edit_amd/csrc`). There is no CPU "
+            f"fallback for the FLUX-Kontext hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().fk_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {code}): {msg}")

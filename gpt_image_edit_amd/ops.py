@@ -1,0 +1,188 @@
+"""Tensor-level wrappers over the C ABI (include/fk.h): tensors in, tensors out.
+
+Only plumbing lives here: argument checking, stride extraction, raw pointers and the current HIP
+stream.  All arithmetic happens in libfk.so; nothing falls back to torch ops.
+"""
+import ctypes
+
+import torch
+
+from . import libfk
+from .libfk import (FK_EPI_GATE_RES, FK_EPI_GELU_TANH, FK_EPI_NONE, FK_EPI_RES, FK_EPI_SCALE,  # noqa: F401
+                    FK_EPI_SILU, GemmArgs, Rows)
+
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("gpt_image_edit_amd ops need GPU tensors: the HIP path has no CPU fallback")
+
+
+def rows_of(t):
+    """(M, Rows) for a [M, K] or [B, R, K] tensor (or view) whose last dimension is contiguous."""
+    if t.stride(-1) != 1:
+        raise ValueError("last dimension must be contiguous")
+    if t.dim() == 2:
+        return t.shape[0], Rows(t.stride(0), 0, 0)
+    if t.dim() == 3:
+        b, r, _ = t.shape
+        return b * r, Rows(t.stride(1), r, t.stride(0))
+    raise ValueError(f"expected a 2-D or 3-D tensor, got {t.dim()}-D")
+
+
+def gemm(a, w, bias=None, out=None, epilogue=FK_EPI_NONE, res=None, gate=None, out_fp32=False, alpha=1.0):
+    """out = epilogue(a @ w.T + bias).  a: [M,K] / [B,R,K] view; w: [N,K]; out likewise (may alias res).
+
+    gate: [B, N] view (row stride = batch stride); used with FK_EPI_GATE_RES and a 3-D ``a``.
+    """
+    _need_cuda(a, w, bias, out, res, gate)
+    M, ra = rows_of(a)
+    N, K = w.shape
+    if a.shape[-1] != K:
+        raise ValueError(f"K mismatch: a {tuple(a.shape)} vs w {tuple(w.shape)}")
+    if a.dtype != BF16 or w.dtype != BF16:
+        raise TypeError("fk_gemm_bf16 takes bf16 operands")
+    if out is None:
+        shape = (*a.shape[:-1], N)
+        out = torch.empty(shape, device=a.device, dtype=torch.float32 if out_fp32 else BF16)
+    Mo, rc = rows_of(out)
+    if Mo != M or out.shape[-1] != N:
+        raise ValueError(f"output shape {tuple(out.shape)} does not match M={M}, N={N}")
+    args = GemmArgs()
+    args.A, args.a = a.data_ptr(), ra
+    args.W, args.ldw = w.data_ptr(), w.stride(0)
+    args.bias = bias.data_ptr() if bias is not None else None
+    args.C, args.c = out.data_ptr(), rc
+    if res is not None:
+        Mr, rr = rows_of(res)
+        if Mr != M:
+            raise ValueError("residual rows mismatch")
+        args.res, args.r = res.data_ptr(), rr
+    if gate is not None:
+        if a.dim() != 3 or gate.dim() != 2 or gate.shape[0] != a.shape[0] or gate.stride(1) != 1:
+            raise ValueError("gate must be a [B, N] view matching a 3-D activation")
+        args.gate = gate.data_ptr()
+        args.gate_batch_stride = gate.stride(0)
+        args.gate_rows_per_batch = a.shape[1]
+    args.M, args.N, args.K = M, N, K
+    args.epilogue, args.out_fp32, args.alpha = epilogue, int(out_fp32), float(alpha)
+    lib = libfk.load()
+    libfk.check(lib.fk_gemm_bf16(ctypes.byref(args), _stream()), "fk_gemm_bf16")
+    return out
+
+
+def ln_modulate(x, shift, scale, out=None, eps=1e-6):
+    """out = LN(x) * (1 + scale[b]) + shift[b]; x/out: [B,R,D] views, shift/scale: [B,D] views."""
+    _need_cuda(x, shift, scale, out)
+    if x.dim() != 3:
+        raise ValueError("x must be [B, R, D]")
+    B, R, D = x.shape
+    if out is None:
+        out = torch.empty((B, R, D), device=x.device, dtype=BF16)
+    M, rx = rows_of(x)
+    _, ro = rows_of(out)
+    if shift.stride(0) != scale.stride(0) or shift.stride(1) != 1 or scale.stride(1) != 1:
+        raise ValueError("shift/scale must be [B, D] views with a common batch stride")
+    lib = libfk.load()
+    libfk.check(lib.fk_ln_modulate_bf16(_ptr(x), rx, _ptr(out), ro, _ptr(shift), _ptr(scale),
+                                        shift.stride(0), R, M, D, eps, _stream()), "fk_ln_modulate_bf16")
+    return out
+
+
+def qkv_post(qkv, q_out, k_out, vt_out, wq_img, wk_img, wq_txt, wk_txt, cos, sin, s_txt, eps=1e-6):
+    """RMSNorm + RoPE + re-layout: qkv [B,S,3*H*128] -> q/k [B,H,S,128], vt [B,H,128,S_pad]."""
+    _need_cuda(qkv, q_out, k_out, vt_out, cos, sin)
+    B, S, D3 = qkv.shape
+    H = D3 // 384
+    S_pad = vt_out.shape[-1]
+    if not qkv.is_contiguous():
+        raise ValueError("qkv must be contiguous")
+    lib = libfk.load()
+    libfk.check(lib.fk_qkv_post_bf16(_ptr(qkv), _ptr(q_out), _ptr(k_out), _ptr(vt_out), _ptr(wq_img),
+                                     _ptr(wk_img), _ptr(wq_txt), _ptr(wk_txt), _ptr(cos), _ptr(sin), B, S,
+                                     s_txt, H, S_pad, eps, _stream()), "fk_qkv_post_bf16")
+
+
+def attention(q, k, vt, out, scale=None):
+    """out[b, s, h*128:(h+1)*128] = softmax(q k^T * scale) v.  out: [B,S,>=H*128] view."""
+    _need_cuda(q, k, vt, out)
+    B, H, S, hd = q.shape
+    if hd != 128:
+        raise ValueError("head_dim must be 128")
+    if scale is None:
+        scale = hd ** -0.5
+    lib = libfk.load()
+    libfk.check(lib.fk_attention_fwd_bf16(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), B, H, S, vt.shape[-1],
+                                          out.stride(1), out.stride(0), scale, _stream()),
+                "fk_attention_fwd_bf16")
+    return out
+
+
+def silu(x, out=None):
+    _need_cuda(x)
+    if out is None:
+        out = torch.empty_like(x)
+    libfk.check(libfk.load().fk_silu_bf16(_ptr(x), _ptr(out), x.numel(), _stream()), "fk_silu_bf16")
+    return out
+
+
+def add3(a, b, c, out=None):
+    _need_cuda(a, b, c)
+    if out is None:
+        out = torch.empty_like(a)
+    libfk.check(libfk.load().fk_add3_bf16(_ptr(a), _ptr(b), _ptr(c), _ptr(out), a.numel(), _stream()),
+                "fk_add3_bf16")
+    return out
+
+
+def timestep_proj(v, freqs, out=None):
+    """[B] (bf16 or fp32) -> [B,256] bf16 sinusoid of bf16(v)*1000 (cos first)."""
+    _need_cuda(v, freqs)
+    B = v.shape[0]
+    if v.dtype not in (BF16, torch.float32):
+        raise TypeError("timestep must be bf16 or fp32")
+    if out is None:
+        out = torch.empty((B, 256), device=v.device, dtype=BF16)
+    libfk.check(libfk.load().fk_timestep_proj(_ptr(v), int(v.dtype == torch.float32), _ptr(freqs), _ptr(out),
+                                              B, _stream()), "fk_timestep_proj")
+    return out
+
+
+def euler_step(x, v, s_tgt, dsigma):
+    """In place: x[:, :s_tgt] += bf16(bf16(dsigma) * v[:, :s_tgt]) with the reference's rounding."""
+    _need_cuda(x, v)
+    B, _, C = x.shape
+    libfk.check(libfk.load().fk_euler_step_bf16(_ptr(x), x.stride(0), _ptr(v), v.stride(0), B, s_tgt, C,
+                                                float(dsigma), _stream()), "fk_euler_step_bf16")
+    return x
+
+
+def transpose(src, dst):
+    """dst[b, c, r] = src[b, r, c] for 3-D views with contiguous last dims."""
+    _need_cuda(src, dst)
+    Bn, R, C = src.shape
+    libfk.check(libfk.load().fk_transpose_bf16(_ptr(src), src.stride(1), src.stride(0), _ptr(dst),
+                                               dst.stride(1), dst.stride(0), R, C, Bn, _stream()),
+                "fk_transpose_bf16")
+    return dst
+
+
+def softmax_rows(x, out=None):
+    """fp32 [rows, n] -> bf16 softmax rows."""
+    _need_cuda(x)
+    rows, n = x.shape
+    if out is None:
+        out = torch.empty((rows, n), device=x.device, dtype=BF16)
+    libfk.check(libfk.load().fk_softmax_rows(_ptr(x), x.stride(0), _ptr(out), out.stride(0), rows, n,
+                                             _stream()), "fk_softmax_rows")
+    return out

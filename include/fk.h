@@ -1,0 +1,182 @@
+/*
+ * fk.h -- C ABI of libfk.so: the MI355X (gfx950) native FLUX-Kontext denoiser hot path.
+ *
+ * Drop-in boundary.  The reference (wyhlovecpp/GPT-Image-Edit) is 100 %
+ * Python and reaches this arithmetic through torch/diffusers module calls; it has no FFI of its
+ * own.  Each entry point below therefore names the reference call site / third-party module whose
+ * device work it replaces.  A Python maintainer binds these with ctypes (INTEGRATION.md shows the
+ * stub); nothing here mentions torch types: plain device pointers (from tensor.data_ptr()),
+ * integer sizes/strides in ELEMENTS, scalars, and the hipStream_t to enqueue on.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative FK_E* code; fk_last_error() returns a
+ *     thread-local message for the last failure.  Nothing throws across the ABI.
+ *   - all work is stream-ordered on `stream`; no function synchronises the device or allocates
+ *     device memory: the caller (PyTorch caching allocator) owns every buffer incl. workspaces.
+ *   - bf16 buffers are raw uint16 storage (torch.bfloat16), row-major, inner dimension contiguous
+ *     and 16-byte aligned unless a stride parameter says otherwise.
+ *   - re-entrant; no global mutable state.
+ */
+#ifndef FK_H_
+#define FK_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fk_stream_t; /* hipStream_t */
+
+enum {
+  FK_OK = 0,
+  FK_EINVAL = -1,  /* bad shape / alignment / null pointer */
+  FK_EUNSUPPORTED = -2,
+  FK_ELAUNCH = -3, /* hipLaunch / runtime error */
+};
+
+/* Epilogues of fk_gemm_bf16 (applied in this order; every stage rounds to bf16 exactly where the
+ * reference's bf16 torch graph does):
+ *   y = bf16(acc + bias)                                   (nn.Linear output)
+ *   FK_EPI_GELU_TANH : y = bf16(gelu_tanh(y))              (FeedForward "gelu-approximate")
+ *   FK_EPI_SILU      : y = bf16(silu(y))                   (TimestepEmbedding / PixArtAlphaTextProjection)
+ *   FK_EPI_GATE_RES  : y = bf16(res + bf16(gate[b] * y))   (gate_msa.unsqueeze(1) * attn_out; h + ...)
+ *   FK_EPI_RES       : y = bf16(res + y)                   (ResnetBlock2D / VAE attention residual)
+ *   FK_EPI_SCALE     : y = bf16(alpha * acc)  (no bias)    (attention scores for the VAE mid block)
+ */
+enum {
+  FK_EPI_NONE = 0,
+  FK_EPI_GELU_TANH = 1,
+  FK_EPI_SILU = 2,
+  FK_EPI_GATE_RES = 3,
+  FK_EPI_RES = 4,
+  FK_EPI_SCALE = 5,
+};
+
+/* Row addressing used for A, C and the residual: logical row m lives at
+ *   base + (m / rows_per_batch) * batch_stride + (m % rows_per_batch) * ld        (elements)
+ * so that the text / image streams of a double block can read from and write into slices of one
+ * joint [B, S, *] buffer without copies.  rows_per_batch <= 0 means "one batch" (offset = m*ld). */
+typedef struct fk_rows {
+  int64_t ld;
+  int64_t rows_per_batch;
+  int64_t batch_stride;
+} fk_rows;
+
+/* C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]);  A, W bf16 K-contiguous; fp32 accumulation on MFMA.
+ * Replaces every nn.Linear of FluxTransformer2DModel / FeedForward / AutoencoderKL.Attention
+ * (diffusers 0.32.2; reached from reference univa/utils/flux_pipeline.py:1067-1077).
+ * K % 64 == 0, ldw % 8 == 0, A/W/C row starts 16-byte aligned.  N % 8 == 0 unless out_fp32. */
+typedef struct fk_gemm_args {
+  const void* A; fk_rows a;
+  const void* W; int64_t ldw;
+  const void* bias;              /* bf16 [N] or NULL */
+  void* C; fk_rows c;            /* bf16, or fp32 when out_fp32 (debug/parity: acc + bias only) */
+  const void* res; fk_rows r;    /* FK_EPI_GATE_RES / FK_EPI_RES */
+  const void* gate;              /* bf16, gate row b at gate + b*gate_batch_stride; b = m / gate_rows_per_batch */
+  int64_t gate_batch_stride;
+  int64_t gate_rows_per_batch;
+  int32_t M, N, K;
+  int32_t epilogue;
+  int32_t out_fp32;
+  float alpha;                   /* FK_EPI_SCALE */
+} fk_gemm_args;
+
+int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream);
+
+/* out = LN(x; eps, no affine) * (1 + scale[b]) + shift[b], rows of width D (=3072), bf16 in/out.
+ * Rounds like the reference graph: LN -> bf16, (1+scale) -> bf16, product -> bf16, sum -> bf16.
+ * Replaces AdaLayerNormZero / AdaLayerNormZeroSingle / AdaLayerNormContinuous / norm2 (+modulate)
+ * of diffusers FluxTransformerBlock.
+ * Row m of x / out uses fk_rows addressing; scale/shift row b = m / mod_rows_per_batch at
+ * base + b * mod_batch_stride. */
+int fk_ln_modulate_bf16(const void* x, fk_rows xr, void* out, fk_rows outr, const void* shift,
+                        const void* scale, int64_t mod_batch_stride, int64_t mod_rows_per_batch,
+                        int64_t M, int32_t D, float eps, fk_stream_t stream);
+
+/* QKV post-processing of FluxAttnProcessor2_0: per-head RMSNorm(eps, weight) on q and k
+ * (text rows s < s_txt use the *_added weights), interleaved-pair RoPE in fp32, and re-layout:
+ *   qkv [B, S, 3*H*128] (q | k | v, head-major inside each)  ->
+ *   q_out, k_out [B, H, S, 128] bf16;  vt_out [B, H, 128, S_pad] bf16 (V transposed, zero padded)
+ * cos/sin: fp32 [S, 128].  S_pad % 64 == 0.  head_dim is fixed at 128. */
+int fk_qkv_post_bf16(const void* qkv, void* q_out, void* k_out, void* vt_out, const void* wq_img,
+                     const void* wk_img, const void* wq_txt, const void* wk_txt, const float* cos,
+                     const float* sin, int32_t B, int32_t S, int32_t S_txt, int32_t H, int32_t S_pad,
+                     float eps, fk_stream_t stream);
+
+/* O = softmax(Q K^T * scale) V, non-causal, no mask (F.scaled_dot_product_attention as called by
+ * FluxAttnProcessor2_0).  q, k: [B, H, S, 128]; vt: [B, H, 128, S_pad]; o: rows (b, s) at
+ * o + b*o_batch_stride + s*o_ld, head h at column h*128 -> the [B, S, H*128] layout the next
+ * Linear consumes (o_ld lets the single block write straight into its [attn | mlp] buffer). */
+int fk_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* o, int32_t B, int32_t H,
+                          int32_t S, int32_t S_pad, int64_t o_ld, int64_t o_batch_stride, float scale,
+                          fk_stream_t stream);
+
+/* Elementwise / tiny kernels ------------------------------------------------------------------ */
+/* y = bf16(silu(x)) over n elements (n % 8 == 0). */
+int fk_silu_bf16(const void* x, void* y, int64_t n, fk_stream_t stream);
+/* out[b, :256] = bf16(cat(cos, sin)(bf16(bf16(v[b]) * 1000) * freqs[k])), k < 128:
+ * Timesteps(256, flip_sin_to_cos=True) after the model's `.to(dtype) * 1000`; v bf16 or fp32 [B];
+ * freqs = exp(-ln(1e4) * k / 128) as a device fp32[128] table (computed once by the host). */
+int fk_timestep_proj(const void* v, int32_t v_is_fp32, const float* freqs, void* out, int32_t B,
+                     fk_stream_t stream);
+/* out = bf16(bf16(a + b) + c) over n elements: temb = (T + G) + P. */
+int fk_add3_bf16(const void* a, const void* b, const void* c, void* out, int64_t n, fk_stream_t stream);
+/* FlowMatchEulerDiscreteScheduler.step fused with the pipeline's `noise_pred[:, :S_tgt]` slice:
+ *   x[b, s, :] = bf16(float(x) + float(bf16(bf16(dsigma) * v[b, s, :])))   for s < S_tgt
+ * x rows at x + b*x_batch_stride + s*C, v rows at v + b*v_batch_stride + s*C.
+ * (reference univa/utils/flux_pipeline.py:1078,1099) */
+int fk_euler_step_bf16(void* x, int64_t x_batch_stride, const void* v, int64_t v_batch_stride,
+                       int32_t B, int32_t S_tgt, int32_t C, float dsigma, fk_stream_t stream);
+/* dst[r, c] = src[c, r] for a [R, C] bf16 matrix with leading dimensions lds/ldd (elements);
+ * batched over `batch` with the given batch strides. */
+int fk_transpose_bf16(const void* src, int64_t lds, int64_t src_batch_stride, void* dst, int64_t ldd,
+                      int64_t dst_batch_stride, int32_t R, int32_t C, int32_t batch, fk_stream_t stream);
+/* y[r, :n] = bf16(softmax(x[r, :n])) with fp32 scores x (row strides ldx / ldy in elements), n % 4 == 0,
+ * n <= 16384: the softmax of the VAE mid-block attention (scores kept in fp32 like a fused SDPA). */
+int fk_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t n,
+                    fk_stream_t stream);
+
+/* FLUX AutoencoderKL pieces (diffusers AutoencoderKL; reference flux_pipeline.py:604-611,1127-1129).
+ * Activations are NHWC bf16 with C % 32 == 0 (3- and 16-channel inputs are zero padded to 32). */
+typedef struct fk_conv_args {
+  const void* x;       /* [B, Hin, Win, Cin] bf16 */
+  const void* w;       /* [Cout, KH, KW, Cin] bf16 (repacked from OIHW, Cin zero padded) */
+  const void* bias;    /* bf16 [Cout] */
+  void* y;             /* [B, Hout, Wout, Cout] bf16 */
+  const void* res;     /* optional residual, same layout as y: y = bf16(res + y) */
+  int32_t B, Hin, Win, Cin, Cout;
+  int32_t ksize;       /* 1 or 3 */
+  int32_t stride;      /* 1 or 2 */
+  int32_t pad;         /* 3x3: 1 = symmetric pad 1; 0 with stride 2 = F.pad(x,(0,1,0,1)) then valid conv */
+  int32_t upsample2x;  /* 1: input is nearest-upsampled 2x on the fly (Upsample2D + conv) */
+  int32_t Hout, Wout;
+} fk_conv_args;
+int fk_conv2d_nhwc_bf16(const fk_conv_args* args, fk_stream_t stream);
+
+/* GroupNorm(32 groups, eps) statistics: stats[b, g] = (mean, rstd) fp32; ws: fp32 workspace of
+ * fk_groupnorm_ws_floats(B, HW, C) floats. */
+int64_t fk_groupnorm_ws_floats(int32_t B, int64_t HW, int32_t C);
+int fk_groupnorm_stats_nhwc_bf16(const void* x, float* stats, float* ws, int32_t B, int64_t HW,
+                                 int32_t C, int32_t groups, float eps, fk_stream_t stream);
+/* y = act(bf16((x - mean) * rstd * gamma + beta)); act = SiLU when silu != 0. */
+int fk_groupnorm_apply_nhwc_bf16(const void* x, void* y, const float* stats, const void* gamma,
+                                 const void* beta, int32_t B, int64_t HW, int32_t C, int32_t groups,
+                                 int32_t silu, fk_stream_t stream);
+/* Layout changes at the VAE boundary. src NCHW (fp32 or bf16) -> dst NHWC bf16 with C padded to Cpad,
+ * applying y = x * mul + add (latent un-scaling `z / scaling + shift` of flux_pipeline.py:1128). */
+int fk_nchw_to_nhwc_bf16(const void* src, int32_t src_is_fp32, void* dst, int32_t B, int32_t C,
+                         int32_t Cpad, int32_t H, int32_t W, float mul, float add, fk_stream_t stream);
+/* src NHWC bf16 (channel stride Cpad) -> dst NCHW (fp32 or bf16), first C channels, y = (x + add) * mul
+ * (`(z - shift) * scaling` of flux_pipeline.py:611). */
+int fk_nhwc_to_nchw(const void* src, void* dst, int32_t dst_is_fp32, int32_t B, int32_t C, int32_t Cpad,
+                    int32_t H, int32_t W, float add, float mul, fk_stream_t stream);
+
+const char* fk_last_error(void);
+/* Build identification: "fk <version> gfx950". */
+const char* fk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FK_H_ */

@@ -1,0 +1,158 @@
+"""Generate the committed golden vectors under tests/golden/.  TEST INFRASTRUCTURE.
+
+Run ONLY in the build container (needs /root/reference, which does not exist on the GPU box):
+
+    python oracle/make_golden.py
+
+G1-G3  the four pure helpers of the reference pipeline driver, executed from the reference file
+       itself: the functions are lifted out of ``univa/utils/flux_pipeline.py`` with ``ast`` (the
+       module cannot be imported -- it needs diffusers) and exec'd with only ``torch`` in scope.
+G4     ``univa/utils/anyres_util.py`` imported normally from the reference tree.
+G5     torch's own CPU definitions of the building-block ops the HIP kernels implement.
+G6     end-to-end outputs of THIS repo's oracle on tiny configs (self-pinned, labelled as such;
+       guards the oracle against accidental edits -- it is not evidence about diffusers).
+
+Only inputs and outputs (data) are written; no reference source text is stored.
+"""
+import ast
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def lift_reference_helpers():
+    src = open(os.path.join(REF, "univa/utils/flux_pipeline.py")).read()
+    wanted = {"calculate_shift", "_prepare_latent_image_ids", "_pack_latents", "_unpack_latents"}
+    ns = {"torch": torch}
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.FunctionDef) and node.name in wanted:
+            node.decorator_list = []
+            exec(compile(ast.Module(body=[node], type_ignores=[]), "<reference>", "exec"), ns)
+    assert wanted <= set(ns), sorted(wanted - set(ns))
+    return ns
+
+
+def g_helpers():
+    ns = lift_reference_helpers()
+    g = torch.Generator().manual_seed(1234)
+    out = {}
+    # G1 pack / unpack
+    x = torch.randn(2, 16, 8, 12, generator=g)
+    packed = ns["_pack_latents"](x, 2, 16, 8, 12)
+    out["pack_in"] = x.numpy()
+    out["pack_out"] = packed.numpy()
+    out["unpack_out"] = ns["_unpack_latents"](packed, 64, 96, 8).numpy()
+    y = torch.randn(1, 6, 64, generator=g)  # odd geometry: 2x3 patches
+    out["unpack2_in"] = y.numpy()
+    out["unpack2_out"] = ns["_unpack_latents"](y, 32, 48, 8).numpy()
+    # G2 ids
+    out["ids_4x6"] = ns["_prepare_latent_image_ids"](1, 4, 6, "cpu", torch.float32).numpy()
+    out["ids_64x64_bf16"] = ns["_prepare_latent_image_ids"](3, 64, 64, "cpu", torch.bfloat16).float().numpy()
+    # G3 shift
+    seqs = np.array([256, 1024, 4096, 6000, 1, 3600], dtype=np.int64)
+    out["shift_seq"] = seqs
+    out["shift_mu"] = np.array([ns["calculate_shift"](int(s)) for s in seqs], dtype=np.float64)
+    out["shift_mu_custom"] = np.array(
+        [ns["calculate_shift"](int(s), 256, 4096, 0.5, 1.16) for s in seqs], dtype=np.float64)
+    np.savez(os.path.join(OUT, "helpers.npz"), **out)
+
+
+def g_anyres():
+    sys.path.insert(0, REF)
+    from univa.utils import anyres_util as ref  # importable: needs only PIL + math
+
+    rows = []
+    sizes = [(512, 512), (1024, 1024), (768, 1024), (1024, 768), (480, 854), (1080, 1920), (333, 1000),
+             (1000, 333), (448, 448), (1568, 672), (700, 500), (37, 41)]
+    modes = ["any_17ratio", "any_11ratio", "any_9ratio", "any_7ratio", "any_5ratio", "any_1ratio"]
+    for h, w in sizes:
+        for mi, m in enumerate(modes):
+            for anchor in (512 * 512, 1024 * 1024):
+                rw, rh = ref.pick_ratio(h, w, m)
+                nh, nw = ref.dynamic_resize(h, w, m, anchor_pixels=anchor)
+                ch, cw = ref.compute_size(rw, rh, 32, anchor_pixels=anchor)
+                mh, mw = ref.compute_size(rw, rh, 32, min_pixels=256 * 256, max_pixels=768 * 768)
+                rows.append([h, w, mi, anchor, rw, rh, nh, nw, ch, cw, mh, mw])
+    np.savez(os.path.join(OUT, "anyres.npz"), table=np.array(rows, dtype=np.int64),
+             modes=np.array(modes))
+
+
+def g_torch_ops():
+    g = torch.Generator().manual_seed(99)
+    out = {}
+    x = torch.randn(3, 5, 64, generator=g) * 2
+    out["x"] = x.numpy()
+    out["gelu_tanh"] = F.gelu(x, approximate="tanh").numpy()
+    out["silu"] = F.silu(x).numpy()
+    out["layer_norm"] = F.layer_norm(x, (64,), None, None, 1e-6).numpy()
+    img = torch.randn(2, 64, 6, 5, generator=g)
+    gw, gb = torch.randn(64, generator=g), torch.randn(64, generator=g)
+    out["gn_in"], out["gn_w"], out["gn_b"] = img.numpy(), gw.numpy(), gb.numpy()
+    out["group_norm"] = F.group_norm(img, 32, gw, gb, 1e-6).numpy()
+    q, k, v = (torch.randn(2, 3, 37, 16, generator=g) for _ in range(3))
+    out["q"], out["k"], out["v"] = q.numpy(), k.numpy(), v.numpy()
+    out["sdpa"] = F.scaled_dot_product_attention(q, k, v).numpy()
+    out["nearest2x"] = F.interpolate(img[:, :4], scale_factor=2.0, mode="nearest").numpy()
+    cw, cb = torch.randn(8, 64, 3, 3, generator=g) * 0.1, torch.randn(8, generator=g)
+    out["conv_w"], out["conv_b"] = cw.numpy(), cb.numpy()
+    out["conv3x3"] = F.conv2d(img, cw, cb, padding=1).numpy()
+    out["conv3x3_s2"] = F.conv2d(F.pad(img, (0, 1, 0, 1)), cw, cb, stride=2).numpy()
+    np.savez(os.path.join(OUT, "torch_ops.npz"), **out)
+
+
+def g_oracle_selfpin():
+    from gpt_image_edit_amd import flux_spec
+    from oracle import mmdit, scheduler, vae
+
+    out = {}
+    cfg = dict(num_layers=2, num_single_layers=2, attention_head_dim=16, num_attention_heads=4,
+               joint_attention_dim=32, pooled_projection_dim=24, in_channels=16, out_channels=16,
+               axes_dims_rope=(4, 6, 6))
+    sd = flux_spec.synthetic_state(flux_spec.flux_param_shapes(cfg), seed=3)
+    g = torch.Generator().manual_seed(5)
+    hs = torch.randn(2, 12, 16, generator=g)
+    enc = torch.randn(2, 5, 32, generator=g)
+    pooled = torch.randn(2, 24, generator=g)
+    t = torch.tensor([0.75, 0.31])
+    gd = torch.tensor([3.5, 1.0])
+    from oracle.helpers import prepare_latent_image_ids
+    img_ids = torch.cat([prepare_latent_image_ids(2, 3), prepare_latent_image_ids(2, 3, first=1.0)])
+    txt_ids = torch.zeros(5, 3)
+    y = mmdit.flux_forward(sd, hs, enc, pooled, t, img_ids, txt_ids, gd, config=cfg)
+    out["mmdit_tiny_out"] = y.numpy()
+    cos, sin = mmdit.rope_tables(torch.cat([txt_ids, img_ids]), (4, 6, 6))
+    out["rope_cos"], out["rope_sin"] = cos.numpy(), sin.numpy()
+    out["sinusoid"] = mmdit.sinusoid_256(torch.tensor([0.0, 1.0, 750.0, 3504.0])).numpy()
+
+    vcfg = dict(block_out_channels=(32, 32, 64, 64), latent_channels=4)
+    vsd = flux_spec.synthetic_state(flux_spec.vae_param_shapes(vcfg), seed=4)
+    z = torch.randn(1, 4, 4, 6, generator=g)
+    out["vae_dec_tiny"] = vae.decode(vsd, z).numpy()
+    im = torch.rand(1, 3, 32, 48, generator=g) * 2 - 1
+    out["vae_enc_tiny"] = vae.encode_moments(vsd, im).numpy()
+
+    ts, sg = scheduler.shifted_sigmas(28, 1.15)
+    out["sched_timesteps_mu1.15"], out["sched_sigmas_mu1.15"] = ts.numpy(), sg.numpy()
+    ts, sg = scheduler.shifted_sigmas(4, 0.6289062500000001)
+    out["sched_timesteps_n4"], out["sched_sigmas_n4"] = ts.numpy(), sg.numpy()
+    np.savez(os.path.join(OUT, "oracle_selfpin.npz"), **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(1)  # deterministic reductions for the committed numbers
+    g_helpers()
+    g_anyres()
+    g_torch_ops()
+    g_oracle_selfpin()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

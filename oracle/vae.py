@@ -1,0 +1,102 @@
+"""Oracle: FLUX ``AutoencoderKL`` encode/decode (diffusers 0.32.2).  TEST INFRASTRUCTURE.
+
+PARITY UNPINNED against the real third-party source; restated from SURVEY.md Appendix A.3.
+Reference call sites: ``univa/utils/flux_pipeline.py:604-611`` (encode + ``mode()``),
+``:1127-1129`` (decode); ``train_denoiser.py:428-432,887,895,1505``.
+
+Functional over a flat state dict with the diffusers key names (``encoder.*`` / ``decoder.*``).
+"""
+import torch
+import torch.nn.functional as F
+
+VAE_CONFIG = dict(
+    in_channels=3, out_channels=3, latent_channels=16, block_out_channels=(128, 256, 512, 512),
+    layers_per_block=2, norm_num_groups=32, scaling_factor=0.3611, shift_factor=0.1159,
+)
+
+
+def conv(sd, name, x, stride=1, padding=1):
+    return F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"], stride=stride, padding=padding)
+
+
+def group_norm(sd, name, x, groups=32, eps=1e-6):
+    return F.group_norm(x, groups, sd[name + ".weight"], sd[name + ".bias"], eps)
+
+
+def resnet(sd, p, x):
+    """ResnetBlock2D (no time embedding, output scale 1)."""
+    y = conv(sd, p + "conv1", F.silu(group_norm(sd, p + "norm1", x)))
+    y = conv(sd, p + "conv2", F.silu(group_norm(sd, p + "norm2", y)))
+    if (p + "conv_shortcut.weight") in sd:
+        x = conv(sd, p + "conv_shortcut", x, padding=0)
+    return x + y
+
+
+def mid_attention(sd, p, x):
+    """Single-head (hd = C) spatial self-attention of UNetMidBlock2D with residual."""
+    b, c, hh, ww = x.shape
+    res = x
+    t = x.view(b, c, hh * ww)
+    t = F.group_norm(t, 32, sd[p + "group_norm.weight"], sd[p + "group_norm.bias"], 1e-6).transpose(1, 2)
+    q = F.linear(t, sd[p + "to_q.weight"], sd[p + "to_q.bias"])[:, None]
+    k = F.linear(t, sd[p + "to_k.weight"], sd[p + "to_k.bias"])[:, None]
+    v = F.linear(t, sd[p + "to_v.weight"], sd[p + "to_v.bias"])[:, None]
+    o = F.scaled_dot_product_attention(q, k, v)[:, 0]
+    o = F.linear(o, sd[p + "to_out.0.weight"], sd[p + "to_out.0.bias"])
+    return o.transpose(1, 2).reshape(b, c, hh, ww) + res
+
+
+def mid_block(sd, p, x):
+    x = resnet(sd, p + "resnets.0.", x)
+    x = mid_attention(sd, p + "attentions.0.", x)
+    return resnet(sd, p + "resnets.1.", x)
+
+
+def decode(sd, z):
+    """Decoder: z [B,16,h,w] -> image [B,3,8h,8w] (no latent rescale; the pipeline does that)."""
+    x = conv(sd, "decoder.conv_in", z)
+    x = mid_block(sd, "decoder.mid_block.", x)
+    for i in range(4):
+        for j in range(3):
+            x = resnet(sd, f"decoder.up_blocks.{i}.resnets.{j}.", x)
+        if i < 3:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            x = conv(sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", x)
+    x = F.silu(group_norm(sd, "decoder.conv_norm_out", x))
+    return conv(sd, "decoder.conv_out", x)
+
+
+def encode_moments(sd, x):
+    """Encoder: image [B,3,H,W] -> moments [B,32,H/8,W/8] (mean | logvar)."""
+    x = conv(sd, "encoder.conv_in", x)
+    for i in range(4):
+        for j in range(2):
+            x = resnet(sd, f"encoder.down_blocks.{i}.resnets.{j}.", x)
+        if i < 3:
+            x = F.pad(x, (0, 1, 0, 1), mode="constant", value=0)
+            x = conv(sd, f"encoder.down_blocks.{i}.downsamplers.0.conv", x, stride=2, padding=0)
+    x = mid_block(sd, "encoder.mid_block.", x)
+    x = F.silu(group_norm(sd, "encoder.conv_norm_out", x))
+    return conv(sd, "encoder.conv_out", x)
+
+
+def encode_mode(sd, x):
+    """``vae.encode(x).latent_dist.mode()`` = mean half of the moments."""
+    return encode_moments(sd, x).chunk(2, dim=1)[0]
+
+
+def encode_for_pipeline(sd, image, cfg=VAE_CONFIG):
+    """flux_pipeline.py:600-613: (mode(z) - shift) * scale."""
+    return (encode_mode(sd, image) - cfg["shift_factor"]) * cfg["scaling_factor"]
+
+
+def decode_for_pipeline(sd, latents, cfg=VAE_CONFIG):
+    """flux_pipeline.py:1128-1129: decode(z / scale + shift)."""
+    return decode(sd, latents / cfg["scaling_factor"] + cfg["shift_factor"])
+
+
+def postprocess_uint8(image):
+    """VaeImageProcessor.postprocess(..., 'pil') up to the uint8 array: NHWC uint8."""
+    x = (image / 2 + 0.5).clamp(0, 1)
+    x = x.cpu().permute(0, 2, 3, 1).float().numpy()
+    return (x * 255).round().astype("uint8")

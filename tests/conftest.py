@@ -1,0 +1,44 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+def bf16_ulp_diff(a, b):
+    """Element-wise distance in bf16 ulps between two bf16 tensors (on CPU)."""
+    import torch
+
+    ai = a.contiguous().view(torch.int16).to(torch.int32)
+    bi = b.contiguous().view(torch.int16).to(torch.int32)
+    # map sign-magnitude to a monotonic integer line
+    ai = torch.where(ai < 0, -(ai & 0x7FFF), ai)
+    bi = torch.where(bi < 0, -(bi & 0x7FFF), bi)
+    return (ai - bi).abs()
+
+
+def report(name, got, ref):
+    """Print error statistics (kept in the pytest -s log that comes back from the GPU box)."""
+    import torch
+
+    g, r = got.float().cpu(), ref.float().cpu()
+    d = (g - r).abs()
+    rel = d / (r.abs() + 1e-6)
+    print(f"[parity] {name}: max_abs={d.max().item():.3e} mean_abs={d.mean().item():.3e} "
+          f"max_rel={rel.max().item():.3e} ref_absmax={r.abs().max().item():.3e} "
+          f"nan={int(torch.isnan(g).sum())}", flush=True)
+    return d

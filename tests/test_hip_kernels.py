@@ -1,0 +1,226 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (libfk.so).
+
+Oracle = the CPU restatement under oracle/ (torch fp32 / bf16 on the host), fed the same seeded
+bf16-rounded inputs.  Tolerances:
+  * fp32 debug outputs vs the fp32 oracle: rtol 1e-3 / atol 1e-4 (the tolerance BASELINE.json states);
+  * bf16 outputs vs the oracle evaluated with the reference's bf16 rounding points: <= 1 bf16 ulp
+    on (nearly) all elements -- two correct bf16 implementations with different accumulation order
+    cannot agree tighter than that.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import bf16_ulp_diff, report
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd import ops as _ops
+    from gpt_image_edit_amd import libfk
+    print("libfk:", libfk.load().fk_version().decode())
+    return _ops
+
+
+def randn(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def assert_bf16_close(name, got, ref, max_ulp=1, frac_exact=0.0, max_bad_frac=0.0):
+    got, ref = got.cpu(), ref.cpu()
+    report(name, got, ref)
+    ulp = bf16_ulp_diff(got, ref)
+    bad = (ulp > max_ulp).float().mean().item()
+    exact = (ulp == 0).float().mean().item()
+    print(f"[parity] {name}: exact={exact:.4f} frac(>{max_ulp}ulp)={bad:.2e} max_ulp={int(ulp.max())}", flush=True)
+    assert not torch.isnan(got.float()).any()
+    assert bad <= max_bad_frac, f"{name}: {bad:.3e} of elements differ by more than {max_ulp} bf16 ulp"
+    assert exact >= frac_exact
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 200, 192), (77, 64, 3072),
+                                   (1, 3072, 256), (2560, 3072, 3072), (1024, 64, 3072), (4096, 3072, 64)])
+def test_gemm_fp32_out(ops, M, N, K):
+    a, w, bias = randn(M, K, seed=1), randn(N, K, seed=2, scale=0.05), randn(N, seed=3, scale=0.1)
+    got = ops.gemm(a.cuda(), w.cuda(), bias.cuda(), out_fp32=True)
+    torch.cuda.synchronize()
+    ref = a.float() @ w.float().T + bias.float()
+    report(f"gemm_f32 {M}x{N}x{K}", got, ref)
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-3, atol=1e-4)
+
+
+def test_gemm_layout_is_transpose_detecting(ops):
+    # A = identity-like selector with an asymmetric W: catches row/col swaps of the MFMA C layout
+    M = N = 128
+    K = 128
+    a = torch.zeros(M, K)
+    a[torch.arange(M), torch.arange(M) % K] = 1.0
+    w = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) / 64.0
+    got = ops.gemm(a.to(BF).cuda(), w.to(BF).cuda(), None, out_fp32=True).cpu()
+    ref = a.to(BF).float() @ w.to(BF).float().T
+    torch.testing.assert_close(got, ref, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("epi", ["none", "gelu", "silu", "scale"])
+def test_gemm_bf16_epilogues(ops, epi):
+    M, N, K = 384, 512, 256
+    a, w, bias = randn(M, K, seed=4), randn(N, K, seed=5, scale=0.06), randn(N, seed=6, scale=0.2)
+    y = (a.float() @ w.float().T + bias.float())
+    if epi == "none":
+        got = ops.gemm(a.cuda(), w.cuda(), bias.cuda())
+        ref = y.to(BF)
+    elif epi == "gelu":
+        got = ops.gemm(a.cuda(), w.cuda(), bias.cuda(), epilogue=ops.FK_EPI_GELU_TANH)
+        ref = F.gelu(y.to(BF), approximate="tanh")
+    elif epi == "silu":
+        got = ops.gemm(a.cuda(), w.cuda(), bias.cuda(), epilogue=ops.FK_EPI_SILU)
+        ref = F.silu(y.to(BF))
+    else:
+        got = ops.gemm(a.cuda(), w.cuda(), None, epilogue=ops.FK_EPI_SCALE, alpha=0.125)
+        ref = (0.125 * (a.float() @ w.float().T)).to(BF)
+    assert_bf16_close(f"gemm_bf16[{epi}]", got, ref, max_ulp=1, max_bad_frac=1e-4)
+
+
+def test_gemm_gate_residual_strided_views(ops):
+    # text / image streams living in one joint [B, S, D] buffer, like the double block uses them
+    B, S_txt, S_img, D, K = 2, 40, 216, 256, 128
+    S = S_txt + S_img
+    a_joint = randn(B, S, K, seed=7)
+    w, bias = randn(D, K, seed=8, scale=0.08), randn(D, seed=9, scale=0.1)
+    res = randn(B, S_img, D, seed=10)
+    mod = randn(B, 6 * D, seed=11, scale=0.5)
+    gate = mod[:, 2 * D:3 * D]
+    a_dev, res_dev, mod_dev = a_joint.cuda(), res.cuda(), mod.cuda()
+    out = res_dev  # in place, like h = h + gate * proj(o_img)
+    ops.gemm(a_dev[:, S_txt:], w.cuda(), bias.cuda(), out=out, epilogue=ops.FK_EPI_GATE_RES, res=res_dev,
+             gate=mod_dev[:, 2 * D:3 * D])
+    y = (a_joint[:, S_txt:].float() @ w.float().T + bias.float()).to(BF)
+    ref = res + gate[:, None] * y
+    assert_bf16_close("gemm_gate_res", out, ref, max_ulp=1, max_bad_frac=2e-3)
+    # plain residual + write into a column slice of a wider buffer (single block's [attn | mlp] buffer)
+    wide = torch.zeros(B, S, 3 * D, dtype=BF, device="cuda")
+    ops.gemm(a_dev, w.cuda(), bias.cuda(), out=wide[:, :, D:2 * D], epilogue=ops.FK_EPI_GELU_TANH)
+    ref2 = F.gelu((a_joint.float() @ w.float().T + bias.float()).to(BF), approximate="tanh")
+    assert_bf16_close("gemm_col_slice", wide[:, :, D:2 * D].contiguous(), ref2, max_ulp=1, max_bad_frac=1e-4)
+    assert wide[:, :, :D].abs().max().item() == 0 and wide[:, :, 2 * D:].abs().max().item() == 0
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    a, w = randn(64, 96).cuda(), randn(64, 96).cuda()  # K = 96 is not a multiple of 64
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.gemm(a, w)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gemm(randn(64, 64), randn(64, 64))
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D", [3072, 512])
+def test_ln_modulate(ops, D):
+    from oracle import mmdit
+    B, R = 2, 37
+    x = randn(B, R, D, seed=12, scale=2.0) + 0.5
+    mod = randn(B, 6 * D, seed=13, scale=0.3)
+    shift, scale = mod[:, :D], mod[:, D:2 * D]
+    md = mod.cuda()
+    got = ops.ln_modulate(x.cuda(), md[:, :D], md[:, D:2 * D])
+    ref = mmdit.layer_norm(x) * (1 + scale[:, None]) + shift[:, None]
+    assert ref.dtype == BF
+    assert_bf16_close(f"ln_modulate D={D}", got, ref, max_ulp=1, max_bad_frac=2e-3)
+    ref32 = mmdit.layer_norm(x.float()) * (1 + scale.float()[:, None]) + shift.float()[:, None]
+    d = report("ln_modulate vs fp32", got, ref32)
+    assert d.max().item() < 0.1
+
+
+def test_qkv_post(ops):
+    from oracle import mmdit
+    from oracle.helpers import prepare_latent_image_ids
+    B, H, S_txt, hh, ww = 2, 3, 21, 6, 9
+    S = S_txt + hh * ww  # 75: not a multiple of 64
+    S_pad = (S + 63) // 64 * 64
+    qkv = randn(B, S, 3 * H * 128, seed=14)
+    wq_i, wk_i, wq_t, wk_t = [(1 + randn(128, seed=15 + i, scale=0.1).float()).to(BF) for i in range(4)]
+    ids = torch.cat([torch.zeros(S_txt, 3), prepare_latent_image_ids(hh, ww)])
+    cos, sin = mmdit.rope_tables(ids)
+    q = torch.empty(B, H, S, 128, dtype=BF, device="cuda")
+    k = torch.empty_like(q)
+    vt = torch.full((B, H, 128, S_pad), 7.0, dtype=BF, device="cuda")
+    ops.qkv_post(qkv.cuda(), q, k, vt, wq_i.cuda(), wk_i.cuda(), wq_t.cuda(), wk_t.cuda(), cos.cuda(),
+                 sin.cuda(), S_txt)
+    D = H * 128
+    def ref_qk(x, w_t, w_i):
+        x = mmdit.heads(x, H)
+        x = torch.cat([mmdit.rms_norm(x[:, :, :S_txt], w_t), mmdit.rms_norm(x[:, :, S_txt:], w_i)], dim=2)
+        return mmdit.apply_rope(x, cos, sin)
+    assert_bf16_close("qkv_post q", q, ref_qk(qkv[..., :D], wq_t, wq_i), max_ulp=1, max_bad_frac=2e-3)
+    assert_bf16_close("qkv_post k", k, ref_qk(qkv[..., D:2 * D], wk_t, wk_i), max_ulp=1, max_bad_frac=2e-3)
+    v_ref = mmdit.heads(qkv[..., 2 * D:], H).transpose(2, 3)  # [B,H,128,S]
+    assert torch.equal(vt[..., :S].cpu(), v_ref)
+    assert vt[..., S:].abs().max().item() == 0  # zero padding
+
+
+@pytest.mark.parametrize("B,H,S", [(1, 2, 64), (2, 3, 75), (1, 2, 300), (1, 24, 2560), (1, 1, 1000)])
+def test_attention(ops, B, H, S):
+    q, k, v = randn(B, H, S, 128, seed=20), randn(B, H, S, 128, seed=21), randn(B, H, S, 128, seed=22)
+    if S == 300:  # spike a few keys so the running max jumps mid-sequence (online-softmax rescale)
+        k[:, :, 200] = q[:, :, 17] * 2.0
+        k[:, :, 290] = q[:, :, 150] * 3.0
+    S_pad = (S + 63) // 64 * 64
+    vt = torch.zeros(B, H, 128, S_pad, dtype=BF)
+    vt[..., :S] = v.transpose(2, 3)
+    out = torch.zeros(B, S, H * 128 + 64, dtype=BF, device="cuda")  # wider row stride than H*128
+    ops.attention(q.cuda(), k.cuda(), vt.cuda(), out)
+    torch.cuda.synchronize()
+    ref = F.scaled_dot_product_attention(q.float(), k.float(), v.float())  # fp32 oracle on bf16 inputs
+    ref = ref.transpose(1, 2).reshape(B, S, H * 128)
+    d = report(f"attention B{B} H{H} S{S}", out[..., :H * 128], ref)
+    assert out[..., H * 128:].abs().max().item() == 0
+    # P is rounded to bf16 before the PV product and O to bf16 at the end: ~2^-8 relative per term
+    assert d.max().item() < 3e-2 and d.mean().item() < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_small_kernels(ops):
+    from oracle import mmdit, scheduler
+    x = randn(4, 3072, seed=30, scale=3.0)
+    assert_bf16_close("silu", ops.silu(x.cuda()), F.silu(x), max_ulp=1, max_bad_frac=1e-3)
+    a, b, c = randn(2, 3072, seed=31), randn(2, 3072, seed=32), randn(2, 3072, seed=33)
+    assert_bf16_close("add3", ops.add3(a.cuda(), b.cuda(), c.cuda()), (a + b) + c, max_ulp=0)
+    # timestep projection: model does timestep.to(bf16) * 1000 then the fp32 sinusoid, cast to bf16
+    t = torch.tensor([1.0, 0.8516, 0.03125, 0.5], dtype=BF)
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(128, dtype=torch.float32) / 128)
+    got = ops.timestep_proj(t.cuda(), freqs.cuda())
+    ref = mmdit.sinusoid_256(t * 1000).to(BF)
+    assert_bf16_close("timestep_proj bf16", got, ref, max_ulp=1, max_bad_frac=0.02)
+    g = torch.tensor([3.5, 1.0, 2.25, 7.0])
+    got = ops.timestep_proj(g.cuda(), freqs.cuda())
+    ref = mmdit.sinusoid_256(g.to(BF) * 1000).to(BF)
+    assert_bf16_close("timestep_proj fp32", got, ref, max_ulp=1, max_bad_frac=0.02)
+    # Euler step with the slice fused
+    xs = randn(2, 24, 64, seed=34)
+    v = randn(2, 24, 64, seed=35)
+    ts, sg = scheduler.shifted_sigmas(28, 1.15)
+    x_dev = xs.cuda()
+    ops.euler_step(x_dev, v.cuda(), 16, float(sg[4] - sg[3]))
+    ref = xs.clone()
+    ref[:, :16] = scheduler.euler_step(v[:, :16], sg[3], sg[4], xs[:, :16])
+    assert_bf16_close("euler", x_dev, ref, max_ulp=0)
+    # transpose
+    m = randn(3, 70, 130, seed=36)
+    dst = torch.empty(3, 130, 70, dtype=BF, device="cuda")
+    ops.transpose(m.cuda(), dst)
+    assert torch.equal(dst.cpu(), m.transpose(1, 2))
+    # row softmax (fp32 scores -> bf16 probabilities)
+    for n in (64, 1000, 4096, 16384):
+        s = torch.randn(5, n, generator=torch.Generator().manual_seed(n)) * 4
+        got = ops.softmax_rows(s.cuda())
+        assert_bf16_close(f"softmax n={n}", got, torch.softmax(s, -1).to(BF), max_ulp=1, max_bad_frac=1e-3)
