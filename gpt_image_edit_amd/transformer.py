@@ -1,0 +1,274 @@
+"""HipFluxTransformer2DModel -- the MI355X-native FLUX-Kontext MMDiT behind the reference's seam.
+
+Drop-in for the ``transformer=`` object the reference injects into its pipeline
+(``FluxKontextPipeline.from_pretrained(flux_path, transformer=denoiser, ...)``, reference
+``univa/serve/cli.py:64-68``) and for ``model.denoise_tower.denoiser``
+(``univa/models/modeling_univa_denoise_tower.py:21``): same call signature as the pipeline uses at
+``univa/utils/flux_pipeline.py:1067-1077``, same ``.config.in_channels / .guidance_embeds``, ``.dtype``,
+and the diffusers state-dict key names, so real checkpoints load unchanged.
+
+All arithmetic runs in libfk.so (hand-written gfx950 HIP kernels) through the C ABI; torch only
+owns the device buffers.  There is no eager / CPU fallback: without a GPU + libfk.so it raises.
+
+Per denoise step the forward issues, on the current HIP stream and with no host sync:
+  embedders (skinny GEMMs) -> ONE modulation GEMM for all 57 blocks -> 19 double blocks
+  {2 LN+modulate, 2 fused-QKV GEMMs, qkv_post, attention, 2 gated out-proj GEMMs, 2 LN+modulate,
+   4 MLP GEMMs} -> 38 single blocks {LN+modulate, QKV GEMM, MLP-up GEMM(+GELU), qkv_post, attention,
+   gated proj_out GEMM over [attn | mlp]} -> final LN+modulate -> proj_out.
+Text and image streams live in ONE [B, S, D] residual buffer (text rows first), so the double->single
+transition needs no concatenation and attention always sees one contiguous sequence.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from . import flux_spec, ops
+
+BF16 = torch.bfloat16
+
+
+def rope_tables(ids, axes_dim=(16, 56, 56), theta=10000.0):
+    """Host-side FluxPosEmbed (step-invariant, computed once per call shape): ids [S,3] -> cos, sin
+    fp32 [S, sum(axes_dim)], frequencies in fp64 like diffusers."""
+    pos = ids.detach().to("cpu", torch.float32)
+    cos_parts, sin_parts = [], []
+    for i, d in enumerate(axes_dim):
+        inv = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64) / d))
+        ang = pos[:, i].to(torch.float64)[:, None] * inv[None, :]
+        cos_parts.append(torch.repeat_interleave(torch.cos(ang), 2, dim=1).float())
+        sin_parts.append(torch.repeat_interleave(torch.sin(ang), 2, dim=1).float())
+    return torch.cat(cos_parts, dim=1).contiguous(), torch.cat(sin_parts, dim=1).contiguous()
+
+
+class HipFluxTransformer2DModel(nn.Module):
+    def __init__(self, config=None, device="cuda", dtype=BF16, init="empty", seed=0):
+        super().__init__()
+        if dtype != BF16:
+            raise ValueError("the HIP path computes in bf16 (fp32 accumulate); dtype must be torch.bfloat16")
+        cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG)
+        cfg.update(config or {})
+        self.config = SimpleNamespace(**cfg)
+        self.num_heads = cfg["num_attention_heads"]
+        if cfg["attention_head_dim"] != 128:
+            raise ValueError("attention_head_dim must be 128 (kernel tiling)")
+        self.inner_dim = self.num_heads * 128
+        shapes = flux_spec.flux_param_shapes(cfg)
+        if init == "synthetic":
+            state = flux_spec.synthetic_state(shapes, seed=seed, device=device, dtype=dtype,
+                                              gen_device="cuda" if str(device).startswith("cuda") else None)
+        else:
+            state = {k: torch.empty(s, device=device, dtype=dtype) for k, s in shapes.items()}
+        self._names = list(shapes.keys())
+        for k, v in state.items():
+            self.register_parameter(k.replace(".", "__"), nn.Parameter(v, requires_grad=False))
+        self._packed = None
+        self._ws = {}
+        self._rope_cache = {}
+        self._freqs = None
+
+    # ---- state dict with the diffusers key names --------------------------------------------------------
+    def p(self, name):
+        return getattr(self, name.replace(".", "__"))
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        return type(sd)((k.replace("__", "."), v) for k, v in sd.items())
+
+    def load_state_dict(self, state_dict, strict=True, **kwargs):
+        self._packed = None
+        return super().load_state_dict({k.replace(".", "__"): v for k, v in state_dict.items()}, strict=strict, **kwargs)
+
+    @property
+    def dtype(self):
+        return BF16
+
+    @property
+    def device(self):
+        return self.p("x_embedder.weight").device
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        self._ws = {}
+        self._rope_cache = {}
+        self._freqs = None
+        return super()._apply(fn, *a, **k)
+
+    # ---- one-time weight packing (fused QKV, all-block modulation) -----------------------------------------
+    def pack_weights(self):
+        c, D = self.config, self.inner_dim
+        pk = SimpleNamespace(double=[], single=[])
+        mod_w, mod_b, off = [], [], 0
+        for i in range(c.num_layers):
+            p = f"transformer_blocks.{i}."
+            blk = SimpleNamespace()
+            blk.wqkv_img = torch.cat([self.p(p + f"attn.{n}.weight") for n in ("to_q", "to_k", "to_v")]).contiguous()
+            blk.bqkv_img = torch.cat([self.p(p + f"attn.{n}.bias") for n in ("to_q", "to_k", "to_v")]).contiguous()
+            blk.wqkv_txt = torch.cat([self.p(p + f"attn.{n}.weight") for n in ("add_q_proj", "add_k_proj", "add_v_proj")]).contiguous()
+            blk.bqkv_txt = torch.cat([self.p(p + f"attn.{n}.bias") for n in ("add_q_proj", "add_k_proj", "add_v_proj")]).contiguous()
+            blk.mod_img, blk.mod_txt = off, off + 6 * D
+            off += 12 * D
+            mod_w += [self.p(p + "norm1.linear.weight"), self.p(p + "norm1_context.linear.weight")]
+            mod_b += [self.p(p + "norm1.linear.bias"), self.p(p + "norm1_context.linear.bias")]
+            pk.double.append(blk)
+        for i in range(c.num_single_layers):
+            p = f"single_transformer_blocks.{i}."
+            blk = SimpleNamespace()
+            blk.wqkv = torch.cat([self.p(p + f"attn.{n}.weight") for n in ("to_q", "to_k", "to_v")]).contiguous()
+            blk.bqkv = torch.cat([self.p(p + f"attn.{n}.bias") for n in ("to_q", "to_k", "to_v")]).contiguous()
+            blk.mod = off
+            off += 3 * D
+            mod_w.append(self.p(p + "norm.linear.weight"))
+            mod_b.append(self.p(p + "norm.linear.bias"))
+            pk.single.append(blk)
+        pk.mod_out = off
+        off += 2 * D
+        mod_w.append(self.p("norm_out.linear.weight"))
+        mod_b.append(self.p("norm_out.linear.bias"))
+        pk.mod_w = torch.cat(mod_w).contiguous()
+        pk.mod_b = torch.cat(mod_b).contiguous()
+        pk.mod_total = off
+        self._packed = pk
+        return pk
+
+    # ---- per-shape workspace (allocated once; the hot loop never allocates) -------------------------------
+    def _workspace(self, B, S_txt, S_img):
+        key = (B, S_txt, S_img)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        dev, D, H = self.device, self.inner_dim, self.num_heads
+        S = S_txt + S_img
+        S_pad = (S + 63) // 64 * 64
+        e = lambda *shape: torch.empty(shape, device=dev, dtype=BF16)  # noqa: E731
+        ws = SimpleNamespace(
+            S=S, S_pad=S_pad,
+            s=e(B, S, D), n=e(B, S, D), qkv=e(B, S, 3 * D), q=e(B, H, S, 128), k=e(B, H, S, 128),
+            vt=e(B, H, 128, S_pad), o=e(B, S, D), ff=e(B, S, 4 * D), cat=e(B, S, 5 * D),
+            mod=e(B, self._packed.mod_total), temb=e(B, D), act=e(B, D), tproj=e(B, 256), e1=e(B, D),
+            t_emb=e(B, D), g_emb=e(B, D), p_emb=e(B, D), out=e(B, S_img, self.config.out_channels),
+        )
+        self._ws = {key: ws}  # keep only the latest shape
+        return ws
+
+    def _rope(self, txt_ids, img_ids):
+        key = (txt_ids.shape[0], img_ids.shape[0], float(img_ids.float().sum()), float(txt_ids.float().sum()))
+        hit = self._rope_cache.get(key)
+        if hit is None:
+            if txt_ids.dim() == 3:
+                txt_ids = txt_ids[0]
+            if img_ids.dim() == 3:
+                img_ids = img_ids[0]
+            ids = torch.cat([txt_ids.float().cpu(), img_ids.float().cpu()], dim=0)
+            cos, sin = rope_tables(ids, self.config.axes_dims_rope)
+            hit = (cos.to(self.device), sin.to(self.device))
+            self._rope_cache = {key: hit}
+        return hit
+
+    # ---- forward ----------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None,
+                img_ids=None, txt_ids=None, guidance=None, joint_attention_kwargs=None, return_dict=True,
+                **unused):
+        """Same arguments as diffusers' FluxTransformer2DModel.forward as called by the reference
+        pipeline (flux_pipeline.py:1067-1077).  ``timestep`` is t/1000.  Returns ``(sample,)``."""
+        if not hidden_states.is_cuda:
+            raise RuntimeError("HipFluxTransformer2DModel needs GPU tensors: there is no CPU fallback")
+        if joint_attention_kwargs and joint_attention_kwargs.get("attention_mask") is not None:
+            raise NotImplementedError("attention_mask (multi-resolution training batches) is not supported")
+        c, D, H = self.config, self.inner_dim, self.num_heads
+        pk = self._packed or self.pack_weights()
+        B, S_img, _ = hidden_states.shape
+        S_txt = encoder_hidden_states.shape[1]
+        ws = self._workspace(B, S_txt, S_img)
+        cos, sin = self._rope(txt_ids, img_ids)
+        if cos.shape[0] != ws.S:
+            raise ValueError(f"txt_ids + img_ids give {cos.shape[0]} positions for a sequence of {ws.S}")
+        if self._freqs is None:
+            self._freqs = torch.exp(-math.log(10000.0) * torch.arange(128, dtype=torch.float32) / 128).to(self.device)
+        hs = hidden_states.to(BF16).contiguous()
+        enc = encoder_hidden_states.to(BF16).contiguous()
+        pooled = pooled_projections.to(BF16).contiguous()
+        P = self.p
+        s, n = ws.s, ws.n
+        h, cx = s[:, S_txt:], s[:, :S_txt]          # image / text residual streams (views)
+        n_img, n_txt = n[:, S_txt:], n[:, :S_txt]
+
+        # -- embedders -------------------------------------------------------------------------------
+        ops.gemm(hs, P("x_embedder.weight"), P("x_embedder.bias"), out=h)
+        ops.gemm(enc, P("context_embedder.weight"), P("context_embedder.bias"), out=cx)
+        te = "time_text_embed."
+        ops.timestep_proj(timestep if timestep.dtype in (BF16, torch.float32) else timestep.float(), self._freqs, out=ws.tproj)
+        ops.gemm(ws.tproj, P(te + "timestep_embedder.linear_1.weight"), P(te + "timestep_embedder.linear_1.bias"), out=ws.e1, epilogue=ops.FK_EPI_SILU)
+        ops.gemm(ws.e1, P(te + "timestep_embedder.linear_2.weight"), P(te + "timestep_embedder.linear_2.bias"), out=ws.t_emb)
+        if c.guidance_embeds:
+            if guidance is None:
+                raise ValueError("guidance is required when config.guidance_embeds is True")
+            ops.timestep_proj(guidance if guidance.dtype in (BF16, torch.float32) else guidance.float(), self._freqs, out=ws.tproj)
+            ops.gemm(ws.tproj, P(te + "guidance_embedder.linear_1.weight"), P(te + "guidance_embedder.linear_1.bias"), out=ws.e1, epilogue=ops.FK_EPI_SILU)
+            ops.gemm(ws.e1, P(te + "guidance_embedder.linear_2.weight"), P(te + "guidance_embedder.linear_2.bias"), out=ws.g_emb)
+        else:
+            ws.g_emb.zero_()
+        ops.gemm(pooled, P(te + "text_embedder.linear_1.weight"), P(te + "text_embedder.linear_1.bias"), out=ws.e1, epilogue=ops.FK_EPI_SILU)
+        ops.gemm(ws.e1, P(te + "text_embedder.linear_2.weight"), P(te + "text_embedder.linear_2.bias"), out=ws.p_emb)
+        ops.add3(ws.t_emb, ws.g_emb, ws.p_emb, out=ws.temb)
+        # -- every block's modulation vectors in one weight-streaming GEMM ----------------------------
+        ops.silu(ws.temb, out=ws.act)
+        ops.gemm(ws.act, pk.mod_w, pk.mod_b, out=ws.mod)
+        mod = ws.mod
+
+        def chunk(off, j):
+            return mod[:, off + j * D: off + (j + 1) * D]
+
+        # -- double-stream blocks ----------------------------------------------------------------------
+        for i, blk in enumerate(pk.double):
+            p = f"transformer_blocks.{i}."
+            mi, mt = blk.mod_img, blk.mod_txt  # chunks: shift, scale, gate, shift_mlp, scale_mlp, gate_mlp
+            ops.ln_modulate(h, chunk(mi, 0), chunk(mi, 1), out=n_img)
+            ops.ln_modulate(cx, chunk(mt, 0), chunk(mt, 1), out=n_txt)
+            ops.gemm(n_img, blk.wqkv_img, blk.bqkv_img, out=ws.qkv[:, S_txt:])
+            ops.gemm(n_txt, blk.wqkv_txt, blk.bqkv_txt, out=ws.qkv[:, :S_txt])
+            ops.qkv_post(ws.qkv, ws.q, ws.k, ws.vt, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"),
+                         P(p + "attn.norm_added_q.weight"), P(p + "attn.norm_added_k.weight"), cos, sin, S_txt)
+            ops.attention(ws.q, ws.k, ws.vt, ws.o)
+            ops.gemm(ws.o[:, S_txt:], P(p + "attn.to_out.0.weight"), P(p + "attn.to_out.0.bias"), out=h,
+                     epilogue=ops.FK_EPI_GATE_RES, res=h, gate=chunk(mi, 2))
+            ops.ln_modulate(h, chunk(mi, 3), chunk(mi, 4), out=n_img)
+            ops.gemm(n_img, P(p + "ff.net.0.proj.weight"), P(p + "ff.net.0.proj.bias"), out=ws.ff[:, S_txt:],
+                     epilogue=ops.FK_EPI_GELU_TANH)
+            ops.gemm(ws.ff[:, S_txt:], P(p + "ff.net.2.weight"), P(p + "ff.net.2.bias"), out=h,
+                     epilogue=ops.FK_EPI_GATE_RES, res=h, gate=chunk(mi, 5))
+            ops.gemm(ws.o[:, :S_txt], P(p + "attn.to_add_out.weight"), P(p + "attn.to_add_out.bias"), out=cx,
+                     epilogue=ops.FK_EPI_GATE_RES, res=cx, gate=chunk(mt, 2))
+            ops.ln_modulate(cx, chunk(mt, 3), chunk(mt, 4), out=n_txt)
+            ops.gemm(n_txt, P(p + "ff_context.net.0.proj.weight"), P(p + "ff_context.net.0.proj.bias"),
+                     out=ws.ff[:, :S_txt], epilogue=ops.FK_EPI_GELU_TANH)
+            ops.gemm(ws.ff[:, :S_txt], P(p + "ff_context.net.2.weight"), P(p + "ff_context.net.2.bias"), out=cx,
+                     epilogue=ops.FK_EPI_GATE_RES, res=cx, gate=chunk(mt, 5))
+
+        # -- single-stream blocks on the joint sequence ------------------------------------------------------
+        for i, blk in enumerate(pk.single):
+            p = f"single_transformer_blocks.{i}."
+            m0 = blk.mod  # chunks: shift, scale, gate
+            ops.ln_modulate(s, chunk(m0, 0), chunk(m0, 1), out=n)
+            ops.gemm(n, blk.wqkv, blk.bqkv, out=ws.qkv)
+            ops.gemm(n, P(p + "proj_mlp.weight"), P(p + "proj_mlp.bias"), out=ws.cat[:, :, D:],
+                     epilogue=ops.FK_EPI_GELU_TANH)
+            ops.qkv_post(ws.qkv, ws.q, ws.k, ws.vt, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"),
+                         None, None, cos, sin, 0)
+            ops.attention(ws.q, ws.k, ws.vt, ws.cat[:, :, :D])
+            ops.gemm(ws.cat, P(p + "proj_out.weight"), P(p + "proj_out.bias"), out=s,
+                     epilogue=ops.FK_EPI_GATE_RES, res=s, gate=chunk(m0, 2))
+
+        # -- output head: AdaLayerNormContinuous (scale first, then shift) + proj_out -----------------------
+        ops.ln_modulate(h, chunk(pk.mod_out, 1), chunk(pk.mod_out, 0), out=n_img)
+        ops.gemm(n_img, P("proj_out.weight"), P("proj_out.bias"), out=ws.out)
+        sample = ws.out
+        if not return_dict:
+            return (sample,)
+        return SimpleNamespace(sample=sample)
+
+    # reference training code calls this on the denoiser (train_denoiser.py:486); inference-only here
+    def enable_gradient_checkpointing(self):
+        raise NotImplementedError("training (cfg 5) is a later row of SURVEY.md section 8(f)")
