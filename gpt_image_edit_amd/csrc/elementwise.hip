@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* src, int64
   }
 }
 
-// Row softmax: fp32 scores in, bf16 probabilities out; one block (256 threads) per row, n <= 16384.
+// Row softmax: fp32 scores in, bf16 probabilities out; one block (256 threads) per row, n <= 32768.
 template <int NV>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* x, bf16_t* y, int64_t ldx,
                                                            int64_t ldy, int n) {
@@ -197,14 +197,15 @@ extern "C" int fk_transpose_bf16(const void* src, int64_t lds, int64_t src_batch
 
 extern "C" int fk_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t n,
                                fk_stream_t stream) {
-  FK_CHECK_ARG(x && y && rows > 0 && n > 0 && n % 4 == 0 && n <= 16384, "fk_softmax_rows: n must be a multiple of 4, <= 16384");
+  FK_CHECK_ARG(x && y && rows > 0 && n > 0 && n % 4 == 0 && n <= 32768, "fk_softmax_rows: n must be a multiple of 4, <= 32768");
   FK_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 8 == 0),
                "fk_softmax_rows: alignment");
   const dim3 grid((unsigned)rows), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (n <= 1024) hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, block, 0, s, x, (bf16_t*)y, ldx, ldy, n);
   else if (n <= 4096) hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, block, 0, s, x, (bf16_t*)y, ldx, ldy, n);
-  else hipLaunchKernelGGL(softmax_rows_kernel<16>, grid, block, 0, s, x, (bf16_t*)y, ldx, ldy, n);
+  else if (n <= 16384) hipLaunchKernelGGL(softmax_rows_kernel<16>, grid, block, 0, s, x, (bf16_t*)y, ldx, ldy, n);
+  else hipLaunchKernelGGL(softmax_rows_kernel<32>, grid, block, 0, s, x, (bf16_t*)y, ldx, ldy, n);
   FK_CHECK_LAUNCH("fk_softmax_rows");
   return FK_OK;
 }

@@ -32,6 +32,13 @@ struct TileCoord {
   int tm, tn;
 };
 
+// Implicit-GEMM view of a 2-D convolution over NHWC activations (VAE, K9 in SURVEY.md 2.2):
+// row m = output pixel (b, oh, ow); K index k = (kh*KW + kw)*Cin + ci; W repacked to [Cout, Kpad].
+struct ConvGeom {
+  int Hin, Win, Cin, Hout, Wout;
+  int ksize, stride, pad, upsample;
+};
+
 FK_DEV TileCoord map_tile(int bid, int nwg, int nbm, int nbn) {
   // bijective XCD chunking (cdna guide T1): XCD x gets a contiguous run of the tile list
   const int q = nwg >> 3, r = nwg & 7;
@@ -49,8 +56,8 @@ FK_DEV TileCoord map_tile(int bid, int nwg, int nbm, int nbn) {
   return c;
 }
 
-template <int EPI, bool OUT_F32>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const fk_gemm_args p) {
+template <int EPI, bool OUT_F32, bool CONV>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const fk_gemm_args p, const ConvGeom g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -67,21 +74,50 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const fk_gemm_ar
   const int kc = tid & 7;       // 16-byte chunk inside the 128-byte K slice
   const bf16_t* a_ptr[4];
   const bf16_t* w_ptr[4];
+  int c_pix[4], c_ih[4], c_iw[4];  // CONV: image base pixel, top-left input coordinate of the window
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int m = min(m0 + ld_row + 32 * i, p.M - 1);
     int n = min(n0 + ld_row + 32 * i, p.N - 1);
-    a_ptr[i] = (const bf16_t*)p.A + fk_row_offset(p.a, m) + kc * 8;
+    if constexpr (CONV) {
+      const int hw = g.Hout * g.Wout;
+      const int b = m / hw, rem = m - b * hw;
+      const int oh = rem / g.Wout, ow = rem - oh * g.Wout;
+      c_pix[i] = b * g.Hin * g.Win;
+      c_ih[i] = oh * g.stride - g.pad;
+      c_iw[i] = ow * g.stride - g.pad;
+      a_ptr[i] = (const bf16_t*)p.A;
+    } else {
+      a_ptr[i] = (const bf16_t*)p.A + fk_row_offset(p.a, m) + kc * 8;
+    }
     w_ptr[i] = (const bf16_t*)p.W + (int64_t)n * p.ldw + kc * 8;
   }
   const int st_off = ld_row * 128 + ((kc ^ ((ld_row >> 1) & 7)) << 4);  // + i*4096 (+ 16 KiB for W)
 
   u32x4_t a_reg[4], w_reg[4];
   auto load_tile = [&](int kt) {
+    if constexpr (CONV) {
+      const int k = kt * BK + kc * 8;
+      const int tap = k / g.Cin, ci = k - tap * g.Cin;
+      const int kh = tap / g.ksize, kw = tap - kh * g.ksize;
+      const int hlim = g.Hin << g.upsample, wlim = g.Win << g.upsample;
+      const bool tap_ok = tap < g.ksize * g.ksize;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      a_reg[i] = *(const u32x4_t*)(a_ptr[i] + (int64_t)kt * BK);
-      w_reg[i] = *(const u32x4_t*)(w_ptr[i] + (int64_t)kt * BK);
+      for (int i = 0; i < 4; ++i) {
+        int ih = c_ih[i] + kh, iw = c_iw[i] + kw;
+        const bool ok = tap_ok && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+        ih >>= g.upsample;
+        iw >>= g.upsample;
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+        a_reg[i] = ok ? *(const u32x4_t*)(a_ptr[i] + ((int64_t)(c_pix[i] + ih * g.Win + iw) * g.Cin + ci)) : z;
+        w_reg[i] = *(const u32x4_t*)(w_ptr[i] + (int64_t)kt * BK);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a_reg[i] = *(const u32x4_t*)(a_ptr[i] + (int64_t)kt * BK);
+        w_reg[i] = *(const u32x4_t*)(w_ptr[i] + (int64_t)kt * BK);
+      }
     }
   };
   auto store_tile = [&](int stage) {
@@ -226,17 +262,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const fk_gemm_ar
   }
 }
 
-template <int EPI, bool OUT_F32>
-int launch(const fk_gemm_args& p, hipStream_t stream) {
+template <int EPI, bool OUT_F32, bool CONV = false>
+int launch(const fk_gemm_args& p, hipStream_t stream, const ConvGeom& g = ConvGeom()) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  auto kern = gemm_bf16_kernel<EPI, OUT_F32>;
+  auto kern = gemm_bf16_kernel<EPI, OUT_F32, CONV>;
   static bool attr_done = false;  // benign race: idempotent
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(NTHREADS), SMEM_BYTES, stream, p);
-  FK_CHECK_LAUNCH("fk_gemm_bf16");
+  hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(NTHREADS), SMEM_BYTES, stream, p, g);
+  FK_CHECK_LAUNCH(CONV ? "fk_conv2d_nhwc_bf16" : "fk_gemm_bf16");
   return FK_OK;
 }
 
@@ -286,4 +322,36 @@ extern "C" int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream_) {
     case FK_EPI_SCALE: return launch<FK_EPI_SCALE, false>(p, stream);
     default: fk_set_error("fk_gemm_bf16: unknown epilogue %d", p.epilogue); return FK_EUNSUPPORTED;
   }
+}
+
+// Conv2d over NHWC bf16 as an implicit GEMM on the same MFMA main loop (A rows gathered per filter tap,
+// zero padding / stride-2 asymmetric padding / fused nearest-2x upsample resolved in the loader).
+extern "C" int fk_conv2d_nhwc_bf16(const fk_conv_args* args, fk_stream_t stream_) {
+  FK_CHECK_ARG(args != nullptr, "fk_conv2d_nhwc_bf16: null args");
+  const fk_conv_args& a = *args;
+  FK_CHECK_ARG(a.x && a.w && a.y, "fk_conv2d_nhwc_bf16: null x/w/y");
+  FK_CHECK_ARG(a.ksize == 1 || a.ksize == 3, "fk_conv2d_nhwc_bf16: ksize must be 1 or 3");
+  FK_CHECK_ARG(a.stride == 1 || a.stride == 2, "fk_conv2d_nhwc_bf16: stride must be 1 or 2");
+  FK_CHECK_ARG(a.Cin % 8 == 0 && a.Cout % 8 == 0, "fk_conv2d_nhwc_bf16: Cin/Cout must be multiples of 8 (pad channels)");
+  FK_CHECK_ARG(a.B > 0 && a.Hin > 0 && a.Win > 0 && a.Hout > 0 && a.Wout > 0, "fk_conv2d_nhwc_bf16: bad sizes");
+  FK_CHECK_ARG(!(a.upsample2x && a.stride != 1), "fk_conv2d_nhwc_bf16: upsample needs stride 1");
+  const int64_t Mll = (int64_t)a.B * a.Hout * a.Wout;
+  FK_CHECK_ARG(Mll < (1ll << 31) && (int64_t)a.B * a.Hin * a.Win < (1ll << 31), "fk_conv2d_nhwc_bf16: too many pixels");
+  const int Kreal = a.ksize * a.ksize * a.Cin;
+  const int Kpad = (Kreal + BK - 1) / BK * BK;  // weight rows are zero padded to Kpad by the caller
+  fk_gemm_args p = {};
+  p.A = a.x; p.a = {0, 0, 0};
+  p.W = a.w; p.ldw = Kpad;
+  p.bias = a.bias;
+  p.C = a.y; p.c = {a.Cout, 0, 0};
+  p.res = a.res; p.r = {a.Cout, 0, 0};
+  p.M = (int)Mll; p.N = a.Cout; p.K = Kpad;
+  p.epilogue = a.res ? FK_EPI_RES : FK_EPI_NONE;
+  ConvGeom g = {a.Hin, a.Win, a.Cin, a.Hout, a.Wout, a.ksize, a.stride, a.pad, a.upsample2x ? 1 : 0};
+  FK_CHECK_ARG(((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.w % 16 == 0) && ((uintptr_t)a.y % 16 == 0) &&
+                   (!a.res || (uintptr_t)a.res % 16 == 0) && (!a.bias || (uintptr_t)a.bias % 8 == 0),
+               "fk_conv2d_nhwc_bf16: alignment");
+  hipStream_t stream = (hipStream_t)stream_;
+  if (a.res) return launch<FK_EPI_RES, false, true>(p, stream, g);
+  return launch<FK_EPI_NONE, false, true>(p, stream, g);
 }

@@ -1,0 +1,213 @@
+// HBM-bound kernels of the FLUX AutoencoderKL (K9b and the layout changes at its boundary).
+// Activations are NHWC bf16 ([B, HW, C], C % 32 == 0).  GroupNorm(32 groups, eps 1e-6) is two passes:
+//   stats : per-block partial (sum, sum of squares) per group -> deterministic fixed-order merge
+//   apply : y = act(bf16((x - mean) * rstd * gamma + beta)), vectorised 16 bytes per lane
+// (the convolutions themselves are the implicit-GEMM path in gemm_bf16.hip).
+#include "fk_common.h"
+
+namespace {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAX_BLOCKS = 512;  // partial-sum blocks per image
+
+inline int gn_blocks(int64_t HW, int C) {
+  const int64_t pix_per_iter = GN_THREADS / (C / 8);
+  int64_t nb = (HW + pix_per_iter * 8 - 1) / (pix_per_iter * 8);  // >= 8 iterations per block
+  if (nb < 1) nb = 1;
+  if (nb > GN_MAX_BLOCKS) nb = GN_MAX_BLOCKS;
+  return (int)nb;
+}
+
+// grid (nblk, B).  Thread t owns channel chunk (t % (C/8)) of pixels (t / (C/8)) + k * ppi.
+__global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(const bf16_t* x, float* ws, int64_t HW, int C,
+                                                                int groups) {
+  __shared__ float gsum[64], gsq[64];
+  const int tid = threadIdx.x;
+  const int cpr = C / 8;                 // 16-byte chunks per pixel
+  const int ppi = GN_THREADS / cpr;      // pixels per iteration
+  const int chunk = tid % cpr, prow = tid / cpr;
+  const int b = blockIdx.y, nblk = gridDim.x;
+  const int64_t per_blk = (HW + nblk - 1) / nblk;
+  const int64_t p0 = (int64_t)blockIdx.x * per_blk;
+  const int64_t p1 = (p0 + per_blk < HW) ? p0 + per_blk : HW;
+  float s_lo = 0.f, q_lo = 0.f, s_hi = 0.f, q_hi = 0.f;  // channels [0,4) and [4,8) of the chunk
+  if (prow < ppi) {
+    const bf16_t* xb = x + (int64_t)b * HW * C + chunk * 8;
+    for (int64_t p = p0 + prow; p < p1; p += ppi) {
+      const u32x4_t w = *(const u32x4_t*)(xb + p * C);
+      const float v0 = bf_lo(w[0]), v1 = bf_hi(w[0]), v2 = bf_lo(w[1]), v3 = bf_hi(w[1]);
+      const float v4 = bf_lo(w[2]), v5 = bf_hi(w[2]), v6 = bf_lo(w[3]), v7 = bf_hi(w[3]);
+      s_lo += (v0 + v1) + (v2 + v3);
+      q_lo += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+      s_hi += (v4 + v5) + (v6 + v7);
+      q_hi += (v4 * v4 + v5 * v5) + (v6 * v6 + v7 * v7);
+    }
+  }
+  if (tid < 64) { gsum[tid] = 0.f; gsq[tid] = 0.f; }
+  __syncthreads();
+  if (prow < ppi) {
+    const int cpg = C / groups;  // channels per group: 4, 8 or 16 (C = 128, 256, 512)
+    const int g_lo = (chunk * 8) / cpg, g_hi = (chunk * 8 + 4) / cpg;
+    atomicAdd(&gsum[g_lo], s_lo);
+    atomicAdd(&gsq[g_lo], q_lo);
+    atomicAdd(&gsum[g_hi], s_hi);
+    atomicAdd(&gsq[g_hi], q_hi);
+  }
+  __syncthreads();
+  if (tid < groups) {
+    float* o = ws + (((int64_t)b * nblk + blockIdx.x) * groups + tid) * 2;
+    o[0] = gsum[tid];
+    o[1] = gsq[tid];
+  }
+}
+
+// grid (B), 64 threads: merge the per-block partials in a fixed order (fp64 to avoid cancellation).
+__global__ void gn_finalize_kernel(const float* ws, float* stats, int nblk, int groups, double count, float eps) {
+  const int b = blockIdx.x, g = threadIdx.x;
+  if (g >= groups) return;
+  double s = 0.0, q = 0.0;
+  for (int i = 0; i < nblk; ++i) {
+    const float* o = ws + (((int64_t)b * nblk + i) * groups + g) * 2;
+    s += (double)o[0];
+    q += (double)o[1];
+  }
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[((int64_t)b * groups + g) * 2 + 0] = (float)mean;
+  stats[((int64_t)b * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x, bf16_t* y, const float* stats,
+                                                       const bf16_t* gamma, const bf16_t* beta, int64_t HW,
+                                                       int C, int groups, int silu) {
+  const int b = blockIdx.y;
+  const int cpr = C / 8, cpg = C / groups;
+  const int64_t nvec = HW * cpr;
+  const bf16_t* xb = x + (int64_t)b * HW * C;
+  bf16_t* yb = y + (int64_t)b * HW * C;
+  const float* st = stats + (int64_t)b * groups * 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int c0 = (int)(i % cpr) * 8;
+    const u32x4_t w = *(const u32x4_t*)(xb + i * 8);
+    const u32x4_t gw = *(const u32x4_t*)(gamma + c0);
+    const u32x4_t bw = *(const u32x4_t*)(beta + c0);
+    u32x4_t ow;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int g = (c0 + 2 * e) / cpg;  // both halves of a dword share a group (cpg >= 2)
+      const float mean = st[2 * g], rstd = st[2 * g + 1];
+      float v0 = (bf_lo(w[e]) - mean) * rstd * bf_lo(gw[e]) + bf_lo(bw[e]);
+      float v1 = (bf_hi(w[e]) - mean) * rstd * bf_hi(gw[e]) + bf_hi(bw[e]);
+      if (silu) {
+        v0 = silu_f(round_bf(v0));
+        v1 = silu_f(round_bf(v1));
+      }
+      ow[e] = pack_bf2(v0, v1);
+    }
+    *(u32x4_t*)(yb + i * 8) = ow;
+  }
+}
+
+// NCHW (fp32 / bf16) -> NHWC bf16 with channel padding; tiled over (32 pixels x all channels).
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const T* src, bf16_t* dst, int C, int Cpad,
+                                                           int64_t HW, float div, float add) {
+  const int b = blockIdx.y;
+  const int64_t total = HW * Cpad;
+  const T* sb = src + (int64_t)b * C * HW;
+  bf16_t* db = dst + (int64_t)b * HW * Cpad;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % Cpad);
+    const int64_t p = i / Cpad;
+    float v = 0.f;
+    if (c < C) {
+      if constexpr (sizeof(T) == 4) v = sb[(int64_t)c * HW + p];
+      else v = bf2f(sb[(int64_t)c * HW + p]);
+      v = round_bf(round_bf(v) / div) + add;  // bf16 tensor / scalar, then + scalar (torch rounding points)
+    }
+    db[i] = f2bf(v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const bf16_t* src, T* dst, int C, int Cpad,
+                                                           int64_t HW, float add, float mul) {
+  const int b = blockIdx.y;
+  const int64_t total = HW * C;
+  const bf16_t* sb = src + (int64_t)b * HW * Cpad;
+  T* db = dst + (int64_t)b * C * HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i / HW);
+    const int64_t p = i - (int64_t)c * HW;
+    const float v = round_bf(round_bf(bf2f(sb[p * Cpad + c]) + add) * mul);
+    if constexpr (sizeof(T) == 4) db[i] = v;
+    else db[i] = f2bf(v);
+  }
+}
+
+inline int ew_grid(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" int64_t fk_groupnorm_ws_floats(int32_t B, int64_t HW, int32_t C) {
+  if (B <= 0 || HW <= 0 || C <= 0 || C % 32 != 0) return -1;
+  return (int64_t)B * gn_blocks(HW, C) * 32 * 2;
+}
+
+extern "C" int fk_groupnorm_stats_nhwc_bf16(const void* x, float* stats, float* ws, int32_t B, int64_t HW,
+                                            int32_t C, int32_t groups, float eps, fk_stream_t stream_) {
+  FK_CHECK_ARG(x && stats && ws && B > 0 && HW > 0, "fk_groupnorm_stats: bad arguments");
+  FK_CHECK_ARG(groups == 32 && C % 128 == 0 && C <= 1024 && (C / 8) <= GN_THREADS,
+               "fk_groupnorm_stats: needs 32 groups and C in {128, 256, 512} (got C=%d groups=%d)", C, groups);
+  FK_CHECK_ARG((uintptr_t)x % 16 == 0, "fk_groupnorm_stats: alignment");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int nblk = gn_blocks(HW, C);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, B), dim3(GN_THREADS), 0, stream, (const bf16_t*)x, ws, HW, C, groups);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, stream, (const float*)ws, stats, nblk, groups,
+                     (double)HW * (C / groups), eps);
+  FK_CHECK_LAUNCH("fk_groupnorm_stats_nhwc_bf16");
+  return FK_OK;
+}
+
+extern "C" int fk_groupnorm_apply_nhwc_bf16(const void* x, void* y, const float* stats, const void* gamma,
+                                            const void* beta, int32_t B, int64_t HW, int32_t C, int32_t groups,
+                                            int32_t silu, fk_stream_t stream_) {
+  FK_CHECK_ARG(x && y && stats && gamma && beta && B > 0 && HW > 0, "fk_groupnorm_apply: bad arguments");
+  FK_CHECK_ARG(groups == 32 && C % 64 == 0, "fk_groupnorm_apply: needs 32 groups, C %% 64 == 0");
+  FK_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)gamma % 16 == 0) &&
+                   ((uintptr_t)beta % 16 == 0), "fk_groupnorm_apply: alignment");
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_grid(HW * (C / 8)), B), dim3(256), 0, (hipStream_t)stream_,
+                     (const bf16_t*)x, (bf16_t*)y, stats, (const bf16_t*)gamma, (const bf16_t*)beta, HW, C, groups,
+                     silu);
+  FK_CHECK_LAUNCH("fk_groupnorm_apply_nhwc_bf16");
+  return FK_OK;
+}
+
+extern "C" int fk_nchw_to_nhwc_bf16(const void* src, int32_t src_is_fp32, void* dst, int32_t B, int32_t C,
+                                    int32_t Cpad, int32_t H, int32_t W, float div, float add,
+                                    fk_stream_t stream_) {
+  FK_CHECK_ARG(src && dst && B > 0 && C > 0 && Cpad >= C && H > 0 && W > 0, "fk_nchw_to_nhwc_bf16: bad arguments");
+  const int64_t HW = (int64_t)H * W;
+  const dim3 grid(ew_grid(HW * Cpad), B), block(256);
+  hipStream_t s = (hipStream_t)stream_;
+  if (src_is_fp32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, block, 0, s, (const float*)src, (bf16_t*)dst, C, Cpad, HW, div, add);
+  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)src, (bf16_t*)dst, C, Cpad, HW, div, add);
+  FK_CHECK_LAUNCH("fk_nchw_to_nhwc_bf16");
+  return FK_OK;
+}
+
+extern "C" int fk_nhwc_to_nchw(const void* src, void* dst, int32_t dst_is_fp32, int32_t B, int32_t C,
+                               int32_t Cpad, int32_t H, int32_t W, float add, float mul, fk_stream_t stream_) {
+  FK_CHECK_ARG(src && dst && B > 0 && C > 0 && Cpad >= C && H > 0 && W > 0, "fk_nhwc_to_nchw: bad arguments");
+  const int64_t HW = (int64_t)H * W;
+  const dim3 grid(ew_grid(HW * C), B), block(256);
+  hipStream_t s = (hipStream_t)stream_;
+  if (dst_is_fp32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, block, 0, s, (const bf16_t*)src, (float*)dst, C, Cpad, HW, add, mul);
+  else hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)src, (bf16_t*)dst, C, Cpad, HW, add, mul);
+  FK_CHECK_LAUNCH("fk_nhwc_to_nchw");
+  return FK_OK;
+}

@@ -53,7 +53,12 @@ SIGNATURES = {
     "fk_euler_step_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "fk_transpose_bf16": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "fk_softmax_rows": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp]),
-    # VAE_SIGNATURES_PLACEHOLDER
+    "fk_conv2d_nhwc_bf16": (c_i32, [ctypes.POINTER(ConvArgs), c_vp]),
+    "fk_groupnorm_ws_floats": (c_i64, [c_i32, c_i64, c_i32]),
+    "fk_groupnorm_stats_nhwc_bf16": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_f32, c_vp]),
+    "fk_groupnorm_apply_nhwc_bf16": (c_i32, [c_vp] * 5 + [c_i32, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "fk_nchw_to_nhwc_bf16": (c_i32, [c_vp, c_i32, c_vp] + [c_i32] * 5 + [c_f32, c_f32, c_vp]),
+    "fk_nhwc_to_nchw": (c_i32, [c_vp, c_vp] + [c_i32] * 6 + [c_f32, c_f32, c_vp]),
     "fk_last_error": (ctypes.c_char_p, []),
     "fk_version": (ctypes.c_char_p, []),
 }

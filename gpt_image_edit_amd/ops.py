@@ -186,3 +186,64 @@ def softmax_rows(x, out=None):
     libfk.check(libfk.load().fk_softmax_rows(_ptr(x), x.stride(0), _ptr(out), out.stride(0), rows, n,
                                              _stream()), "fk_softmax_rows")
     return out
+
+
+# ---- FLUX AutoencoderKL pieces (NHWC bf16 activations) -------------------------------------------------
+def conv2d_nhwc(x, w_packed, bias, cout, ksize=3, stride=1, pad=1, upsample2x=False, res=None, out=None):
+    """x: [B,H,W,Cin] bf16; w_packed: [cout, Kpad] (k = (kh*ks+kw)*Cin + ci, zero padded to 64)."""
+    _need_cuda(x, w_packed, bias, res)
+    B, Hin, Win, Cin = x.shape
+    He, We = (Hin * 2, Win * 2) if upsample2x else (Hin, Win)
+    if stride == 1:
+        Hout, Wout = He, We
+    else:  # F.pad(x, (0,1,0,1)) + 3x3 stride-2 valid conv
+        Hout, Wout = (He + 1 - 3) // 2 + 1, (We + 1 - 3) // 2 + 1
+    if out is None:
+        out = torch.empty((B, Hout, Wout, cout), device=x.device, dtype=BF16)
+    a = libfk.ConvArgs()
+    a.x, a.w, a.bias, a.y = x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), out.data_ptr()
+    a.res = res.data_ptr() if res is not None else None
+    a.B, a.Hin, a.Win, a.Cin, a.Cout = B, Hin, Win, Cin, cout
+    a.ksize, a.stride, a.pad, a.upsample2x = ksize, stride, pad, int(upsample2x)
+    a.Hout, a.Wout = Hout, Wout
+    if not x.is_contiguous() or (res is not None and not res.is_contiguous()):
+        raise ValueError("conv2d_nhwc needs contiguous NHWC tensors")
+    libfk.check(libfk.load().fk_conv2d_nhwc_bf16(ctypes.byref(a), _stream()), "fk_conv2d_nhwc_bf16")
+    return out
+
+
+def group_norm_nhwc(x, gamma, beta, silu, eps=1e-6, out=None):
+    """GroupNorm(32) (+SiLU) over [B, ..., C] NHWC bf16."""
+    _need_cuda(x, gamma, beta)
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    lib = libfk.load()
+    ws = torch.empty(lib.fk_groupnorm_ws_floats(B, HW, C), device=x.device, dtype=torch.float32)
+    stats = torch.empty((B, 32, 2), device=x.device, dtype=torch.float32)
+    libfk.check(lib.fk_groupnorm_stats_nhwc_bf16(_ptr(x), _ptr(stats), _ptr(ws), B, HW, C, 32, eps, _stream()),
+                "fk_groupnorm_stats_nhwc_bf16")
+    if out is None:
+        out = torch.empty_like(x)
+    libfk.check(lib.fk_groupnorm_apply_nhwc_bf16(_ptr(x), _ptr(out), _ptr(stats), _ptr(gamma), _ptr(beta), B, HW,
+                                                 C, 32, int(silu), _stream()), "fk_groupnorm_apply_nhwc_bf16")
+    return out
+
+
+def nchw_to_nhwc(x, cpad, div=1.0, add=0.0):
+    _need_cuda(x)
+    B, C, H, W = x.shape
+    if x.dtype not in (BF16, torch.float32) or not x.is_contiguous():
+        raise TypeError("nchw_to_nhwc takes contiguous fp32/bf16 NCHW")
+    out = torch.empty((B, H, W, cpad), device=x.device, dtype=BF16)
+    libfk.check(libfk.load().fk_nchw_to_nhwc_bf16(_ptr(x), int(x.dtype == torch.float32), _ptr(out), B, C, cpad,
+                                                  H, W, float(div), float(add), _stream()), "fk_nchw_to_nhwc_bf16")
+    return out
+
+
+def nhwc_to_nchw(x, c, add=0.0, mul=1.0, dtype=BF16):
+    _need_cuda(x)
+    B, H, W, cpad = x.shape
+    out = torch.empty((B, c, H, W), device=x.device, dtype=dtype)
+    libfk.check(libfk.load().fk_nhwc_to_nchw(_ptr(x), _ptr(out), int(dtype == torch.float32), B, c, cpad, H, W,
+                                             float(add), float(mul), _stream()), "fk_nhwc_to_nchw")
+    return out

@@ -1,0 +1,212 @@
+"""HipAutoencoderKL -- the FLUX 16-channel VAE on the HIP kernels, behind the diffusers interface the
+reference pipeline uses: ``vae.encode(x).latent_dist.mode()`` (reference
+``univa/utils/flux_pipeline.py:604-609``), ``vae.decode(z, return_dict=False)[0]`` (``:1129``),
+``vae.config.{block_out_channels, latent_channels, scaling_factor, shift_factor}`` (``:255-258,611,1128``)
+and ``vae.dtype`` (``:601``).  Parameters carry the diffusers key names (flux_spec.vae_param_shapes).
+
+Internally activations are NHWC bf16; every conv is the implicit-GEMM MFMA kernel (taps gathered in
+the loader, nearest-2x upsample and the stride-2 (0,1,0,1) padding fused into the addressing, residual
+add fused into the epilogue); GroupNorm is a two-pass stats + fused apply/SiLU; the single-head
+mid-block attention is QK^T (fp32 scores) -> row softmax -> PV on the same GEMM kernel.
+No torch math runs on the data path; there is no CPU fallback.
+"""
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from . import flux_spec, ops
+
+BF16 = torch.bfloat16
+
+
+def _pack_conv(w, cin_pad=None, cout_pad=None):
+    """OIHW -> [Cout_pad, Kpad] with k = (kh*KW + kw)*Cin_pad + ci, zero padded (one-time weight prep)."""
+    co, ci, kh, kw = w.shape
+    cin_pad = cin_pad or ci
+    cout_pad = cout_pad or co
+    t = torch.zeros((cout_pad, kh, kw, cin_pad), device=w.device, dtype=w.dtype)
+    t[:co, :, :, :ci] = w.permute(0, 2, 3, 1)
+    k = kh * kw * cin_pad
+    kpad = (k + 63) // 64 * 64
+    out = torch.zeros((cout_pad, kpad), device=w.device, dtype=w.dtype)
+    out[:, :k] = t.reshape(cout_pad, k)
+    return out.contiguous()
+
+
+def _pad_vec(b, n):
+    out = torch.zeros(n, device=b.device, dtype=b.dtype)
+    out[: b.shape[0]] = b
+    return out
+
+
+class _LatentDist:
+    """DiagonalGaussianDistribution surface used by the reference (mode / sample / mean / logvar)."""
+
+    def __init__(self, moments):
+        self.mean, self.logvar = moments.chunk(2, dim=1)
+
+    def mode(self):
+        return self.mean.contiguous()
+
+    def sample(self, generator=None):
+        std = torch.exp(0.5 * self.logvar.float().clamp(-30.0, 20.0))
+        eps = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=torch.float32)
+        return (self.mean.float() + std * eps).to(self.mean.dtype)
+
+
+class HipAutoencoderKL(nn.Module):
+    def __init__(self, config=None, device="cuda", dtype=BF16, init="empty", seed=0):
+        super().__init__()
+        if dtype != BF16:
+            raise ValueError("HipAutoencoderKL computes in bf16")
+        cfg = dict(flux_spec.FLUX_VAE_CONFIG)
+        cfg.update(config or {})
+        self.config = SimpleNamespace(**cfg)
+        shapes = flux_spec.vae_param_shapes(cfg)
+        if init == "synthetic":
+            state = flux_spec.synthetic_state(shapes, seed=seed, device=device, dtype=dtype)
+        else:
+            state = {k: torch.empty(s, device=device, dtype=dtype) for k, s in shapes.items()}
+        for k, v in state.items():
+            self.register_parameter(k.replace(".", "__"), nn.Parameter(v, requires_grad=False))
+        self._pk = None
+
+    def p(self, name):
+        return getattr(self, name.replace(".", "__"))
+
+    def has(self, name):
+        return hasattr(self, name.replace(".", "__"))
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        return type(sd)((k.replace("__", "."), v) for k, v in sd.items())
+
+    def load_state_dict(self, state_dict, strict=True, **kwargs):
+        self._pk = None
+        return super().load_state_dict({k.replace(".", "__"): v for k, v in state_dict.items()}, strict=strict, **kwargs)
+
+    def _apply(self, fn, *a, **k):
+        self._pk = None
+        return super()._apply(fn, *a, **k)
+
+    @property
+    def dtype(self):
+        return BF16
+
+    @property
+    def device(self):
+        return self.p("decoder.conv_in.weight").device
+
+    # slicing / tiling passthroughs exist on the reference pipeline (flux_pipeline.py:616-646); the HIP
+    # path decodes whole batches, so they are accepted and ignored.
+    def enable_slicing(self): pass
+    def disable_slicing(self): pass
+    def enable_tiling(self): pass
+    def disable_tiling(self): pass
+
+    # ---- weight prep -----------------------------------------------------------------------------------
+    def _packed(self):
+        if self._pk is not None:
+            return self._pk
+        pk = {}
+        for name, prm in self.state_dict().items():
+            if name.endswith(".weight") and prm.dim() == 4:
+                base = name[: -len(".weight")]
+                ci, co = prm.shape[1], prm.shape[0]
+                cin_pad = max(32, (ci + 7) // 8 * 8) if ci < 32 else ci
+                cout_pad = (co + 7) // 8 * 8
+                pk[base] = (_pack_conv(prm, cin_pad, cout_pad), _pad_vec(self.p(base + ".bias"), cout_pad), cout_pad)
+        for side in ("encoder", "decoder"):
+            a = f"{side}.mid_block.attentions.0."
+            pk[a + "qkv"] = (torch.cat([self.p(a + f"{n}.weight") for n in ("to_q", "to_k", "to_v")]).contiguous(),
+                             torch.cat([self.p(a + f"{n}.bias") for n in ("to_q", "to_k", "to_v")]).contiguous())
+        self._pk = pk
+        return pk
+
+    # ---- building blocks (NHWC) ------------------------------------------------------------------------------
+    def _conv(self, name, x, stride=1, pad=1, upsample=False, res=None):
+        w, b, cout = self._packed()[name]
+        ks = 3 if self.p(name + ".weight").shape[-1] == 3 else 1
+        return ops.conv2d_nhwc(x, w, b, cout, ksize=ks, stride=stride, pad=pad if ks == 3 else 0,
+                               upsample2x=upsample, res=res)
+
+    def _gn(self, name, x, silu):
+        return ops.group_norm_nhwc(x, self.p(name + ".weight"), self.p(name + ".bias"), silu)
+
+    def _resnet(self, p, x):
+        t = self._conv(p + "conv1", self._gn(p + "norm1", x, True))
+        t = self._gn(p + "norm2", t, True)
+        xs = self._conv(p + "conv_shortcut", x) if self.has(p + "conv_shortcut.weight") else x
+        return self._conv(p + "conv2", t, res=xs)
+
+    def _mid_attention(self, p, x):
+        B, H, W, C = x.shape
+        S = H * W
+        n = self._gn(p + "group_norm", x, False).view(B, S, C)
+        wqkv, bqkv = self._packed()[p + "qkv"]
+        qkv = ops.gemm(n, wqkv, bqkv)                               # [B, S, 3C]
+        o = torch.empty((B, S, C), device=x.device, dtype=BF16)
+        S_pad = (S + 63) // 64 * 64                                 # GEMM K granularity for P @ V
+        scores = torch.empty((S, S_pad), device=x.device, dtype=torch.float32)
+        probs = torch.zeros((S, S_pad), device=x.device, dtype=BF16)
+        vt = torch.zeros((1, C, S_pad), device=x.device, dtype=BF16)
+        for b in range(B):
+            q, k, v = qkv[b, :, :C], qkv[b, :, C:2 * C], qkv[b, :, 2 * C:]
+            ops.gemm(q, k, None, out=scores[:, :S], epilogue=ops.FK_EPI_SCALE, alpha=C ** -0.5, out_fp32=True)
+            ops.softmax_rows(scores[:, :S], out=probs[:, :S])
+            ops.transpose(v.unsqueeze(0), vt[:, :, :S])
+            ops.gemm(probs, vt[0], None, out=o[b])
+        xr = x.view(B, S, C)
+        out = ops.gemm(o, self.p(p + "to_out.0.weight"), self.p(p + "to_out.0.bias"), epilogue=ops.FK_EPI_RES, res=xr)
+        return out.view(B, H, W, C)
+
+    def _mid(self, p, x):
+        x = self._resnet(p + "resnets.0.", x)
+        x = self._mid_attention(p + "attentions.0.", x)
+        return self._resnet(p + "resnets.1.", x)
+
+    # ---- public interface -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def decode(self, z, return_dict=True, generator=None, pre_div=1.0, pre_add=0.0):
+        """z [B,16,h,w] -> image [B,3,8h,8w] bf16.  ``pre_div/pre_add`` fuse the pipeline's
+        ``z / scaling_factor + shift_factor`` (flux_pipeline.py:1128) into the layout change."""
+        if not z.is_cuda:
+            raise RuntimeError("HipAutoencoderKL needs GPU tensors: there is no CPU fallback")
+        x = ops.nchw_to_nhwc(z.contiguous(), 32, pre_div, pre_add)
+        x = self._conv("decoder.conv_in", x)
+        x = self._mid("decoder.mid_block.", x)
+        n_up = len(self.config.block_out_channels)
+        for i in range(n_up):
+            for j in range(self.config.layers_per_block + 1):
+                x = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}.", x)
+            if i < n_up - 1:
+                x = self._conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", x, upsample=True)
+        x = self._gn("decoder.conv_norm_out", x, True)
+        x = self._conv("decoder.conv_out", x)
+        img = ops.nhwc_to_nchw(x, self.config.out_channels)
+        if not return_dict:
+            return (img,)
+        return SimpleNamespace(sample=img)
+
+    @torch.no_grad()
+    def encode(self, x, return_dict=True, post_add=0.0, post_mul=1.0):
+        """image [B,3,H,W] (fp32 or bf16, in [-1,1]) -> latent distribution with [B,16,H/8,W/8] moments."""
+        if not x.is_cuda:
+            raise RuntimeError("HipAutoencoderKL needs GPU tensors: there is no CPU fallback")
+        t = ops.nchw_to_nhwc(x.contiguous(), 32)
+        t = self._conv("encoder.conv_in", t)
+        n_down = len(self.config.block_out_channels)
+        for i in range(n_down):
+            for j in range(self.config.layers_per_block):
+                t = self._resnet(f"encoder.down_blocks.{i}.resnets.{j}.", t)
+            if i < n_down - 1:
+                t = self._conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", t, stride=2, pad=0)
+        t = self._mid("encoder.mid_block.", t)
+        t = self._gn("encoder.conv_norm_out", t, True)
+        t = self._conv("encoder.conv_out", t)
+        moments = ops.nhwc_to_nchw(t, 2 * self.config.latent_channels, post_add, post_mul)
+        dist = _LatentDist(moments)
+        if not return_dict:
+            return (dist,)
+        return SimpleNamespace(latent_dist=dist)

@@ -133,7 +133,7 @@ int fk_euler_step_bf16(void* x, int64_t x_batch_stride, const void* v, int64_t v
 int fk_transpose_bf16(const void* src, int64_t lds, int64_t src_batch_stride, void* dst, int64_t ldd,
                       int64_t dst_batch_stride, int32_t R, int32_t C, int32_t batch, fk_stream_t stream);
 /* y[r, :n] = bf16(softmax(x[r, :n])) with fp32 scores x (row strides ldx / ldy in elements), n % 4 == 0,
- * n <= 16384: the softmax of the VAE mid-block attention (scores kept in fp32 like a fused SDPA). */
+ * n <= 32768: the softmax of the VAE mid-block attention (scores kept in fp32 like a fused SDPA). */
 int fk_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t n,
                     fk_stream_t stream);
 
@@ -163,12 +163,13 @@ int fk_groupnorm_stats_nhwc_bf16(const void* x, float* stats, float* ws, int32_t
 int fk_groupnorm_apply_nhwc_bf16(const void* x, void* y, const float* stats, const void* gamma,
                                  const void* beta, int32_t B, int64_t HW, int32_t C, int32_t groups,
                                  int32_t silu, fk_stream_t stream);
-/* Layout changes at the VAE boundary. src NCHW (fp32 or bf16) -> dst NHWC bf16 with C padded to Cpad,
- * applying y = x * mul + add (latent un-scaling `z / scaling + shift` of flux_pipeline.py:1128). */
+/* Layout changes at the VAE boundary. src NCHW (fp32 or bf16) -> dst NHWC bf16 with C zero padded to Cpad,
+ * applying y = bf16(bf16(bf16(x) / div) + add) (latent un-scaling `z / scaling + shift` of
+ * flux_pipeline.py:1128; div = 1, add = 0 is the plain `image.to(vae.dtype)` cast). */
 int fk_nchw_to_nhwc_bf16(const void* src, int32_t src_is_fp32, void* dst, int32_t B, int32_t C,
-                         int32_t Cpad, int32_t H, int32_t W, float mul, float add, fk_stream_t stream);
-/* src NHWC bf16 (channel stride Cpad) -> dst NCHW (fp32 or bf16), first C channels, y = (x + add) * mul
- * (`(z - shift) * scaling` of flux_pipeline.py:611). */
+                         int32_t Cpad, int32_t H, int32_t W, float div, float add, fk_stream_t stream);
+/* src NHWC bf16 (channel stride Cpad) -> dst NCHW (fp32 or bf16), first C channels,
+ * y = bf16(bf16(x + add) * mul)  (`(z - shift) * scaling` of flux_pipeline.py:611). */
 int fk_nhwc_to_nchw(const void* src, void* dst, int32_t dst_is_fp32, int32_t B, int32_t C, int32_t Cpad,
                     int32_t H, int32_t W, float add, float mul, fk_stream_t stream);
 

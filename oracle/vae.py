@@ -85,14 +85,30 @@ def encode_mode(sd, x):
     return encode_moments(sd, x).chunk(2, dim=1)[0]
 
 
+def _scalar_op(x, op, c):
+    """``x (op) python_scalar`` with the rounding the reference's CUDA torch build applies to a
+    bf16/fp16 tensor: the scalar stays fp32 (opmath), only the result is rounded to x.dtype.
+    (CPU torch instead rounds the scalar itself to bf16 first -- 0.1159 -> 0.11572 -- which is a
+    CPU-only artefact the GPU reference never sees, so the oracle does not reproduce it.)"""
+    y = x.float()
+    y = y / c if op == "div" else (y * c if op == "mul" else y + c)
+    return y.to(x.dtype)
+
+
 def encode_for_pipeline(sd, image, cfg=VAE_CONFIG):
     """flux_pipeline.py:600-613: (mode(z) - shift) * scale."""
-    return (encode_mode(sd, image) - cfg["shift_factor"]) * cfg["scaling_factor"]
+    z = encode_mode(sd, image)
+    return _scalar_op(_scalar_op(z, "add", -cfg["shift_factor"]), "mul", cfg["scaling_factor"])
+
+
+def unscale_latents(latents, cfg=VAE_CONFIG):
+    """flux_pipeline.py:1128: latents / scaling_factor + shift_factor."""
+    return _scalar_op(_scalar_op(latents, "div", cfg["scaling_factor"]), "add", cfg["shift_factor"])
 
 
 def decode_for_pipeline(sd, latents, cfg=VAE_CONFIG):
     """flux_pipeline.py:1128-1129: decode(z / scale + shift)."""
-    return decode(sd, latents / cfg["scaling_factor"] + cfg["shift_factor"])
+    return decode(sd, unscale_latents(latents, cfg))
 
 
 def postprocess_uint8(image):

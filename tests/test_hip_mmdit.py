@@ -1,0 +1,85 @@
+"""GPU parity of the whole HIP MMDiT forward (HipFluxTransformer2DModel) against the CPU oracle.
+
+The model is built at FULL width (D = 3072, 24 heads, FF 12288, joint dim 4096) but reduced depth so
+the fp32 CPU oracle finishes in seconds; weights are the seeded synthetic set with the real
+checkpoint key names.  Two comparisons:
+  * vs the oracle run in bf16 (= the reference's rounding points): tight, element-wise;
+  * vs the oracle run in fp32 on the same bf16-rounded weights/inputs: bounded by bf16 round-off
+    accumulated over the blocks (reported; asserted relative to the output scale).
+"""
+import pytest
+import torch
+
+from conftest import report
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _inputs(B, S_txt, h, w, cfg, seed=0):
+    from oracle.helpers import prepare_latent_image_ids
+    g = torch.Generator().manual_seed(seed)
+    S_tgt = h * w
+    hs = torch.randn(B, 2 * S_tgt, cfg["in_channels"], generator=g).to(BF)
+    enc = torch.randn(B, S_txt, cfg["joint_attention_dim"], generator=g).to(BF)
+    pooled = torch.randn(B, cfg["pooled_projection_dim"], generator=g).to(BF)
+    # t*1000 and g*1000 are chosen exactly representable in bf16 (500, 250, 4000): the model's
+    # `.to(bf16) * 1000` then rounds identically in the fp32 and bf16 oracles, so their difference is
+    # pure arithmetic round-off (3.5 -> 3504 vs 3500 would instead change the embedding itself)
+    t = torch.tensor([0.5, 0.25][:B]).to(BF)
+    gd = torch.full((B,), 4.0)
+    img_ids = torch.cat([prepare_latent_image_ids(h, w), prepare_latent_image_ids(h, w, first=1.0)])
+    txt_ids = torch.zeros(S_txt, 3)
+    return hs, enc, pooled, t, gd, img_ids, txt_ids
+
+
+@pytest.mark.parametrize("n_double,n_single,B,S_txt,h,w", [(1, 0, 1, 64, 8, 8), (0, 1, 1, 64, 8, 8),
+                                                            (2, 2, 2, 77, 10, 12)])
+def test_mmdit_forward_matches_oracle(n_double, n_single, B, S_txt, h, w):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd import flux_spec
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    from oracle import mmdit
+
+    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=n_double, num_single_layers=n_single)
+    sd32 = flux_spec.synthetic_state(flux_spec.flux_param_shapes(cfg), seed=1)
+    sd_bf = {k: v.to(BF) for k, v in sd32.items()}
+    model = HipFluxTransformer2DModel(cfg, device="cuda")
+    model.load_state_dict(sd_bf)
+    hs, enc, pooled, t, gd, img_ids, txt_ids = _inputs(B, S_txt, h, w, cfg)
+
+    out = model(hidden_states=hs.cuda(), timestep=t.cuda(), guidance=gd.cuda(), pooled_projections=pooled.cuda(),
+                encoder_hidden_states=enc.cuda(), txt_ids=txt_ids.cuda(), img_ids=img_ids.cuda(),
+                joint_attention_kwargs={}, return_dict=False)[0]
+    torch.cuda.synchronize()
+    out = out.cpu()
+    assert out.shape == (B, 2 * h * w, 64) and not torch.isnan(out.float()).any()
+
+    ref_bf = mmdit.flux_forward(sd_bf, hs, enc, pooled, t, img_ids, txt_ids, gd, config=cfg)
+    sd_r = {k: v.float() for k, v in sd_bf.items()}  # fp32 math on the bf16-rounded weights
+    ref32 = mmdit.flux_forward(sd_r, hs.float(), enc.float(), pooled.float(), t, img_ids, txt_ids, gd, config=cfg)
+    tag = f"mmdit d{n_double}s{n_single}"
+    d_bf = report(tag + " vs bf16-oracle", out, ref_bf)
+    d_32 = report(tag + " vs fp32-oracle", out, ref32)
+    d_ref = report(tag + " bf16-oracle vs fp32-oracle (round-off floor)", ref_bf, ref32)
+    scale = ref32.abs().max().item()
+    # the HIP path must be as close to the exact result as the reference's own bf16 execution is
+    assert d_32.max().item() <= max(2.0 * d_ref.max().item(), 2e-2 * scale)
+    assert d_32.mean().item() <= max(2.0 * d_ref.mean().item(), 2e-3 * scale)
+    assert d_bf.max().item() <= 4e-2 * scale
+
+
+def test_state_dict_roundtrip_and_seam():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd import flux_spec
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=1, num_single_layers=1)
+    m = HipFluxTransformer2DModel(cfg, device="cuda", init="synthetic", seed=2)
+    sd = m.state_dict()
+    assert set(sd) == set(flux_spec.flux_param_shapes(cfg))
+    assert sd["transformer_blocks.0.attn.to_q.weight"].shape == (3072, 3072)
+    assert m.config.in_channels == 64 and m.config.guidance_embeds and m.dtype == BF
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(hidden_states=torch.zeros(1, 4, 64), encoder_hidden_states=torch.zeros(1, 4, 4096))

@@ -1,0 +1,145 @@
+"""GPU parity of the HIP FLUX VAE (HipAutoencoderKL) and its kernels against the CPU oracle.
+
+Real channel widths (128/256/512, 32 groups) at small spatial sizes so the fp32 CPU oracle is quick.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import bf16_ulp_diff, report
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _skip():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def randn(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,mode", [(128, 128, 9, 7, "s1"), (32, 512, 8, 8, "s1"), (256, 128, 6, 10, "up"),
+                                               (128, 128, 10, 8, "s2"), (512, 256, 5, 5, "1x1"), (128, 8, 12, 12, "s1")])
+def test_conv_nhwc(cin, cout, h, w, mode):
+    _skip()
+    from gpt_image_edit_amd import ops
+    from gpt_image_edit_amd.vae import _pack_conv, _pad_vec
+    B = 2
+    ks = 1 if mode == "1x1" else 3
+    x = randn(B, cin, h, w, seed=1)
+    wt = randn(cout, cin, ks, ks, seed=2, scale=0.05)
+    bias = randn(cout, seed=3, scale=0.1)
+    xf, wf, bf = x.float(), wt.float(), bias.float()
+    if mode == "up":
+        ref = F.conv2d(F.interpolate(xf, scale_factor=2.0, mode="nearest"), wf, bf, padding=1)
+    elif mode == "s2":
+        ref = F.conv2d(F.pad(xf, (0, 1, 0, 1)), wf, bf, stride=2)
+    elif mode == "1x1":
+        ref = F.conv2d(xf, wf, bf)
+    else:
+        ref = F.conv2d(xf, wf, bf, padding=1)
+    res = randn(*ref.shape, seed=4)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = _pack_conv(wt.cuda())
+    got = ops.conv2d_nhwc(x_nhwc, wp, bias.cuda(), cout, ksize=ks, stride=2 if mode == "s2" else 1,
+                          pad=0 if mode in ("s2", "1x1") else 1, upsample2x=(mode == "up"))
+    got_r = ops.conv2d_nhwc(x_nhwc, wp, bias.cuda(), cout, ksize=ks, stride=2 if mode == "s2" else 1,
+                            pad=0 if mode in ("s2", "1x1") else 1, upsample2x=(mode == "up"),
+                            res=res.permute(0, 2, 3, 1).contiguous().cuda())
+    torch.cuda.synchronize()
+    got = got.permute(0, 3, 1, 2).cpu()
+    got_r = got_r.permute(0, 3, 1, 2).cpu()
+    d = report(f"conv {mode} {cin}->{cout}", got, ref)
+    ulp = bf16_ulp_diff(got, ref.to(BF))
+    assert (ulp > 1).float().mean().item() < 1e-3
+    ref_r = res + ref.to(BF)
+    ulp = bf16_ulp_diff(got_r, ref_r)
+    assert (ulp > 1).float().mean().item() < 2e-3
+
+
+@pytest.mark.parametrize("C,hw,silu", [(128, 33 * 17, True), (512, 64, False), (256, 4096, True)])
+def test_group_norm(C, hw, silu):
+    _skip()
+    from gpt_image_edit_amd import ops
+    B = 2
+    x = (randn(B, C, hw, seed=5, scale=1.5).float() + torch.linspace(-2, 2, C)[None, :, None]).to(BF)
+    gamma, beta = (1 + randn(C, seed=6, scale=0.1).float()).to(BF), randn(C, seed=7, scale=0.1)
+    got = ops.group_norm_nhwc(x.permute(0, 2, 1).contiguous().cuda(), gamma.cuda(), beta.cuda(), silu)
+    ref = F.group_norm(x, 32, gamma, beta, 1e-6)
+    if silu:
+        ref = F.silu(ref)
+    got = got.permute(0, 2, 1).cpu()
+    report(f"group_norm C={C} hw={hw}", got, ref)
+    ulp = bf16_ulp_diff(got, ref)
+    d = (got.float() - ref.float()).abs()
+    assert (ulp > 1).float().mean().item() < 5e-3 and d.max().item() < 2e-2
+
+
+def test_layout_kernels():
+    _skip()
+    from gpt_image_edit_amd import ops
+    z = randn(2, 16, 6, 10, seed=8)
+    got = ops.nchw_to_nhwc(z.cuda(), 32, 0.3611, 0.1159).cpu()
+    from oracle import vae as ovae
+    ref = ovae.unscale_latents(z)
+    assert torch.equal(got[..., :16], ref.permute(0, 2, 3, 1)) and got[..., 16:].abs().max() == 0
+    img = torch.rand(2, 3, 8, 8) * 2 - 1
+    got = ops.nchw_to_nhwc(img.cuda(), 32).cpu()
+    assert torch.equal(got[..., :3], img.to(BF).permute(0, 2, 3, 1))
+    y = randn(2, 6, 10, 32, seed=9)
+    back = ops.nhwc_to_nchw(y.cuda(), 16, -0.1159, 0.3611).cpu()
+    ref = ovae._scalar_op(ovae._scalar_op(y[..., :16].permute(0, 3, 1, 2), "add", -0.1159), "mul", 0.3611)
+    assert torch.equal(back, ref)
+
+
+def _vae_pair(seed=3):
+    from gpt_image_edit_amd import flux_spec
+    from gpt_image_edit_amd.vae import HipAutoencoderKL
+    sd = flux_spec.synthetic_state(flux_spec.vae_param_shapes(), seed=seed)
+    sd_bf = {k: v.to(BF) for k, v in sd.items()}
+    vae = HipAutoencoderKL(device="cuda")
+    vae.load_state_dict(sd_bf)
+    return vae, sd_bf
+
+
+def test_vae_decode_matches_oracle():
+    _skip()
+    from oracle import vae as ovae
+    vae, sd_bf = _vae_pair()
+    z = randn(1, 16, 8, 6, seed=10)
+    got = vae.decode(z.cuda(), return_dict=False)[0].cpu()
+    assert got.shape == (1, 3, 64, 48)
+    ref_bf = ovae.decode(sd_bf, z)
+    ref32 = ovae.decode({k: v.float() for k, v in sd_bf.items()}, z.float())
+    d_bf = report("vae.decode vs bf16-oracle", got, ref_bf)
+    d32 = report("vae.decode vs fp32-oracle", got, ref32)
+    floor = report("vae.decode bf16-oracle vs fp32-oracle (floor)", ref_bf, ref32)
+    scale = ref32.abs().max().item()
+    assert d32.max().item() <= max(2.0 * floor.max().item(), 2e-2 * scale)
+    assert d32.mean().item() <= max(2.0 * floor.mean().item(), 2e-3 * scale)
+    # fused latent un-scaling
+    got2 = vae.decode(z.cuda(), return_dict=False, pre_div=0.3611, pre_add=0.1159)[0].cpu()
+    ref2 = ovae.decode_for_pipeline(sd_bf, z)
+    d2 = report("vae.decode(+unscale) vs bf16-oracle", got2, ref2)
+    assert d2.max().item() <= max(2.0 * floor.max().item(), 2e-2 * ref2.float().abs().max().item())
+
+
+def test_vae_encode_matches_oracle():
+    _skip()
+    from oracle import vae as ovae
+    vae, sd_bf = _vae_pair(seed=4)
+    img = (torch.rand(1, 3, 64, 48, generator=torch.Generator().manual_seed(11)) * 2 - 1)
+    lat = vae.encode(img.cuda()).latent_dist.mode().cpu()
+    assert lat.shape == (1, 16, 8, 6)
+    ref_bf = ovae.encode_mode(sd_bf, img.to(BF))
+    ref32 = ovae.encode_mode({k: v.float() for k, v in sd_bf.items()}, img.to(BF).float())
+    d32 = report("vae.encode vs fp32-oracle", lat, ref32)
+    report("vae.encode vs bf16-oracle", lat, ref_bf)
+    floor = report("vae.encode bf16-oracle vs fp32-oracle (floor)", ref_bf, ref32)
+    scale = ref32.abs().max().item()
+    assert d32.max().item() <= max(2.0 * floor.max().item(), 2e-2 * scale)
+    assert d32.mean().item() <= max(2.0 * floor.mean().item(), 2e-3 * scale)
