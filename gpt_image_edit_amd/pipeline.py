@@ -1,0 +1,244 @@
+"""FluxKontextPipeline -- MI355X-native counterpart of the reference's pipeline driver.
+
+Mirrors the call surface and semantics of ``univa/utils/flux_pipeline.py::FluxKontextPipeline.__call__``
+(:732-1138) for the embeds-driven path every reference caller uses (``univa/serve/cli.py:239-248``,
+``univa/eval/gedit/step1_gen_samples.py:194-203``, ``train_denoiser.py:1587-1600``):
+same argument names and defaults, the ``max_area`` / preferred-resolution quirks, the same
+latent packing, ids, sigma schedule, 28-step Euler loop and VAE decode -- but the loop body is
+
+    transformer (HIP MMDiT)  ->  fused slice + Euler update (one HIP kernel, in place)
+
+over ONE persistent token buffer [B, S_tgt + S_cond, 64] (target tokens first, condition tokens after:
+the reference's per-step ``torch.cat([latents, image_latents], dim=1)`` disappears), with all per-step
+scalars prepared before the loop so the 28 steps enqueue without a host sync.
+
+Host-side pre/post-processing of pixels (resize of the condition image, uint8/PIL conversion) is the
+"next row" of SURVEY.md section 8(f) and still uses torch ops; it is outside the timed hot path.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import helpers, ops
+from .scheduler import FlowMatchEulerDiscreteScheduler
+
+BF16 = torch.bfloat16
+
+
+class FluxPipelineOutput(SimpleNamespace):
+    pass
+
+
+class FluxKontextPipeline:
+    def __init__(self, transformer, vae, scheduler=None, text_encoder=None, tokenizer=None,
+                 text_encoder_2=None, tokenizer_2=None):
+        self.transformer = transformer
+        self.vae = vae
+        self.scheduler = scheduler or FlowMatchEulerDiscreteScheduler()
+        self.text_encoder, self.tokenizer = text_encoder, tokenizer
+        self.text_encoder_2, self.tokenizer_2 = text_encoder_2, tokenizer_2
+        self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1)
+        self.latent_channels = vae.config.latent_channels
+        self.default_sample_size = 128
+        self._interrupt = False
+        self._guidance_scale = None
+        self._num_timesteps = 0
+
+    # static helpers the training script reaches for directly (train_denoiser.py:925,1009,1021,1098)
+    _pack_latents = staticmethod(helpers._pack_latents)
+    _unpack_latents = staticmethod(helpers._unpack_latents)
+    _prepare_latent_image_ids = staticmethod(helpers._prepare_latent_image_ids)
+
+    def to(self, device):
+        self.transformer.to(device)
+        self.vae.to(device)
+        return self
+
+    @property
+    def device(self):
+        return self.transformer.device
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def num_timesteps(self):
+        return self._num_timesteps
+
+    def enable_vae_slicing(self): self.vae.enable_slicing()
+    def disable_vae_slicing(self): self.vae.disable_slicing()
+    def enable_vae_tiling(self): self.vae.enable_tiling()
+    def disable_vae_tiling(self): self.vae.disable_tiling()
+    def maybe_free_model_hooks(self): pass
+
+    # ---- input validation: the cases that can still occur with embeds-only input ----------------------
+    def check_inputs(self, height, width, prompt_embeds, pooled_prompt_embeds, max_sequence_length=512):
+        m = self.vae_scale_factor * 2
+        if height % m != 0 or width % m != 0:
+            print(f"`height` and `width` have to be divisible by {m} but are {height} and {width}. "
+                  f"Dimensions will be resized accordingly")
+        if prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and "
+                             "`prompt_embeds` undefined.")
+        if pooled_prompt_embeds is None:
+            raise ValueError("If `prompt_embeds` are provided, `pooled_prompt_embeds` also have to be passed. Make "
+                             "sure to generate `pooled_prompt_embeds` from the same text encoder that was used to "
+                             "generate `prompt_embeds`.")
+        if max_sequence_length is not None and max_sequence_length > 512:
+            raise ValueError(f"`max_sequence_length` cannot be greater than 512 but is {max_sequence_length}")
+
+    def _encode_vae_image(self, image):
+        """(mode(vae.encode(image)) - shift) * scale, the affine fused into the layout kernel (:600-613)."""
+        cfg = self.vae.config
+        return self.vae.encode(image, post_add=-cfg.shift_factor, post_mul=cfg.scaling_factor).latent_dist.mode()
+
+    def prepare_latents(self, image, batch_size, num_channels_latents, height, width, dtype, device,
+                        generator=None, latents=None):
+        """Same contract as flux_pipeline.py:648-708 -> (latents, image_latents, latent_ids, image_ids)."""
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an "
+                             f"effective batch size of {batch_size}. Make sure the batch size matches the length "
+                             f"of the generators.")
+        height = 2 * (int(height) // (self.vae_scale_factor * 2))
+        width = 2 * (int(width) // (self.vae_scale_factor * 2))
+        image_latents = image_ids = None
+        if image is not None:
+            image = image.to(device=device)
+            if image.shape[1] != self.latent_channels:
+                image_latents = self._encode_vae_image(image)
+            else:
+                image_latents = image.to(dtype)
+            n = image_latents.shape[0]
+            if batch_size > n and batch_size % n == 0:
+                image_latents = torch.cat([image_latents] * (batch_size // n), dim=0)
+            elif batch_size > n:
+                raise ValueError(f"Cannot duplicate `image` of batch size {n} to {batch_size} text prompts.")
+            ih, iw = image_latents.shape[2:]
+            image_latents = self._pack_latents(image_latents, batch_size, num_channels_latents, ih, iw)
+            image_ids = self._prepare_latent_image_ids(batch_size, ih // 2, iw // 2, device, dtype)
+            image_ids[..., 0] = 1  # condition tokens: first id = 1
+        latent_ids = self._prepare_latent_image_ids(batch_size, height // 2, width // 2, device, dtype)
+        if latents is None:
+            shape = (batch_size, num_channels_latents, height, width)
+            gdev = generator.device if isinstance(generator, torch.Generator) else device
+            noise = torch.randn(shape, generator=generator if not isinstance(generator, list) else None,
+                                device=gdev, dtype=dtype).to(device)
+            latents = self._pack_latents(noise, batch_size, num_channels_latents, height, width)
+        else:
+            latents = latents.to(device=device, dtype=dtype)
+        return latents, image_latents, latent_ids, image_ids
+
+    @torch.no_grad()
+    def __call__(self, image=None, prompt=None, prompt_2=None, negative_prompt=None, negative_prompt_2=None,
+                 true_cfg_scale=1.0, height=None, width=None, num_inference_steps=28, sigmas=None,
+                 guidance_scale=3.5, num_images_per_prompt=1, generator=None, latents=None, prompt_embeds=None,
+                 pooled_prompt_embeds=None, negative_prompt_embeds=None, negative_pooled_prompt_embeds=None,
+                 output_type="pil", return_dict=True, joint_attention_kwargs=None, callback_on_step_end=None,
+                 callback_on_step_end_tensor_inputs=("latents",), max_sequence_length=512,
+                 max_area=1024 ** 2, _auto_resize=True):
+        if prompt is not None or prompt_2 is not None or negative_prompt is not None:
+            raise NotImplementedError("string prompts need the T5/CLIP encoders (reused as-is from transformers); "
+                                      "pass prompt_embeds / pooled_prompt_embeds like every reference caller does")
+        device = self.device
+        height = height or self.default_sample_size * self.vae_scale_factor
+        width = width or self.default_sample_size * self.vae_scale_factor
+        multiple_of = self.vae_scale_factor * 2
+        oh, ow = height, width
+        height, width = helpers.fit_to_max_area(height, width, max_area, multiple_of)
+        if (height, width) != (oh, ow):
+            print(f"Generation `height` and `width` have been adjusted to {height} and {width} to fit the model "
+                  f"requirements.")
+        self.check_inputs(height, width, prompt_embeds, pooled_prompt_embeds, max_sequence_length)
+        self._guidance_scale = guidance_scale
+        self._interrupt = False
+        has_neg = negative_prompt_embeds is not None and negative_pooled_prompt_embeds is not None
+        if true_cfg_scale > 1 and has_neg:
+            raise NotImplementedError("true-CFG (second transformer pass) is a later row of SURVEY.md 8(f); "
+                                      "no reference caller enables it")
+        batch_size = prompt_embeds.shape[0] * num_images_per_prompt
+        prompt_embeds = prompt_embeds.to(device=device, dtype=BF16)
+        pooled_prompt_embeds = pooled_prompt_embeds.to(device=device, dtype=BF16)
+        if num_images_per_prompt > 1:
+            prompt_embeds = prompt_embeds.repeat_interleave(num_images_per_prompt, dim=0)
+            pooled_prompt_embeds = pooled_prompt_embeds.repeat_interleave(num_images_per_prompt, dim=0)
+        text_ids = torch.zeros(prompt_embeds.shape[1], 3, device=device, dtype=BF16)  # :436
+
+        # 3. condition image: preferred-resolution snap + nearest resize (VaeImageProcessor tensor path)
+        if image is not None and not (isinstance(image, torch.Tensor) and image.size(1) == self.latent_channels):
+            if not isinstance(image, torch.Tensor) or image.dim() != 4:
+                raise NotImplementedError("pass the condition image as a [N,3,H,W] tensor in [-1,1] (cli.py:99-116)")
+            ih, iw = helpers.preferred_condition_size(image.shape[2], image.shape[3], multiple_of, _auto_resize)
+            if (ih, iw) != tuple(image.shape[2:]):
+                image = torch.nn.functional.interpolate(image.float(), size=(ih, iw))
+            if image.min() >= 0:  # VaeImageProcessor.preprocess: normalise only [0,1] inputs
+                image = 2.0 * image - 1.0
+
+        # 4. latents
+        num_channels_latents = self.transformer.config.in_channels // 4
+        latents, image_latents, latent_ids, image_ids = self.prepare_latents(
+            image, batch_size, num_channels_latents, height, width, BF16, device, generator, latents)
+        S_tgt = latents.shape[1]
+        if image_ids is not None:
+            latent_ids = torch.cat([latent_ids, image_ids], dim=0)
+            tokens = torch.cat([latents, image_latents], dim=1).contiguous()  # built ONCE, updated in place
+        else:
+            tokens = latents.contiguous().clone()
+
+        # 5. timesteps (host float32 arithmetic, like diffusers' numpy path)
+        sig = np.linspace(1.0, 1 / num_inference_steps, num_inference_steps) if sigmas is None else sigmas
+        cfg = self.scheduler.config
+        mu = helpers.calculate_shift(S_tgt, cfg.get("base_image_seq_len", 256), cfg.get("max_image_seq_len", 4096),
+                                     cfg.get("base_shift", 0.5), cfg.get("max_shift", 1.15))
+        self.scheduler.set_timesteps(sigmas=sig, mu=mu, device="cpu")
+        timesteps = self.scheduler.timesteps
+        self._num_timesteps = len(timesteps)
+        # `t.expand(B).to(bf16)` then `/ 1000` (flux_pipeline.py:1065,1069): all steps prepared up front
+        t_model = (timesteps.to(BF16) / 1000)[:, None].expand(-1, batch_size).contiguous().to(device)
+        guidance = None
+        if self.transformer.config.guidance_embeds:
+            guidance = torch.full([batch_size], guidance_scale, device=device, dtype=torch.float32)
+        self.scheduler.set_begin_index(0)
+
+        # 6. denoising loop: no allocation, no host sync
+        for i in range(len(timesteps)):
+            if self._interrupt:
+                continue
+            noise_pred = self.transformer(
+                hidden_states=tokens, timestep=t_model[i], guidance=guidance,
+                pooled_projections=pooled_prompt_embeds, encoder_hidden_states=prompt_embeds,
+                txt_ids=text_ids, img_ids=latent_ids, joint_attention_kwargs=joint_attention_kwargs or {},
+                return_dict=False)[0]
+            ops.euler_step(tokens, noise_pred, S_tgt, self.scheduler.dsigma(i))
+            if callback_on_step_end is not None:
+                out = callback_on_step_end(self, i, timesteps[i], {"latents": tokens[:, :S_tgt]})
+                if out and "latents" in out:
+                    tokens[:, :S_tgt].copy_(out["latents"])
+
+        latents = tokens[:, :S_tgt]
+        if output_type == "latent":
+            image_out = latents.contiguous()
+        else:
+            z = self._unpack_latents(latents, height, width, self.vae_scale_factor).contiguous()
+            vcfg = self.vae.config
+            img = self.vae.decode(z, return_dict=False, pre_div=vcfg.scaling_factor, pre_add=vcfg.shift_factor)[0]
+            image_out = self.postprocess(img, output_type)
+        if not return_dict:
+            return (image_out,)
+        return FluxPipelineOutput(images=image_out, latents=latents)  # .latents: packed final latents (DP gather)
+
+    @staticmethod
+    def postprocess(image, output_type="pil"):
+        """VaeImageProcessor.postprocess: denormalise, clamp; 'pt' tensor, 'np' float NHWC, 'pil' images."""
+        if output_type == "pt_raw":
+            return image
+        x = (image / 2 + 0.5).clamp(0, 1)
+        if output_type == "pt":
+            return x
+        arr = x.cpu().permute(0, 2, 3, 1).float().numpy()
+        if output_type == "np":
+            return arr
+        from PIL import Image
+        arr = (arr * 255).round().astype("uint8")
+        return [Image.fromarray(a) for a in arr]

@@ -153,18 +153,18 @@ class HipFluxTransformer2DModel(nn.Module):
         return ws
 
     def _rope(self, txt_ids, img_ids):
-        key = (txt_ids.shape[0], img_ids.shape[0], float(img_ids.float().sum()), float(txt_ids.float().sum()))
+        # Step-invariant: keyed on the identity of the id tensors (the pipeline passes the same objects for
+        # all 28 steps), so the hot loop never reads ids back to the host.  Strong refs keep the ids alive.
+        key = (id(txt_ids), id(img_ids), txt_ids._version, img_ids._version)
         hit = self._rope_cache.get(key)
         if hit is None:
-            if txt_ids.dim() == 3:
-                txt_ids = txt_ids[0]
-            if img_ids.dim() == 3:
-                img_ids = img_ids[0]
-            ids = torch.cat([txt_ids.float().cpu(), img_ids.float().cpu()], dim=0)
+            t2 = txt_ids[0] if txt_ids.dim() == 3 else txt_ids
+            i2 = img_ids[0] if img_ids.dim() == 3 else img_ids
+            ids = torch.cat([t2.float().cpu(), i2.float().cpu()], dim=0)
             cos, sin = rope_tables(ids, self.config.axes_dims_rope)
-            hit = (cos.to(self.device), sin.to(self.device))
+            hit = (cos.to(self.device), sin.to(self.device), txt_ids, img_ids)
             self._rope_cache = {key: hit}
-        return hit
+        return hit[0], hit[1]
 
     # ---- forward ----------------------------------------------------------------------------------------
     @torch.no_grad()

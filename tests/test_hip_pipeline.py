@@ -1,0 +1,95 @@
+"""GPU parity of the whole edit (FluxKontextPipeline on HIP) against the CPU oracle pipeline, plus the
+size-independent properties used at BASELINE sizes."""
+import pytest
+import torch
+
+from conftest import report
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def test_smoke_entry():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as g
+    g.smoke()
+
+
+def test_edit_matches_oracle_pipeline():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd import flux_spec
+    from gpt_image_edit_amd.pipeline import FluxKontextPipeline
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    from gpt_image_edit_amd.vae import HipAutoencoderKL
+    from oracle import pipeline as opipe
+
+    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=1, num_single_layers=2)
+    sd_f = {k: v.to(BF) for k, v in flux_spec.synthetic_state(flux_spec.flux_param_shapes(cfg), seed=21).items()}
+    sd_v = {k: v.to(BF) for k, v in flux_spec.synthetic_state(flux_spec.vae_param_shapes(), seed=22).items()}
+    tr = HipFluxTransformer2DModel(cfg, device="cuda"); tr.load_state_dict(sd_f)
+    vae = HipAutoencoderKL(device="cuda"); vae.load_state_dict(sd_v)
+    pipe = FluxKontextPipeline(tr, vae)
+    g = torch.Generator().manual_seed(7)
+    B, H, W, Hc, Wc = 2, 64, 96, 96, 64      # target and condition of different shapes
+    cond = torch.rand(B, 3, Hc, Wc, generator=g) * 2 - 1
+    emb = torch.randn(B, 40, 4096, generator=g).to(BF)
+    pooled = torch.randn(B, 768, generator=g).to(BF)
+    noise = torch.randn(B, 16, H // 8, W // 8, generator=g).to(BF)
+    steps = 3
+    out = pipe(image=cond.cuda(), prompt_embeds=emb.cuda(), pooled_prompt_embeds=pooled.cuda(), height=H, width=W,
+               num_inference_steps=steps, guidance_scale=4.0, latents=pipe._pack_latents(noise, B, 16, H // 8, W // 8).cuda(),
+               output_type="pt_raw", max_area=H * W, _auto_resize=False)
+    ref = opipe.kontext_edit(sd_f, sd_v, cond, emb, pooled, noise, H, W, num_inference_steps=steps,
+                             guidance_scale=4.0, flux_config=cfg)
+    sd_f32, sd_v32 = {k: v.float() for k, v in sd_f.items()}, {k: v.float() for k, v in sd_v.items()}
+    ref32 = opipe.kontext_edit(sd_f32, sd_v32, cond.to(BF).float(), emb.float(), pooled.float(), noise.float(), H, W,
+                               num_inference_steps=steps, guidance_scale=4.0, flux_config=cfg)
+    d_l = report("edit latents vs bf16-oracle", out.latents, ref["latents"])
+    d_l32 = report("edit latents vs fp32-oracle", out.latents, ref32["latents"])
+    fl_l = report("edit latents bf16-oracle vs fp32-oracle (floor)", ref["latents"], ref32["latents"])
+    d_i32 = report("edit image vs fp32-oracle", out.images, ref32["image"])
+    fl_i = report("edit image bf16-oracle vs fp32-oracle (floor)", ref["image"], ref32["image"])
+    assert out.images.shape == (B, 3, H, W)
+    sl, si = ref32["latents"].abs().max().item(), ref32["image"].abs().max().item()
+    assert d_l32.max().item() <= max(2.5 * fl_l.max().item(), 3e-2 * sl)
+    assert d_i32.max().item() <= max(2.5 * fl_i.max().item(), 5e-2 * si)
+    assert d_l.max().item() <= 6e-2 * sl
+
+
+def test_full_size_properties():
+    """At the BASELINE size (512^2 edit, S = 2560, full-width blocks) the oracle is too slow to run whole,
+    so check size-independent properties of the HIP path: determinism, batch independence (a sample's
+    result does not depend on its neighbours) and linearity of the Euler update."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd import flux_spec, ops
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=2, num_single_layers=2)
+    m = HipFluxTransformer2DModel(cfg, device="cuda", init="synthetic", seed=3)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    B, S_txt, S_img = 2, 512, 2048
+    hs = torch.randn(B, S_img, 64, generator=g, device="cuda").to(BF)
+    enc = torch.randn(B, S_txt, 4096, generator=g, device="cuda").to(BF)
+    pooled = torch.randn(B, 768, generator=g, device="cuda").to(BF)
+    t = torch.tensor([0.5, 0.25], device="cuda").to(BF)
+    gd = torch.full((B,), 3.5, device="cuda")
+    from gpt_image_edit_amd.helpers import _prepare_latent_image_ids as ids
+    img_ids = torch.cat([ids(1, 32, 32, "cuda", BF), ids(1, 32, 32, "cuda", BF)])
+    img_ids[1024:, 0] = 1
+    txt_ids = torch.zeros(S_txt, 3, device="cuda", dtype=BF)
+    kw = dict(txt_ids=txt_ids, img_ids=img_ids, return_dict=False)
+    o2 = m(hidden_states=hs, encoder_hidden_states=enc, pooled_projections=pooled, timestep=t, guidance=gd, **kw)[0].clone()
+    o2b = m(hidden_states=hs, encoder_hidden_states=enc, pooled_projections=pooled, timestep=t, guidance=gd, **kw)[0].clone()
+    assert torch.equal(o2, o2b), "forward is not deterministic"
+    o1 = m(hidden_states=hs[1:], encoder_hidden_states=enc[1:], pooled_projections=pooled[1:], timestep=t[1:],
+           guidance=gd[1:], **kw)[0]
+    assert torch.equal(o1[0], o2[1]), "a sample's output depends on its batch neighbours"
+    assert torch.isfinite(o2.float()).all()
+    # Euler: two half steps with the same velocity == one full step up to one bf16 rounding per step
+    x = torch.randn(1, 1024, 64, generator=g, device="cuda").to(BF)
+    v = torch.randn(1, 1024, 64, generator=g, device="cuda").to(BF)
+    a = x.clone(); ops.euler_step(a, v, 1024, -0.0625)
+    b = x.clone(); ops.euler_step(b, v, 1024, -0.03125); ops.euler_step(b, v, 1024, -0.03125)
+    assert (a.float() - b.float()).abs().max().item() <= 2 ** -6 * (1 + x.float().abs().max().item())
