@@ -1,0 +1,181 @@
+"""CPU tests: the oracle and the product's host logic against the committed golden vectors.
+
+helpers.npz / anyres.npz were produced by EXECUTING THE REFERENCE's own functions (oracle/make_golden.py);
+torch_ops.npz pins torch's CPU definitions of the building-block ops; oracle_selfpin.npz guards the
+(upstream-unpinned) MMDiT / VAE / scheduler restatement against accidental edits.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpt_image_edit_amd import anyres_util, flux_spec, helpers as phelpers
+from gpt_image_edit_amd.scheduler import FlowMatchEulerDiscreteScheduler
+from oracle import helpers as ohelpers
+from oracle import mmdit, scheduler as osched, vae as ovae
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_pack_unpack_ids_shift_match_reference(golden_dir):
+    g = _load(golden_dir, "helpers.npz")
+    x = torch.from_numpy(g["pack_in"])
+    for impl_pack, impl_unpack in ((ohelpers.pack_latents, ohelpers.unpack_latents),
+                                   (lambda t: phelpers._pack_latents(t, *t.shape), phelpers._unpack_latents)):
+        packed = impl_pack(x)
+        assert np.array_equal(packed.numpy(), g["pack_out"])
+        assert np.array_equal(impl_unpack(packed, 64, 96, 8).numpy(), g["unpack_out"])
+        assert np.array_equal(impl_unpack(torch.from_numpy(g["unpack2_in"]), 32, 48, 8).numpy(), g["unpack2_out"])
+    assert np.array_equal(ohelpers.prepare_latent_image_ids(4, 6).numpy(), g["ids_4x6"])
+    assert np.array_equal(phelpers._prepare_latent_image_ids(1, 4, 6, "cpu", torch.float32).numpy(), g["ids_4x6"])
+    ids_bf = phelpers._prepare_latent_image_ids(3, 64, 64, "cpu", torch.bfloat16).float().numpy()
+    assert np.array_equal(ids_bf, g["ids_64x64_bf16"])
+    assert np.array_equal(ohelpers.prepare_latent_image_ids(64, 64, torch.bfloat16).float().numpy(), g["ids_64x64_bf16"])
+    for fn in (ohelpers.calculate_shift, phelpers.calculate_shift):
+        mu = np.array([fn(int(s)) for s in g["shift_seq"]])
+        assert np.array_equal(mu, g["shift_mu"])
+        mu2 = np.array([fn(int(s), 256, 4096, 0.5, 1.16) for s in g["shift_seq"]])
+        assert np.array_equal(mu2, g["shift_mu_custom"])
+    assert abs(ohelpers.calculate_shift(4096) - 1.15) < 1e-12 and abs(ohelpers.calculate_shift(1024) - 0.63) < 5e-3
+
+
+def test_pack_unpack_roundtrip_edge_cases():
+    for shape in [(1, 16, 2, 2), (3, 16, 128, 128), (2, 4, 6, 10)]:
+        x = torch.randn(*shape)
+        p = ohelpers.pack_latents(x)
+        assert p.shape == (shape[0], shape[2] * shape[3] // 4, shape[1] * 4)
+        assert torch.equal(ohelpers.unpack_latents(p, shape[2] * 8, shape[3] * 8), x)
+        assert torch.equal(phelpers._unpack_latents(phelpers._pack_latents(x, *shape), shape[2] * 8, shape[3] * 8, 8), x)
+
+
+def test_anyres_matches_reference(golden_dir):
+    g = _load(golden_dir, "anyres.npz")
+    modes = [str(m) for m in g["modes"]]
+    for row in g["table"]:
+        h, w, mi, anchor, rw, rh, nh, nw, ch, cw, mh, mw = (int(v) for v in row)
+        for mod in (ohelpers, anyres_util):
+            assert mod.pick_ratio(h, w, modes[mi]) == (rw, rh)
+            assert mod.dynamic_resize(h, w, modes[mi], anchor_pixels=anchor) == (nh, nw)
+            assert mod.compute_size(rw, rh, 32, anchor_pixels=anchor) == (ch, cw)
+            assert mod.compute_size(rw, rh, 32, min_pixels=256 * 256, max_pixels=768 * 768) == (mh, mw)
+    # the cli default: 1024x1024 anchor, any_11ratio (cli.py:82-97)
+    assert anyres_util.dynamic_resize(768, 1024, "any_11ratio", anchor_pixels=1024 * 1024) == ohelpers.dynamic_resize(
+        768, 1024, "any_11ratio", anchor_pixels=1024 * 1024)
+
+
+def test_resolution_quirks_F6_F7():
+    # F6: any requested size is rescaled to max_area (default 1024^2) and floored to multiples of 16
+    assert ohelpers.kontext_target_size(512, 512) == (1024, 1024)
+    assert phelpers.fit_to_max_area(512, 512, 1024 ** 2, 16) == (1024, 1024)
+    assert phelpers.fit_to_max_area(512, 512, 512 ** 2, 16) == (512, 512)
+    assert phelpers.fit_to_max_area(720, 1280, 1024 ** 2, 16) == ohelpers.kontext_target_size(720, 1280)
+    # F7: a pixel condition image snaps to the nearest preferred ~1 MP resolution
+    assert ohelpers.preferred_condition_size(512, 512) == (1024, 1024)
+    assert phelpers.preferred_condition_size(512, 512, 16) == (1024, 1024)
+    assert phelpers.preferred_condition_size(512, 512, 16, auto_resize=False) == (512, 512)
+    for h, w in [(480, 854), (1080, 1920), (1000, 333), (37, 41)]:
+        assert phelpers.preferred_condition_size(h, w, 16) == ohelpers.preferred_condition_size(h, w)
+
+
+def test_torch_building_blocks_are_pinned(golden_dir):
+    g = _load(golden_dir, "torch_ops.npz")
+    x = torch.from_numpy(g["x"])
+    tol = dict(rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(F.gelu(x, approximate="tanh"), torch.from_numpy(g["gelu_tanh"]), **tol)
+    torch.testing.assert_close(F.silu(x), torch.from_numpy(g["silu"]), **tol)
+    torch.testing.assert_close(mmdit.layer_norm(x), torch.from_numpy(g["layer_norm"]), **tol)
+    img = torch.from_numpy(g["gn_in"])
+    gn = F.group_norm(img, 32, torch.from_numpy(g["gn_w"]), torch.from_numpy(g["gn_b"]), 1e-6)
+    torch.testing.assert_close(gn, torch.from_numpy(g["group_norm"]), rtol=1e-4, atol=1e-5)
+    q, k, v = (torch.from_numpy(g[n]) for n in "qkv")
+    torch.testing.assert_close(F.scaled_dot_product_attention(q, k, v), torch.from_numpy(g["sdpa"]), rtol=1e-4, atol=1e-5)
+    ref = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(16), -1) @ v
+    torch.testing.assert_close(ref, torch.from_numpy(g["sdpa"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(F.interpolate(img[:, :4], scale_factor=2.0, mode="nearest"), torch.from_numpy(g["nearest2x"]))
+    w, b = torch.from_numpy(g["conv_w"]), torch.from_numpy(g["conv_b"])
+    torch.testing.assert_close(F.conv2d(img, w, b, padding=1), torch.from_numpy(g["conv3x3"]), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(F.conv2d(F.pad(img, (0, 1, 0, 1)), w, b, stride=2), torch.from_numpy(g["conv3x3_s2"]),
+                               rtol=1e-4, atol=1e-4)
+
+
+def test_oracle_selfpin(golden_dir):
+    g = _load(golden_dir, "oracle_selfpin.npz")
+    cfg = dict(num_layers=2, num_single_layers=2, attention_head_dim=16, num_attention_heads=4,
+               joint_attention_dim=32, pooled_projection_dim=24, in_channels=16, out_channels=16,
+               axes_dims_rope=(4, 6, 6))
+    sd = flux_spec.synthetic_state(flux_spec.flux_param_shapes(cfg), seed=3)
+    gen = torch.Generator().manual_seed(5)
+    hs = torch.randn(2, 12, 16, generator=gen)
+    enc = torch.randn(2, 5, 32, generator=gen)
+    pooled = torch.randn(2, 24, generator=gen)
+    img_ids = torch.cat([ohelpers.prepare_latent_image_ids(2, 3), ohelpers.prepare_latent_image_ids(2, 3, first=1.0)])
+    txt_ids = torch.zeros(5, 3)
+    y = mmdit.flux_forward(sd, hs, enc, pooled, torch.tensor([0.75, 0.31]), img_ids, txt_ids, torch.tensor([3.5, 1.0]),
+                           config=cfg)
+    torch.testing.assert_close(y, torch.from_numpy(g["mmdit_tiny_out"]), rtol=1e-4, atol=1e-5)
+    cos, sin = mmdit.rope_tables(torch.cat([txt_ids, img_ids]), (4, 6, 6))
+    torch.testing.assert_close(cos, torch.from_numpy(g["rope_cos"]))
+    torch.testing.assert_close(sin, torch.from_numpy(g["rope_sin"]))
+    torch.testing.assert_close(mmdit.sinusoid_256(torch.tensor([0.0, 1.0, 750.0, 3504.0])), torch.from_numpy(g["sinusoid"]),
+                               rtol=1e-5, atol=1e-6)
+    vcfg = dict(block_out_channels=(32, 32, 64, 64), latent_channels=4)
+    vsd = flux_spec.synthetic_state(flux_spec.vae_param_shapes(vcfg), seed=4)
+    z = torch.randn(1, 4, 4, 6, generator=gen)
+    torch.testing.assert_close(ovae.decode(vsd, z), torch.from_numpy(g["vae_dec_tiny"]), rtol=1e-4, atol=1e-5)
+    im = torch.rand(1, 3, 32, 48, generator=gen) * 2 - 1
+    torch.testing.assert_close(ovae.encode_moments(vsd, im), torch.from_numpy(g["vae_enc_tiny"]), rtol=1e-4, atol=1e-5)
+
+
+def test_scheduler_host_logic(golden_dir):
+    g = _load(golden_dir, "oracle_selfpin.npz")
+    ts, sg = osched.shifted_sigmas(28, 1.15)
+    assert np.array_equal(ts.numpy(), g["sched_timesteps_mu1.15"]) and np.array_equal(sg.numpy(), g["sched_sigmas_mu1.15"])
+    s = FlowMatchEulerDiscreteScheduler()
+    s.set_timesteps(sigmas=np.linspace(1.0, 1 / 28, 28), mu=1.15, device="cpu")
+    assert np.array_equal(s.timesteps.numpy(), ts.numpy()) and np.array_equal(s.sigmas.numpy(), sg.numpy())
+    assert s.order == 1 and s.config.get("base_image_seq_len", 256) == 256 and s.config.get("max_shift") == 1.15
+    # first sigma is exactly 1 (t = 1000), last appended sigma is 0, strictly decreasing
+    assert float(sg[0]) == 1.0 and float(sg[-1]) == 0.0 and bool((sg[1:] < sg[:-1]).all())
+    for i in range(28):
+        assert s.dsigma(i) == float(sg[i + 1] - sg[i])
+    with pytest.raises(ValueError):
+        FlowMatchEulerDiscreteScheduler().set_timesteps(sigmas=[1.0, 0.5], device="cpu")  # mu missing
+    # closed form of the dynamic shift
+    mu = 0.63
+    ts4, sg4 = osched.shifted_sigmas(4, mu)
+    lin = np.linspace(1.0, 0.25, 4)
+    np.testing.assert_allclose(sg4[:-1].numpy(), math.exp(mu) / (math.exp(mu) + (1 / lin - 1)), rtol=1e-6)
+
+
+def test_euler_step_reference_rounding():
+    # 0-dim fp32 sigma times a bf16 tensor is formed in bf16 (torch promotion), then added in fp32
+    v = torch.tensor([1.5, -2.25, 0.3333], dtype=torch.bfloat16)
+    x = torch.tensor([0.1, 0.2, 0.3], dtype=torch.bfloat16)
+    out = osched.euler_step(v, torch.tensor(0.9), torch.tensor(0.8765), x)
+    assert out.dtype == torch.bfloat16
+    ds = (torch.tensor(0.8765) - torch.tensor(0.9)).to(torch.bfloat16).float()
+    manual = (x.float() + (ds * v.float()).to(torch.bfloat16).float()).to(torch.bfloat16)
+    assert torch.equal(out, manual)
+
+
+def test_param_layout_matches_checkpoint_names():
+    shapes = flux_spec.flux_param_shapes()
+    assert shapes["transformer_blocks.18.norm1.linear.weight"] == (18432, 3072)
+    assert shapes["single_transformer_blocks.37.proj_out.weight"] == (3072, 15360)
+    assert shapes["time_text_embed.guidance_embedder.linear_1.weight"] == (3072, 256)
+    assert shapes["proj_out.weight"] == (64, 3072) and shapes["context_embedder.weight"] == (3072, 4096)
+    n = sum(math.prod(s) for s in shapes.values())
+    assert 11.8e9 < n < 12.0e9  # ~11.9 B parameters
+    v = flux_spec.vae_param_shapes()
+    assert v["decoder.conv_in.weight"] == (512, 16, 3, 3) and v["encoder.conv_out.weight"] == (32, 512, 3, 3)
+    assert "decoder.up_blocks.2.resnets.0.conv_shortcut.weight" in v and "decoder.up_blocks.0.resnets.0.conv_shortcut.weight" not in v
+    pj = flux_spec.projector_param_shapes()
+    assert pj["denoise_projector.0.weight"] == (12288, 3584) and pj["denoise_projector.2.weight"] == (4096, 12288)
+    a = flux_spec.synthetic_state({"x.weight": (4, 4), "x.bias": (4,)}, seed=1)
+    b = flux_spec.synthetic_state({"x.bias": (4,), "x.weight": (4, 4)}, seed=1)
+    assert torch.equal(a["x.weight"], b["x.weight"]) and torch.equal(a["x.bias"], b["x.bias"])
