@@ -33,17 +33,27 @@ FK_DEV float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
 FK_DEV float gelu_tanh_f(float x) {
   // torch: 0.5 * x * (1 + tanh(sqrt(2/pi) * (x + 0.044715 x^3)))
+  // tanh(u) = 1 - 2 / (exp(2u) + 1) on the hardware exp2 / rcp (relative error ~1e-6, far below the
+  // bf16 rounding that follows); saturates correctly: exp -> inf gives 1, exp -> 0 gives -1.
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float inner = k0 * (x + k1 * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(inner));
+  const float inner = k0 * (x + k1 * x * x * x);
+  const float e = __builtin_amdgcn_exp2f(inner * 2.885390081777927f);  // exp(2 u)
+  const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+  return 0.5f * x * (1.0f + th);
 }
-FK_DEV float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// x * sigmoid(x); hardware exp2 / rcp, same accuracy argument as above
+FK_DEV float silu_f(float x) {
+  const float e = __builtin_amdgcn_exp2f(-x * 1.4426950408889634f);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
 
 FK_DEV int64_t fk_row_offset(const fk_rows& r, int64_t m) {
   if (r.rows_per_batch <= 0) return m * r.ld;
   int64_t b = m / r.rows_per_batch;
   return b * r.batch_stride + (m - b * r.rows_per_batch) * r.ld;
 }
+
+int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t stream);  // gemm2_bf16.hip
 
 // host side ---------------------------------------------------------------------------------------
 void fk_set_error(const char* fmt, ...);

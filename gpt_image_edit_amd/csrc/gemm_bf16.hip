@@ -17,6 +17,8 @@
 // Tile order: XCD-aware (block b runs on XCD b % 8, so each XCD is given a contiguous chunk of the
 // tile list) and grouped 8 m-tiles deep so the ~64 tiles resident on one XCD form an ~8x8 patch that
 // shares A / W K-slices through that XCD's L2.
+#include <stdlib.h>
+
 #include "fk_common.h"
 
 namespace {
@@ -278,10 +280,7 @@ int launch(const fk_gemm_args& p, hipStream_t stream, const ConvGeom& g = ConvGe
 
 }  // namespace
 
-extern "C" int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream_) {
-  FK_CHECK_ARG(args != nullptr, "fk_gemm_bf16: null args");
-  const fk_gemm_args& p = *args;
-  hipStream_t stream = (hipStream_t)stream_;
+static int validate_gemm(const fk_gemm_args& p) {
   FK_CHECK_ARG(p.A && p.W && p.C, "fk_gemm_bf16: null A/W/C");
   FK_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "fk_gemm_bf16: bad M/N/K %d %d %d", p.M, p.N, p.K);
   FK_CHECK_ARG(p.K % BK == 0, "fk_gemm_bf16: K=%d must be a multiple of %d", p.K, BK);
@@ -306,6 +305,36 @@ extern "C" int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream_) {
                      p.gate_rows_per_batch > 0,
                  "fk_gemm_bf16: gate pointer/stride invalid");
   }
+  FK_CHECK_ARG(p.epilogue >= FK_EPI_NONE && p.epilogue <= FK_EPI_SCALE, "fk_gemm_bf16: unknown epilogue %d", p.epilogue);
+  return FK_OK;
+}
+
+// FK_GEMM_IMPL=small forces the 128x128 kernel, =large the 256x128 LDS-DMA kernel (A/B benchmarking).
+static int gemm_impl_override() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FK_GEMM_IMPL");
+    v = !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'l' ? 2 : 0));
+  }
+  return v;
+}
+
+// FK_GEMM_BN=128|256 forces the N tile of the 256-row kernel (default: chosen per problem size).
+static int gemm_bn_override() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FK_GEMM_BN");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+extern "C" int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream_) {
+  FK_CHECK_ARG(args != nullptr, "fk_gemm_bf16: null args");
+  const fk_gemm_args& p = *args;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int rc = validate_gemm(p);
+  if (rc != FK_OK) return rc;
   if (p.out_fp32) {
     switch (p.epilogue) {
       case FK_EPI_NONE: return launch<FK_EPI_NONE, true>(p, stream);
@@ -313,6 +342,8 @@ extern "C" int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream_) {
       default: fk_set_error("fk_gemm_bf16: fp32 output supports FK_EPI_NONE / FK_EPI_SCALE only"); return FK_EUNSUPPORTED;
     }
   }
+  const int ov = gemm_impl_override();
+  if (ov == 2 || (ov == 0 && p.M >= 192)) return fk_gemm2_launch(&p, 1, gemm_bn_override(), stream);
   switch (p.epilogue) {
     case FK_EPI_NONE: return launch<FK_EPI_NONE, false>(p, stream);
     case FK_EPI_GELU_TANH: return launch<FK_EPI_GELU_TANH, false>(p, stream);
@@ -322,6 +353,35 @@ extern "C" int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream_) {
     case FK_EPI_SCALE: return launch<FK_EPI_SCALE, false>(p, stream);
     default: fk_set_error("fk_gemm_bf16: unknown epilogue %d", p.epilogue); return FK_EUNSUPPORTED;
   }
+}
+
+extern "C" int fk_gemm_bf16_grouped(const fk_gemm_args* args, int32_t n, fk_stream_t stream_) {
+  FK_CHECK_ARG(args != nullptr && n >= 1 && n <= FK_MAX_GROUP, "fk_gemm_bf16_grouped: 1 <= n <= %d", FK_MAX_GROUP);
+  for (int i = 0; i < n; ++i) {
+    const int rc = validate_gemm(args[i]);
+    if (rc != FK_OK) return rc;
+    FK_CHECK_ARG(!args[i].out_fp32, "fk_gemm_bf16_grouped: bf16 output only");
+    FK_CHECK_ARG(args[i].N == args[0].N && args[i].K == args[0].K && args[i].epilogue == args[0].epilogue,
+                 "fk_gemm_bf16_grouped: all problems must share N, K and the epilogue");
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  if (gemm_impl_override() == 1) {  // A/B: one 128x128 launch per problem
+    for (int i = 0; i < n; ++i) {
+      fk_gemm_args one = args[i];
+      int rc;
+      switch (one.epilogue) {
+        case FK_EPI_NONE: rc = launch<FK_EPI_NONE, false>(one, stream); break;
+        case FK_EPI_GELU_TANH: rc = launch<FK_EPI_GELU_TANH, false>(one, stream); break;
+        case FK_EPI_SILU: rc = launch<FK_EPI_SILU, false>(one, stream); break;
+        case FK_EPI_GATE_RES: rc = launch<FK_EPI_GATE_RES, false>(one, stream); break;
+        case FK_EPI_RES: rc = launch<FK_EPI_RES, false>(one, stream); break;
+        default: rc = launch<FK_EPI_SCALE, false>(one, stream); break;
+      }
+      if (rc != FK_OK) return rc;
+    }
+    return FK_OK;
+  }
+  return fk_gemm2_launch(args, n, gemm_bn_override(), stream);
 }
 
 // Conv2d over NHWC bf16 as an implicit GEMM on the same MFMA main loop (A rows gathered per filter tap,

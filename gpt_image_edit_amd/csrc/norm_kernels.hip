@@ -11,8 +11,10 @@ namespace {
 template <int NV>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16_t* x, fk_rows xr, bf16_t* out,
                                                           fk_rows outr, const bf16_t* shift,
-                                                          const bf16_t* scale, int64_t mod_bs,
-                                                          int64_t mod_rpb, int64_t M, float eps) {
+                                                          const bf16_t* scale, const bf16_t* shift_b,
+                                                          const bf16_t* scale_b, int64_t split,
+                                                          int64_t mod_bs, int64_t mod_rpb, int64_t M,
+                                                          float eps) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -46,8 +48,9 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16_t* x, fk_ro
   const float rstd = rsqrtf(sq * (1.0f / D) + eps);
 
   const int64_t b = row / mod_rpb;
-  const bf16_t* sc = scale + b * mod_bs + lane * 8;
-  const bf16_t* sh = shift + b * mod_bs + lane * 8;
+  const bool second = (row - b * mod_rpb) >= split;  // rows >= split of each batch use the second vector set
+  const bf16_t* sc = (second ? scale_b : scale) + b * mod_bs + lane * 8;
+  const bf16_t* sh = (second ? shift_b : shift) + b * mod_bs + lane * 8;
   bf16_t* op = out + fk_row_offset(outr, row) + lane * 8;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -167,10 +170,12 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const bf16_t* qkv, bf16_t
 
 }  // namespace
 
-extern "C" int fk_ln_modulate_bf16(const void* x, fk_rows xr, void* out, fk_rows outr, const void* shift,
-                                   const void* scale, int64_t mod_batch_stride, int64_t mod_rows_per_batch,
-                                   int64_t M, int32_t D, float eps, fk_stream_t stream_) {
-  FK_CHECK_ARG(x && out && shift && scale, "fk_ln_modulate_bf16: null pointer");
+extern "C" int fk_ln_modulate2_bf16(const void* x, fk_rows xr, void* out, fk_rows outr, const void* shift,
+                                    const void* scale, const void* shift_b, const void* scale_b, int64_t split,
+                                    int64_t mod_batch_stride, int64_t mod_rows_per_batch, int64_t M, int32_t D,
+                                    float eps, fk_stream_t stream_) {
+  FK_CHECK_ARG(x && out && shift && scale && shift_b && scale_b, "fk_ln_modulate_bf16: null pointer");
+  FK_CHECK_ARG(((uintptr_t)shift_b % 16 == 0) && ((uintptr_t)scale_b % 16 == 0), "fk_ln_modulate_bf16: alignment");
   FK_CHECK_ARG(M > 0 && mod_rows_per_batch > 0, "fk_ln_modulate_bf16: bad M / rows per batch");
   FK_CHECK_ARG(xr.ld % 8 == 0 && outr.ld % 8 == 0 && mod_batch_stride % 8 == 0 &&
                    (xr.rows_per_batch <= 0 || xr.batch_stride % 8 == 0) &&
@@ -185,7 +190,8 @@ extern "C" int fk_ln_modulate_bf16(const void* x, fk_rows xr, void* out, fk_rows
   case NV * 512:                                                                                    \
     hipLaunchKernelGGL(ln_modulate_kernel<NV>, grid, block, 0, stream, (const bf16_t*)x, xr,        \
                        (bf16_t*)out, outr, (const bf16_t*)shift, (const bf16_t*)scale,              \
-                       mod_batch_stride, mod_rows_per_batch, M, eps);                               \
+                       (const bf16_t*)shift_b, (const bf16_t*)scale_b, split, mod_batch_stride,     \
+                       mod_rows_per_batch, M, eps);                                                 \
     break;
   switch (D) {
     FK_LN_CASE(1)
@@ -198,6 +204,13 @@ extern "C" int fk_ln_modulate_bf16(const void* x, fk_rows xr, void* out, fk_rows
 #undef FK_LN_CASE
   FK_CHECK_LAUNCH("fk_ln_modulate_bf16");
   return FK_OK;
+}
+
+extern "C" int fk_ln_modulate_bf16(const void* x, fk_rows xr, void* out, fk_rows outr, const void* shift,
+                                   const void* scale, int64_t mod_batch_stride, int64_t mod_rows_per_batch,
+                                   int64_t M, int32_t D, float eps, fk_stream_t stream) {
+  return fk_ln_modulate2_bf16(x, xr, out, outr, shift, scale, shift, scale, mod_rows_per_batch, mod_batch_stride,
+                              mod_rows_per_batch, M, D, eps, stream);
 }
 
 extern "C" int fk_qkv_post_bf16(const void* qkv, void* q_out, void* k_out, void* vt_out, const void* wq_img,

@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfk_gfx950.so")  # not "libfk.so": python would import it as module `libfk`
+# not "libfk.so": python would import it as module `libfk`.  FK_LIB_PATH: A/B-test another build of the library.
+LIB_PATH = os.environ.get("FK_LIB_PATH") or os.path.join(_HERE, "libfk_gfx950.so")
 
 c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -44,7 +45,9 @@ class ConvArgs(ctypes.Structure):
 # symbol -> (restype, argtypes); must list every entry point of include/fk.h
 SIGNATURES = {
     "fk_gemm_bf16": (c_i32, [ctypes.POINTER(GemmArgs), c_vp]),
+    "fk_gemm_bf16_grouped": (c_i32, [ctypes.POINTER(GemmArgs), c_i32, c_vp]),
     "fk_ln_modulate_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
+    "fk_ln_modulate2_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "fk_qkv_post_bf16": (c_i32, [c_vp] * 10 + [c_i32] * 5 + [c_f32, c_vp]),
     "fk_attention_fwd_bf16": (c_i32, [c_vp] * 4 + [c_i32] * 4 + [c_i64, c_i64, c_f32, c_vp]),
     "fk_silu_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),

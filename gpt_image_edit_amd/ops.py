@@ -40,11 +40,7 @@ def rows_of(t):
     raise ValueError(f"expected a 2-D or 3-D tensor, got {t.dim()}-D")
 
 
-def gemm(a, w, bias=None, out=None, epilogue=FK_EPI_NONE, res=None, gate=None, out_fp32=False, alpha=1.0):
-    """out = epilogue(a @ w.T + bias).  a: [M,K] / [B,R,K] view; w: [N,K]; out likewise (may alias res).
-
-    gate: [B, N] view (row stride = batch stride); used with FK_EPI_GATE_RES and a 3-D ``a``.
-    """
+def _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha):
     _need_cuda(a, w, bias, out, res, gate)
     M, ra = rows_of(a)
     N, K = w.shape
@@ -76,9 +72,32 @@ def gemm(a, w, bias=None, out=None, epilogue=FK_EPI_NONE, res=None, gate=None, o
         args.gate_rows_per_batch = a.shape[1]
     args.M, args.N, args.K = M, N, K
     args.epilogue, args.out_fp32, args.alpha = epilogue, int(out_fp32), float(alpha)
-    lib = libfk.load()
-    libfk.check(lib.fk_gemm_bf16(ctypes.byref(args), _stream()), "fk_gemm_bf16")
+    return args, out
+
+
+def gemm(a, w, bias=None, out=None, epilogue=FK_EPI_NONE, res=None, gate=None, out_fp32=False, alpha=1.0):
+    """out = epilogue(a @ w.T + bias).  a: [M,K] / [B,R,K] view; w: [N,K]; out likewise (may alias res).
+
+    gate: [B, N] view (row stride = batch stride); used with FK_EPI_GATE_RES and a 3-D ``a``.
+    """
+    args, out = _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha)
+    libfk.check(libfk.load().fk_gemm_bf16(ctypes.byref(args), _stream()), "fk_gemm_bf16")
     return out
+
+
+def gemm_grouped(problems, epilogue=FK_EPI_NONE):
+    """Several independent GEMMs sharing (N, K, epilogue) in ONE launch.  ``problems`` is a list of dicts
+    with the keyword arguments of :func:`gemm` (a, w, bias, out, res, gate); returns the outputs."""
+    n = len(problems)
+    arr = (GemmArgs * n)()
+    outs = []
+    for i, pr in enumerate(problems):
+        args, out = _gemm_args(pr["a"], pr["w"], pr.get("bias"), pr.get("out"), epilogue, pr.get("res"),
+                               pr.get("gate"), False, 1.0)
+        arr[i] = args
+        outs.append(out)
+    libfk.check(libfk.load().fk_gemm_bf16_grouped(arr, n, _stream()), "fk_gemm_bf16_grouped")
+    return outs
 
 
 def ln_modulate(x, shift, scale, out=None, eps=1e-6):
@@ -96,6 +115,23 @@ def ln_modulate(x, shift, scale, out=None, eps=1e-6):
     lib = libfk.load()
     libfk.check(lib.fk_ln_modulate_bf16(_ptr(x), rx, _ptr(out), ro, _ptr(shift), _ptr(scale),
                                         shift.stride(0), R, M, D, eps, _stream()), "fk_ln_modulate_bf16")
+    return out
+
+
+def ln_modulate2(x, shift_a, scale_a, shift_b, scale_b, split, out=None, eps=1e-6):
+    """Joint-sequence LN+modulate: rows [0, split) of every batch use (shift_a, scale_a), the rest (b)."""
+    _need_cuda(x, shift_a, scale_a, shift_b, scale_b, out)
+    B, R, D = x.shape
+    if out is None:
+        out = torch.empty((B, R, D), device=x.device, dtype=BF16)
+    M, rx = rows_of(x)
+    _, ro = rows_of(out)
+    st = shift_a.stride(0)
+    if any(t.stride(0) != st or t.stride(1) != 1 for t in (scale_a, shift_b, scale_b)):
+        raise ValueError("modulation views must share one batch stride")
+    libfk.check(libfk.load().fk_ln_modulate2_bf16(_ptr(x), rx, _ptr(out), ro, _ptr(shift_a), _ptr(scale_a),
+                                                  _ptr(shift_b), _ptr(scale_b), split, st, R, M, D, eps, _stream()),
+                "fk_ln_modulate2_bf16")
     return out
 
 

@@ -12,8 +12,8 @@ owns the device buffers.  There is no eager / CPU fallback: without a GPU + libf
 
 Per denoise step the forward issues, on the current HIP stream and with no host sync:
   embedders (skinny GEMMs) -> ONE modulation GEMM for all 57 blocks -> 19 double blocks
-  {2 LN+modulate, 2 fused-QKV GEMMs, qkv_post, attention, 2 gated out-proj GEMMs, 2 LN+modulate,
-   4 MLP GEMMs} -> 38 single blocks {LN+modulate, QKV GEMM, MLP-up GEMM(+GELU), qkv_post, attention,
+  {joint LN+modulate, grouped fused-QKV GEMM (text+image in one grid), qkv_post, attention, grouped gated
+   out-proj GEMM, joint LN+modulate, grouped MLP-up (GELU) and MLP-down (gated residual) GEMMs} -> 38 single blocks {LN+modulate, QKV GEMM, MLP-up GEMM(+GELU), qkv_post, attention,
    gated proj_out GEMM over [attn | mlp]} -> final LN+modulate -> proj_out.
 Text and image streams live in ONE [B, S, D] residual buffer (text rows first), so the double->single
 transition needs no concatenation and attention always sees one contiguous sequence.
@@ -225,27 +225,25 @@ class HipFluxTransformer2DModel(nn.Module):
         for i, blk in enumerate(pk.double):
             p = f"transformer_blocks.{i}."
             mi, mt = blk.mod_img, blk.mod_txt  # chunks: shift, scale, gate, shift_mlp, scale_mlp, gate_mlp
-            ops.ln_modulate(h, chunk(mi, 0), chunk(mi, 1), out=n_img)
-            ops.ln_modulate(cx, chunk(mt, 0), chunk(mt, 1), out=n_txt)
-            ops.gemm(n_img, blk.wqkv_img, blk.bqkv_img, out=ws.qkv[:, S_txt:])
-            ops.gemm(n_txt, blk.wqkv_txt, blk.bqkv_txt, out=ws.qkv[:, :S_txt])
+            # text + image streams share every launch: joint LN+modulate, grouped GEMMs (one grid, two weights)
+            ops.ln_modulate2(s, chunk(mt, 0), chunk(mt, 1), chunk(mi, 0), chunk(mi, 1), S_txt, out=n)
+            ops.gemm_grouped([dict(a=n_img, w=blk.wqkv_img, bias=blk.bqkv_img, out=ws.qkv[:, S_txt:]),
+                              dict(a=n_txt, w=blk.wqkv_txt, bias=blk.bqkv_txt, out=ws.qkv[:, :S_txt])])
             ops.qkv_post(ws.qkv, ws.q, ws.k, ws.vt, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"),
                          P(p + "attn.norm_added_q.weight"), P(p + "attn.norm_added_k.weight"), cos, sin, S_txt)
             ops.attention(ws.q, ws.k, ws.vt, ws.o)
-            ops.gemm(ws.o[:, S_txt:], P(p + "attn.to_out.0.weight"), P(p + "attn.to_out.0.bias"), out=h,
-                     epilogue=ops.FK_EPI_GATE_RES, res=h, gate=chunk(mi, 2))
-            ops.ln_modulate(h, chunk(mi, 3), chunk(mi, 4), out=n_img)
-            ops.gemm(n_img, P(p + "ff.net.0.proj.weight"), P(p + "ff.net.0.proj.bias"), out=ws.ff[:, S_txt:],
-                     epilogue=ops.FK_EPI_GELU_TANH)
-            ops.gemm(ws.ff[:, S_txt:], P(p + "ff.net.2.weight"), P(p + "ff.net.2.bias"), out=h,
-                     epilogue=ops.FK_EPI_GATE_RES, res=h, gate=chunk(mi, 5))
-            ops.gemm(ws.o[:, :S_txt], P(p + "attn.to_add_out.weight"), P(p + "attn.to_add_out.bias"), out=cx,
-                     epilogue=ops.FK_EPI_GATE_RES, res=cx, gate=chunk(mt, 2))
-            ops.ln_modulate(cx, chunk(mt, 3), chunk(mt, 4), out=n_txt)
-            ops.gemm(n_txt, P(p + "ff_context.net.0.proj.weight"), P(p + "ff_context.net.0.proj.bias"),
-                     out=ws.ff[:, :S_txt], epilogue=ops.FK_EPI_GELU_TANH)
-            ops.gemm(ws.ff[:, :S_txt], P(p + "ff_context.net.2.weight"), P(p + "ff_context.net.2.bias"), out=cx,
-                     epilogue=ops.FK_EPI_GATE_RES, res=cx, gate=chunk(mt, 5))
+            ops.gemm_grouped([dict(a=ws.o[:, S_txt:], w=P(p + "attn.to_out.0.weight"), bias=P(p + "attn.to_out.0.bias"),
+                                   out=h, res=h, gate=chunk(mi, 2)),
+                              dict(a=ws.o[:, :S_txt], w=P(p + "attn.to_add_out.weight"), bias=P(p + "attn.to_add_out.bias"),
+                                   out=cx, res=cx, gate=chunk(mt, 2))], epilogue=ops.FK_EPI_GATE_RES)
+            ops.ln_modulate2(s, chunk(mt, 3), chunk(mt, 4), chunk(mi, 3), chunk(mi, 4), S_txt, out=n)
+            ops.gemm_grouped([dict(a=n_img, w=P(p + "ff.net.0.proj.weight"), bias=P(p + "ff.net.0.proj.bias"), out=ws.ff[:, S_txt:]),
+                              dict(a=n_txt, w=P(p + "ff_context.net.0.proj.weight"), bias=P(p + "ff_context.net.0.proj.bias"),
+                                   out=ws.ff[:, :S_txt])], epilogue=ops.FK_EPI_GELU_TANH)
+            ops.gemm_grouped([dict(a=ws.ff[:, S_txt:], w=P(p + "ff.net.2.weight"), bias=P(p + "ff.net.2.bias"),
+                                   out=h, res=h, gate=chunk(mi, 5)),
+                              dict(a=ws.ff[:, :S_txt], w=P(p + "ff_context.net.2.weight"), bias=P(p + "ff_context.net.2.bias"),
+                                   out=cx, res=cx, gate=chunk(mt, 5))], epilogue=ops.FK_EPI_GATE_RES)
 
         # -- single-stream blocks on the joint sequence ------------------------------------------------------
         for i, blk in enumerate(pk.single):

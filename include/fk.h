@@ -84,6 +84,12 @@ typedef struct fk_gemm_args {
 
 int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream);
 
+/* n (<= FK_MAX_GROUP) independent problems that share N, K and the epilogue in ONE launch: the text- and
+ * image-stream linears of a FluxTransformerBlock (different weights, different row counts) fill the GPU
+ * together.  args is an array of n fk_gemm_args; bf16 output only. */
+#define FK_MAX_GROUP 4
+int fk_gemm_bf16_grouped(const fk_gemm_args* args, int32_t n, fk_stream_t stream);
+
 /* out = LN(x; eps, no affine) * (1 + scale[b]) + shift[b], rows of width D (=3072), bf16 in/out.
  * Rounds like the reference graph: LN -> bf16, (1+scale) -> bf16, product -> bf16, sum -> bf16.
  * Replaces AdaLayerNormZero / AdaLayerNormZeroSingle / AdaLayerNormContinuous / norm2 (+modulate)
@@ -93,6 +99,13 @@ int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream);
 int fk_ln_modulate_bf16(const void* x, fk_rows xr, void* out, fk_rows outr, const void* shift,
                         const void* scale, int64_t mod_batch_stride, int64_t mod_rows_per_batch,
                         int64_t M, int32_t D, float eps, fk_stream_t stream);
+
+/* Same, over a joint [text | image] sequence: rows with (m % rows_per_batch) < split use (shift, scale),
+ * the others (shift_b, scale_b) -- both AdaLayerNormZero streams of a FluxTransformerBlock in one launch. */
+int fk_ln_modulate2_bf16(const void* x, fk_rows xr, void* out, fk_rows outr, const void* shift,
+                         const void* scale, const void* shift_b, const void* scale_b, int64_t split,
+                         int64_t mod_batch_stride, int64_t mod_rows_per_batch, int64_t M, int32_t D, float eps,
+                         fk_stream_t stream);
 
 /* QKV post-processing of FluxAttnProcessor2_0: per-head RMSNorm(eps, weight) on q and k
  * (text rows s < s_txt use the *_added weights), interleaved-pair RoPE in fp32, and re-layout:

@@ -115,6 +115,39 @@ def test_gemm_gate_residual_strided_views(ops):
     assert wide[:, :, :D].abs().max().item() == 0 and wide[:, :, 2 * D:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (2560, 3072, 3072), (2048 + 3, 9216, 128), (700, 200, 192)])
+def test_gemm_large_tile_kernel(ops, M, N, K):
+    # M >= 192 routes to the 256x128 LDS-DMA kernel; compare bf16 outputs with the exact fp32 product
+    a, w, bias = randn(M, K, seed=41), randn(N, K, seed=42, scale=0.05), randn(N, seed=43, scale=0.1)
+    got = ops.gemm(a.cuda(), w.cuda(), bias.cuda())
+    ref = (a.float() @ w.float().T + bias.float()).to(BF)
+    assert_bf16_close(f"gemm_large {M}x{N}x{K}", got, ref, max_ulp=1, max_bad_frac=1e-4)
+
+
+def test_gemm_grouped(ops):
+    # text + image stream linears of a double block in one launch: different weights and row counts
+    B, S_txt, S_img, D, K = 2, 100, 412, 384, 256
+    joint_in = randn(B, S_txt + S_img, K, seed=44)
+    w_t, w_i = randn(D, K, seed=45, scale=0.06), randn(D, K, seed=46, scale=0.06)
+    b_t, b_i = randn(D, seed=47, scale=0.1), randn(D, seed=48, scale=0.1)
+    res = randn(B, S_txt + S_img, D, seed=49)
+    mod = randn(B, 2 * D, seed=50, scale=0.5)
+    x, r, md = joint_in.cuda(), res.cuda(), mod.cuda()
+    ops.gemm_grouped([dict(a=x[:, S_txt:], w=w_i.cuda(), bias=b_i.cuda(), out=r[:, S_txt:], res=r[:, S_txt:], gate=md[:, :D]),
+                      dict(a=x[:, :S_txt], w=w_t.cuda(), bias=b_t.cuda(), out=r[:, :S_txt], res=r[:, :S_txt], gate=md[:, D:])],
+                     epilogue=ops.FK_EPI_GATE_RES)
+    y_i = (joint_in[:, S_txt:].float() @ w_i.float().T + b_i.float()).to(BF)
+    y_t = (joint_in[:, :S_txt].float() @ w_t.float().T + b_t.float()).to(BF)
+    ref = res.clone()
+    ref[:, S_txt:] = res[:, S_txt:] + mod[:, None, :D] * y_i
+    ref[:, :S_txt] = res[:, :S_txt] + mod[:, None, D:] * y_t
+    assert_bf16_close("gemm_grouped gate_res", r, ref, max_ulp=1, max_bad_frac=2e-3)
+    outs = ops.gemm_grouped([dict(a=x[:, S_txt:], w=w_i.cuda(), bias=b_i.cuda()), dict(a=x[:, :S_txt], w=w_t.cuda(), bias=b_t.cuda())],
+                            epilogue=ops.FK_EPI_GELU_TANH)
+    assert_bf16_close("gemm_grouped gelu img", outs[0], F.gelu(y_i, approximate="tanh"), max_ulp=1, max_bad_frac=1e-4)
+    assert_bf16_close("gemm_grouped gelu txt", outs[1], F.gelu(y_t, approximate="tanh"), max_ulp=1, max_bad_frac=1e-4)
+
+
 def test_gemm_rejects_bad_arguments(ops):
     a, w = randn(64, 96).cuda(), randn(64, 96).cuda()  # K = 96 is not a multiple of 64
     with pytest.raises(RuntimeError, match="multiple of 64"):
