@@ -26,7 +26,13 @@ FK_DEV bf16_t f2bf(float f) {
 }
 FK_DEV float round_bf(float f) { return bf2f(f2bf(f)); }
 
-FK_DEV uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+// two floats -> packed bf16 pair in ONE v_cvt_pk_bf16_f32 (round-to-nearest-even, like torch)
+typedef __bf16 fk_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float fk_f32x2_t __attribute__((ext_vector_type(2)));
+FK_DEV uint32_t pack_bf2(float lo, float hi) {
+  const fk_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, fk_bf16x2_t));
+}
 
 FK_DEV float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 FK_DEV float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }

@@ -1,6 +1,6 @@
 // HBM-bound fused normalisation kernels of the MMDiT blocks (K2, K3 in SURVEY.md section 2.2).
 //   fk_ln_modulate_bf16 : LayerNorm(no affine) + AdaLN modulate, one read + one write per element.
-//   fk_qkv_post_bf16    : per-head RMSNorm + RoPE + [B,S,3D] -> [B,H,S,128] re-layout (+ V transpose).
+//   fk_qkv_post_bf16    : per-head RMSNorm + RoPE of q, k and [B,S,3D] -> [B,H,S,128] re-layout (V stays in place).
 // Every intermediate is rounded to bf16 where the reference's bf16 torch graph rounds it (see fk.h).
 #include "fk_common.h"
 
@@ -74,15 +74,13 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16_t* x, fk_ro
 // ------------------------------------------------------------------------------------------------------
 // QKV post-processing.  grid = (S_pad/64, H, B), 256 threads; one block = 64 tokens of one head.
 constexpr int HD = 128;
-constexpr int VT_LD = 130;  // token-major staging tile row stride (elements): 65 dwords -> spread banks
 
 __global__ __launch_bounds__(256) void qkv_post_kernel(const bf16_t* qkv, bf16_t* q_out, bf16_t* k_out,
-                                                       bf16_t* vt_out, const bf16_t* wq_img,
+                                                       const bf16_t* wq_img,
                                                        const bf16_t* wk_img, const bf16_t* wq_txt,
                                                        const bf16_t* wk_txt, const float* cosT,
                                                        const float* sinT, int B, int S, int S_txt, int H,
-                                                       int S_pad, float eps) {
-  __shared__ uint32_t vtile[64 * VT_LD / 2];
+                                                       float eps) {
   const int tid = threadIdx.x;
   const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
   const int D3 = 3 * H * HD;
@@ -140,32 +138,6 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const bf16_t* qkv, bf16_t
     }
   }
 
-  // --- v: transpose the [64 tokens][128 d] tile to [128 d][64 tokens] through LDS ---------------------
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = r0 + 16 * i;
-    const int s = s0 + r;
-    u32x4_t w = {0u, 0u, 0u, 0u};  // zero padding for s >= S
-    if (s < S) w = *(const u32x4_t*)(base + (int64_t)s * D3 + 2 * H * HD);
-    uint32_t* row = vtile + r * (VT_LD / 2) + chunk * 4;
-    row[0] = w[0]; row[1] = w[1]; row[2] = w[2]; row[3] = w[3];
-  }
-  __syncthreads();
-  const bf16_t* vt16 = (const bf16_t*)vtile;
-  const int tc = tid & 7;  // 8-token chunk
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int d = (tid >> 3) + 32 * i;
-    uint32_t pk[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t lo = vt16[(8 * tc + 2 * j) * VT_LD + d];
-      const uint32_t hi = vt16[(8 * tc + 2 * j + 1) * VT_LD + d];
-      pk[j] = lo | (hi << 16);
-    }
-    u32x4_t ow = {pk[0], pk[1], pk[2], pk[3]};
-    *(u32x4_t*)(vt_out + (((int64_t)b * H + h) * HD + d) * S_pad + s0 + 8 * tc) = ow;
-  }
 }
 
 }  // namespace
@@ -213,23 +185,21 @@ extern "C" int fk_ln_modulate_bf16(const void* x, fk_rows xr, void* out, fk_rows
                               mod_rows_per_batch, M, D, eps, stream);
 }
 
-extern "C" int fk_qkv_post_bf16(const void* qkv, void* q_out, void* k_out, void* vt_out, const void* wq_img,
+extern "C" int fk_qkv_post_bf16(const void* qkv, void* q_out, void* k_out, const void* wq_img,
                                 const void* wk_img, const void* wq_txt, const void* wk_txt,
                                 const float* cos, const float* sin, int32_t B, int32_t S, int32_t S_txt,
-                                int32_t H, int32_t S_pad, float eps, fk_stream_t stream_) {
-  FK_CHECK_ARG(qkv && q_out && k_out && vt_out && wq_img && wk_img && cos && sin,
-               "fk_qkv_post_bf16: null pointer");
+                                int32_t H, float eps, fk_stream_t stream_) {
+  FK_CHECK_ARG(qkv && q_out && k_out && wq_img && wk_img && cos && sin, "fk_qkv_post_bf16: null pointer");
   FK_CHECK_ARG(S_txt == 0 || (wq_txt && wk_txt), "fk_qkv_post_bf16: text-stream norm weights missing");
   FK_CHECK_ARG(B > 0 && S > 0 && H > 0 && S_txt >= 0 && S_txt <= S, "fk_qkv_post_bf16: bad sizes");
-  FK_CHECK_ARG(S_pad % 64 == 0 && S_pad >= S && S_pad - S < 64, "fk_qkv_post_bf16: S_pad must be S rounded up to 64");
   FK_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)q_out % 16 == 0) && ((uintptr_t)k_out % 16 == 0) &&
-                   ((uintptr_t)vt_out % 16 == 0) && ((uintptr_t)cos % 16 == 0) && ((uintptr_t)sin % 16 == 0),
+                   ((uintptr_t)cos % 16 == 0) && ((uintptr_t)sin % 16 == 0),
                "fk_qkv_post_bf16: pointers must be 16-byte aligned");
   if (!wq_txt) { wq_txt = wq_img; wk_txt = wk_img; }
-  hipLaunchKernelGGL(qkv_post_kernel, dim3(S_pad / 64, H, B), dim3(256), 0, (hipStream_t)stream_,
-                     (const bf16_t*)qkv, (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)vt_out,
+  hipLaunchKernelGGL(qkv_post_kernel, dim3((S + 63) / 64, H, B), dim3(256), 0, (hipStream_t)stream_,
+                     (const bf16_t*)qkv, (bf16_t*)q_out, (bf16_t*)k_out,
                      (const bf16_t*)wq_img, (const bf16_t*)wk_img, (const bf16_t*)wq_txt,
-                     (const bf16_t*)wk_txt, cos, sin, B, S, S_txt, H, S_pad, eps);
+                     (const bf16_t*)wk_txt, cos, sin, B, S, S_txt, H, eps);
   FK_CHECK_LAUNCH("fk_qkv_post_bf16");
   return FK_OK;
 }

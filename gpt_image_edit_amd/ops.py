@@ -135,30 +135,34 @@ def ln_modulate2(x, shift_a, scale_a, shift_b, scale_b, split, out=None, eps=1e-
     return out
 
 
-def qkv_post(qkv, q_out, k_out, vt_out, wq_img, wk_img, wq_txt, wk_txt, cos, sin, s_txt, eps=1e-6):
-    """RMSNorm + RoPE + re-layout: qkv [B,S,3*H*128] -> q/k [B,H,S,128], vt [B,H,128,S_pad]."""
-    _need_cuda(qkv, q_out, k_out, vt_out, cos, sin)
+def qkv_post(qkv, q_out, k_out, wq_img, wk_img, wq_txt, wk_txt, cos, sin, s_txt, eps=1e-6):
+    """RMSNorm + RoPE + re-layout of q, k: qkv [B,S,3*H*128] -> q/k [B,H,S,128] (V stays in qkv)."""
+    _need_cuda(qkv, q_out, k_out, cos, sin)
     B, S, D3 = qkv.shape
     H = D3 // 384
-    S_pad = vt_out.shape[-1]
     if not qkv.is_contiguous():
         raise ValueError("qkv must be contiguous")
     lib = libfk.load()
-    libfk.check(lib.fk_qkv_post_bf16(_ptr(qkv), _ptr(q_out), _ptr(k_out), _ptr(vt_out), _ptr(wq_img),
-                                     _ptr(wk_img), _ptr(wq_txt), _ptr(wk_txt), _ptr(cos), _ptr(sin), B, S,
-                                     s_txt, H, S_pad, eps, _stream()), "fk_qkv_post_bf16")
+    libfk.check(lib.fk_qkv_post_bf16(_ptr(qkv), _ptr(q_out), _ptr(k_out), _ptr(wq_img), _ptr(wk_img), _ptr(wq_txt),
+                                     _ptr(wk_txt), _ptr(cos), _ptr(sin), B, S, s_txt, H, eps, _stream()),
+                "fk_qkv_post_bf16")
 
 
-def attention(q, k, vt, out, scale=None):
-    """out[b, s, h*128:(h+1)*128] = softmax(q k^T * scale) v.  out: [B,S,>=H*128] view."""
-    _need_cuda(q, k, vt, out)
+def attention(q, k, v, out, scale=None):
+    """out[b, s, h*128:(h+1)*128] = softmax(q k^T * scale) v.
+
+    q, k: [B,H,S,128] contiguous; v: [B,S,H*128] view with contiguous last dim (e.g. qkv[:, :, 2D:]);
+    out: [B,S,>=H*128] view."""
+    _need_cuda(q, k, v, out)
     B, H, S, hd = q.shape
     if hd != 128:
         raise ValueError("head_dim must be 128")
+    if v.dim() != 3 or v.shape[-1] != H * 128 or v.stride(2) != 1:
+        raise ValueError("v must be a [B, S, H*128] view with a contiguous last dimension")
     if scale is None:
         scale = hd ** -0.5
     lib = libfk.load()
-    libfk.check(lib.fk_attention_fwd_bf16(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), B, H, S, vt.shape[-1],
+    libfk.check(lib.fk_attention_fwd_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, S, v.stride(1), v.stride(0),
                                           out.stride(1), out.stride(0), scale, _stream()),
                 "fk_attention_fwd_bf16")
     return out

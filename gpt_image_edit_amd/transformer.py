@@ -145,7 +145,7 @@ class HipFluxTransformer2DModel(nn.Module):
         ws = SimpleNamespace(
             S=S, S_pad=S_pad,
             s=e(B, S, D), n=e(B, S, D), qkv=e(B, S, 3 * D), q=e(B, H, S, 128), k=e(B, H, S, 128),
-            vt=e(B, H, 128, S_pad), o=e(B, S, D), ff=e(B, S, 4 * D), cat=e(B, S, 5 * D),
+            o=e(B, S, D), ff=e(B, S, 4 * D), cat=e(B, S, 5 * D),
             mod=e(B, self._packed.mod_total), temb=e(B, D), act=e(B, D), tproj=e(B, 256), e1=e(B, D),
             t_emb=e(B, D), g_emb=e(B, D), p_emb=e(B, D), out=e(B, S_img, self.config.out_channels),
         )
@@ -229,9 +229,9 @@ class HipFluxTransformer2DModel(nn.Module):
             ops.ln_modulate2(s, chunk(mt, 0), chunk(mt, 1), chunk(mi, 0), chunk(mi, 1), S_txt, out=n)
             ops.gemm_grouped([dict(a=n_img, w=blk.wqkv_img, bias=blk.bqkv_img, out=ws.qkv[:, S_txt:]),
                               dict(a=n_txt, w=blk.wqkv_txt, bias=blk.bqkv_txt, out=ws.qkv[:, :S_txt])])
-            ops.qkv_post(ws.qkv, ws.q, ws.k, ws.vt, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"),
+            ops.qkv_post(ws.qkv, ws.q, ws.k, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"),
                          P(p + "attn.norm_added_q.weight"), P(p + "attn.norm_added_k.weight"), cos, sin, S_txt)
-            ops.attention(ws.q, ws.k, ws.vt, ws.o)
+            ops.attention(ws.q, ws.k, ws.qkv[:, :, 2 * D:], ws.o)
             ops.gemm_grouped([dict(a=ws.o[:, S_txt:], w=P(p + "attn.to_out.0.weight"), bias=P(p + "attn.to_out.0.bias"),
                                    out=h, res=h, gate=chunk(mi, 2)),
                               dict(a=ws.o[:, :S_txt], w=P(p + "attn.to_add_out.weight"), bias=P(p + "attn.to_add_out.bias"),
@@ -253,9 +253,9 @@ class HipFluxTransformer2DModel(nn.Module):
             ops.gemm(n, blk.wqkv, blk.bqkv, out=ws.qkv)
             ops.gemm(n, P(p + "proj_mlp.weight"), P(p + "proj_mlp.bias"), out=ws.cat[:, :, D:],
                      epilogue=ops.FK_EPI_GELU_TANH)
-            ops.qkv_post(ws.qkv, ws.q, ws.k, ws.vt, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"),
+            ops.qkv_post(ws.qkv, ws.q, ws.k, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"),
                          None, None, cos, sin, 0)
-            ops.attention(ws.q, ws.k, ws.vt, ws.cat[:, :, :D])
+            ops.attention(ws.q, ws.k, ws.qkv[:, :, 2 * D:], ws.cat[:, :, :D])
             ops.gemm(ws.cat, P(p + "proj_out.weight"), P(p + "proj_out.bias"), out=s,
                      epilogue=ops.FK_EPI_GATE_RES, res=s, gate=chunk(m0, 2))
 

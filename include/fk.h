@@ -109,21 +109,21 @@ int fk_ln_modulate2_bf16(const void* x, fk_rows xr, void* out, fk_rows outr, con
 
 /* QKV post-processing of FluxAttnProcessor2_0: per-head RMSNorm(eps, weight) on q and k
  * (text rows s < s_txt use the *_added weights), interleaved-pair RoPE in fp32, and re-layout:
- *   qkv [B, S, 3*H*128] (q | k | v, head-major inside each)  ->
- *   q_out, k_out [B, H, S, 128] bf16;  vt_out [B, H, 128, S_pad] bf16 (V transposed, zero padded)
- * cos/sin: fp32 [S, 128].  S_pad % 64 == 0.  head_dim is fixed at 128. */
-int fk_qkv_post_bf16(const void* qkv, void* q_out, void* k_out, void* vt_out, const void* wq_img,
-                     const void* wk_img, const void* wq_txt, const void* wk_txt, const float* cos,
-                     const float* sin, int32_t B, int32_t S, int32_t S_txt, int32_t H, int32_t S_pad,
-                     float eps, fk_stream_t stream);
+ *   qkv [B, S, 3*H*128] (q | k | v, head-major inside each)  ->  q_out, k_out [B, H, S, 128] bf16.
+ * V is NOT copied: fk_attention_fwd_bf16 reads it in place from the qkv buffer.
+ * cos/sin: fp32 [S, 128].  head_dim is fixed at 128. */
+int fk_qkv_post_bf16(const void* qkv, void* q_out, void* k_out, const void* wq_img, const void* wk_img,
+                     const void* wq_txt, const void* wk_txt, const float* cos, const float* sin, int32_t B,
+                     int32_t S, int32_t S_txt, int32_t H, float eps, fk_stream_t stream);
 
 /* O = softmax(Q K^T * scale) V, non-causal, no mask (F.scaled_dot_product_attention as called by
- * FluxAttnProcessor2_0).  q, k: [B, H, S, 128]; vt: [B, H, 128, S_pad]; o: rows (b, s) at
- * o + b*o_batch_stride + s*o_ld, head h at column h*128 -> the [B, S, H*128] layout the next
- * Linear consumes (o_ld lets the single block write straight into its [attn | mlp] buffer). */
-int fk_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* o, int32_t B, int32_t H,
-                          int32_t S, int32_t S_pad, int64_t o_ld, int64_t o_batch_stride, float scale,
-                          fk_stream_t stream);
+ * FluxAttnProcessor2_0).  q, k: [B, H, S, 128] contiguous; v: token s of batch b, head h at
+ * v + b*v_batch_stride + s*v_ld + h*128 (e.g. the V third of the qkv buffer: v_ld = 3*H*128);
+ * o: rows (b, s) at o + b*o_batch_stride + s*o_ld, head h at column h*128 -> the [B, S, H*128] layout the
+ * next Linear consumes (o_ld lets the single block write straight into its [attn | mlp] buffer). */
+int fk_attention_fwd_bf16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H,
+                          int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld,
+                          int64_t o_batch_stride, float scale, fk_stream_t stream);
 
 /* Elementwise / tiny kernels ------------------------------------------------------------------ */
 /* y = bf16(silu(x)) over n elements (n % 8 == 0). */

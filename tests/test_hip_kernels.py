@@ -179,16 +179,14 @@ def test_qkv_post(ops):
     from oracle.helpers import prepare_latent_image_ids
     B, H, S_txt, hh, ww = 2, 3, 21, 6, 9
     S = S_txt + hh * ww  # 75: not a multiple of 64
-    S_pad = (S + 63) // 64 * 64
     qkv = randn(B, S, 3 * H * 128, seed=14)
     wq_i, wk_i, wq_t, wk_t = [(1 + randn(128, seed=15 + i, scale=0.1).float()).to(BF) for i in range(4)]
     ids = torch.cat([torch.zeros(S_txt, 3), prepare_latent_image_ids(hh, ww)])
     cos, sin = mmdit.rope_tables(ids)
     q = torch.empty(B, H, S, 128, dtype=BF, device="cuda")
     k = torch.empty_like(q)
-    vt = torch.full((B, H, 128, S_pad), 7.0, dtype=BF, device="cuda")
-    ops.qkv_post(qkv.cuda(), q, k, vt, wq_i.cuda(), wk_i.cuda(), wq_t.cuda(), wk_t.cuda(), cos.cuda(),
-                 sin.cuda(), S_txt)
+    qkv_dev = qkv.cuda()
+    ops.qkv_post(qkv_dev, q, k, wq_i.cuda(), wk_i.cuda(), wq_t.cuda(), wk_t.cuda(), cos.cuda(), sin.cuda(), S_txt)
     D = H * 128
     def ref_qk(x, w_t, w_i):
         x = mmdit.heads(x, H)
@@ -196,22 +194,20 @@ def test_qkv_post(ops):
         return mmdit.apply_rope(x, cos, sin)
     assert_bf16_close("qkv_post q", q, ref_qk(qkv[..., :D], wq_t, wq_i), max_ulp=1, max_bad_frac=2e-3)
     assert_bf16_close("qkv_post k", k, ref_qk(qkv[..., D:2 * D], wk_t, wk_i), max_ulp=1, max_bad_frac=2e-3)
-    v_ref = mmdit.heads(qkv[..., 2 * D:], H).transpose(2, 3)  # [B,H,128,S]
-    assert torch.equal(vt[..., :S].cpu(), v_ref)
-    assert vt[..., S:].abs().max().item() == 0  # zero padding
+    assert torch.equal(qkv_dev.cpu(), qkv)  # V (and the inputs) are left in place
 
 
-@pytest.mark.parametrize("B,H,S", [(1, 2, 64), (2, 3, 75), (1, 2, 300), (1, 24, 2560), (1, 1, 1000)])
+@pytest.mark.parametrize("B,H,S", [(1, 2, 64), (2, 3, 75), (1, 2, 300), (1, 24, 2560), (1, 1, 1000), (2, 2, 257)])
 def test_attention(ops, B, H, S):
-    q, k, v = randn(B, H, S, 128, seed=20), randn(B, H, S, 128, seed=21), randn(B, H, S, 128, seed=22)
+    q, k = randn(B, H, S, 128, seed=20), randn(B, H, S, 128, seed=21)
+    qkv = randn(B, S, 3 * H * 128, seed=22)          # V is read in place from the fused projection buffer
+    v = qkv[:, :, 2 * H * 128:].reshape(B, S, H, 128).transpose(1, 2)
     if S == 300:  # spike a few keys so the running max jumps mid-sequence (online-softmax rescale)
         k[:, :, 200] = q[:, :, 17] * 2.0
         k[:, :, 290] = q[:, :, 150] * 3.0
-    S_pad = (S + 63) // 64 * 64
-    vt = torch.zeros(B, H, 128, S_pad, dtype=BF)
-    vt[..., :S] = v.transpose(2, 3)
     out = torch.zeros(B, S, H * 128 + 64, dtype=BF, device="cuda")  # wider row stride than H*128
-    ops.attention(q.cuda(), k.cuda(), vt.cuda(), out)
+    qkv_dev = qkv.cuda()
+    ops.attention(q.cuda(), k.cuda(), qkv_dev[:, :, 2 * H * 128:], out)
     torch.cuda.synchronize()
     ref = F.scaled_dot_product_attention(q.float(), k.float(), v.float())  # fp32 oracle on bf16 inputs
     ref = ref.transpose(1, 2).reshape(B, S, H * 128)
@@ -219,6 +215,25 @@ def test_attention(ops, B, H, S):
     assert out[..., H * 128:].abs().max().item() == 0
     # P is rounded to bf16 before the PV product and O to bf16 at the end: ~2^-8 relative per term
     assert d.max().item() < 3e-2 and d.mean().item() < 2e-3
+
+
+def test_attention_value_layout_is_transpose_detecting(ops):
+    # one-hot attention (huge matching logit) must copy exactly the selected V row: catches any mix-up of
+    # the key <-> MFMA k-slot binding or of the LDS transpose-read addressing
+    B, H, S = 1, 1, 192
+    q = torch.zeros(B, H, S, 128)
+    k = torch.zeros(B, H, S, 128)
+    perm = torch.randperm(S, generator=torch.Generator().manual_seed(3))
+    for i in range(S):
+        q[0, 0, i, i % 128] = 12.0 + (i // 128)
+        k[0, 0, perm[i], i % 128] = 12.0 + (i // 128)
+    # rows i and i+128 share a one-hot direction; scale so the larger dot product wins decisively
+    v = (torch.arange(S * 128, dtype=torch.float32).reshape(1, S, 128) % 509) / 32.0
+    out = torch.zeros(B, S, 128, dtype=BF, device="cuda")
+    ops.attention(q.to(BF).cuda(), k.to(BF).cuda(), v.to(BF).cuda(), out, scale=8.0)
+    ref = F.scaled_dot_product_attention(q.to(BF).float(), k.to(BF).float(), v.to(BF).float()[:, None], scale=8.0)[:, 0]
+    d = report("attention one-hot", out, ref)
+    assert d.max().item() < 2e-2
 
 
 # ---------------------------------------------------------------------------------------------------
