@@ -236,6 +236,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
   }
 }
 
+// Measured dead ends (kept out of the tree, see git history): (1) issuing QK^T of tile t+1 before the softmax
+// of tile t inside one wave (register pressure -> spills, compiler does not interleave: 760 TF vs 844);
+// (2) rotating waves 4..7 by one phase so that softmax of one wave meets MFMA of its SIMD partner
+// (4-stage ring): 725 TF vs 844.  PMC: matrix pipe 48 % busy, VALU 52 %, no LDS bank conflicts.
+
 template <int NW, int STAGES>
 int launch(const AttnParams& p, hipStream_t stream) {
   constexpr int SMEM = STAGES * STAGE_BYTES;
