@@ -200,6 +200,8 @@ class FluxKontextPipeline:
         if self.transformer.config.guidance_embeds:
             guidance = torch.full([batch_size], guidance_scale, device=device, dtype=torch.float32)
         self.scheduler.set_begin_index(0)
+        if hasattr(self.transformer, "prepare_conditioning"):  # all steps' modulation vectors in one pass
+            self.transformer.prepare_conditioning(t_model, guidance, pooled_prompt_embeds)
 
         # 6. denoising loop: no allocation, no host sync
         for i in range(len(timesteps)):

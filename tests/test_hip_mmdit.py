@@ -83,3 +83,26 @@ def test_state_dict_roundtrip_and_seam():
     assert m.config.in_channels == 64 and m.config.guidance_embeds and m.dtype == BF
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(hidden_states=torch.zeros(1, 4, 64), encoder_hidden_states=torch.zeros(1, 4, 4096))
+
+
+def test_prepare_conditioning_is_bit_identical():
+    """All-steps modulation precompute (one weight-streaming pass) must reproduce the per-step path exactly."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd import flux_spec
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=1, num_single_layers=1)
+    m = HipFluxTransformer2DModel(cfg, device="cuda", init="synthetic", seed=5)
+    hs, enc, pooled, _, gd, img_ids, txt_ids = _inputs(2, 40, 6, 8, cfg, seed=3)
+    hs, enc, pooled, gd, img_ids, txt_ids = (x.cuda() for x in (hs, enc, pooled, gd, img_ids, txt_ids))
+    steps = (torch.tensor([[1.0, 1.0], [0.8516, 0.8516], [0.4375, 0.4375]]).to(BF)).cuda()
+    kw = dict(hidden_states=hs, encoder_hidden_states=enc, pooled_projections=pooled, guidance=gd, txt_ids=txt_ids,
+              img_ids=img_ids, return_dict=False)
+    plain = [m(timestep=steps[i].clone(), **kw)[0].clone() for i in range(3)]
+    m.prepare_conditioning(steps, gd, pooled)
+    cached = [m(timestep=steps[i], **kw)[0].clone() for i in range(3)]
+    for a, b in zip(plain, cached):
+        assert torch.equal(a, b)
+    # a timestep tensor that is not part of the prepared schedule falls back to on-the-fly conditioning
+    other = m(timestep=torch.tensor([0.25, 0.25]).to(BF).cuda(), **kw)[0]
+    assert not torch.equal(other, cached[0])
