@@ -243,6 +243,48 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GroupArgs ga) {
     const int m = m0 + ml, n = n0 + cc * 8;
     if (m >= p.M || n >= p.N) continue;
     u32x4_t y = *(const u32x4_t*)(ct + ml * C::CT_LD + cc * 8);
+    if constexpr (EPI == FK_EPI_QKV) {
+      // 16 consecutive lanes hold one 128-wide head row of the tile (tiles never straddle q | k | v)
+      const int D = p.qkv_heads * 128;
+      const int which = n / D;  // 0 = q, 1 = k, 2 = v
+      if (which < 2) {
+        float xv[8];
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xv[2 * e] = bf_lo(y[e]);
+          xv[2 * e + 1] = bf_hi(y[e]);
+          ss += xv[2 * e] * xv[2 * e] + xv[2 * e + 1] * xv[2 * e + 1];
+        }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+        const float rs = rsqrtf(ss * (1.0f / 128) + 1e-6f);
+        const int rpb = p.c.rows_per_batch > 0 ? (int)p.c.rows_per_batch : p.M;
+        const int bidx = m / rpb;
+        const int srow = p.qkv_s_offset + (m - bidx * rpb);
+        const int hn = n - which * D;            // column inside q or k
+        const int head = hn >> 7, dch = hn & 127;  // dch = 8 * chunk-in-head
+        const u32x4_t ww = *(const u32x4_t*)((const bf16_t*)(which == 0 ? p.wq : p.wk) + dch);
+        const float* cp = p.rope_cos + (int64_t)srow * 128 + dch;
+        const float* sp = p.rope_sin + (int64_t)srow * 128 + dch;
+        const f32x4_t c0 = *(const f32x4_t*)cp, c1 = *(const f32x4_t*)(cp + 4);
+        const f32x4_t s0 = *(const f32x4_t*)sp, s1 = *(const f32x4_t*)(sp + 4);
+        const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        const float sn[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        u32x4_t ow;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float re = round_bf(round_bf(xv[2 * e] * rs) * bf_lo(ww[e]));
+          const float im = round_bf(round_bf(xv[2 * e + 1] * rs) * bf_hi(ww[e]));
+          const float o0 = __fadd_rn(__fmul_rn(re, cs[2 * e]), __fmul_rn(-im, sn[2 * e]));
+          const float o1 = __fadd_rn(__fmul_rn(im, cs[2 * e + 1]), __fmul_rn(re, sn[2 * e + 1]));
+          ow[e] = pack_bf2(o0, o1);
+        }
+        bf16_t* dst = (bf16_t*)(which == 0 ? p.q_out : p.k_out);
+        *(u32x4_t*)(dst + (((int64_t)bidx * p.qkv_heads + head) * p.qkv_s_total + srow) * 128 + dch) = ow;
+        continue;
+      }
+    }
     if constexpr (EPI == FK_EPI_GATE_RES || EPI == FK_EPI_RES) {
       const u32x4_t rv = *(const u32x4_t*)((const bf16_t*)p.res + fk_row_offset(p.r, m) + n);
       u32x4_t gv;
@@ -320,6 +362,7 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t s
     case FK_EPI_GATE_RES: return launch_bn<FK_EPI_GATE_RES>(ga, probs, n, bn, stream);
     case FK_EPI_RES: return launch_bn<FK_EPI_RES>(ga, probs, n, bn, stream);
     case FK_EPI_SCALE: return launch_bn<FK_EPI_SCALE>(ga, probs, n, bn, stream);
+    case FK_EPI_QKV: return launch_bn<FK_EPI_QKV>(ga, probs, n, bn, stream);
     default: fk_set_error("fk_gemm_bf16: unknown epilogue %d", probs[0].epilogue); return FK_EUNSUPPORTED;
   }
 }

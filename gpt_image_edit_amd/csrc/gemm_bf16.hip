@@ -305,7 +305,16 @@ static int validate_gemm(const fk_gemm_args& p) {
                      p.gate_rows_per_batch > 0,
                  "fk_gemm_bf16: gate pointer/stride invalid");
   }
-  FK_CHECK_ARG(p.epilogue >= FK_EPI_NONE && p.epilogue <= FK_EPI_SCALE, "fk_gemm_bf16: unknown epilogue %d", p.epilogue);
+  FK_CHECK_ARG(p.epilogue >= FK_EPI_NONE && p.epilogue <= FK_EPI_QKV, "fk_gemm_bf16: unknown epilogue %d", p.epilogue);
+  if (p.epilogue == FK_EPI_QKV) {
+    FK_CHECK_ARG(!p.out_fp32 && p.q_out && p.k_out && p.wq && p.wk && p.rope_cos && p.rope_sin,
+                 "fk_gemm_bf16: FK_EPI_QKV needs q_out/k_out/wq/wk/rope tables");
+    FK_CHECK_ARG(p.qkv_heads > 0 && p.N == 3 * p.qkv_heads * 128 && p.qkv_s_total > 0 && p.qkv_s_offset >= 0,
+                 "fk_gemm_bf16: FK_EPI_QKV needs N = 3*H*128");
+    FK_CHECK_ARG(((uintptr_t)p.q_out % 16 == 0) && ((uintptr_t)p.k_out % 16 == 0) && ((uintptr_t)p.wq % 16 == 0) &&
+                     ((uintptr_t)p.wk % 16 == 0) && ((uintptr_t)p.rope_cos % 16 == 0) && ((uintptr_t)p.rope_sin % 16 == 0),
+                 "fk_gemm_bf16: FK_EPI_QKV pointers must be 16-byte aligned");
+  }
   return FK_OK;
 }
 
@@ -343,7 +352,7 @@ extern "C" int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream_) {
     }
   }
   const int ov = gemm_impl_override();
-  if (ov == 2 || (ov == 0 && p.M >= 192)) return fk_gemm2_launch(&p, 1, gemm_bn_override(), stream);
+  if (ov == 2 || p.epilogue == FK_EPI_QKV || (ov == 0 && p.M >= 192)) return fk_gemm2_launch(&p, 1, gemm_bn_override(), stream);
   switch (p.epilogue) {
     case FK_EPI_NONE: return launch<FK_EPI_NONE, false>(p, stream);
     case FK_EPI_GELU_TANH: return launch<FK_EPI_GELU_TANH, false>(p, stream);
@@ -365,7 +374,7 @@ extern "C" int fk_gemm_bf16_grouped(const fk_gemm_args* args, int32_t n, fk_stre
                  "fk_gemm_bf16_grouped: all problems must share N, K and the epilogue");
   }
   hipStream_t stream = (hipStream_t)stream_;
-  if (gemm_impl_override() == 1) {  // A/B: one 128x128 launch per problem
+  if (gemm_impl_override() == 1 && args[0].epilogue != FK_EPI_QKV) {  // A/B: one 128x128 launch per problem
     for (int i = 0; i < n; ++i) {
       fk_gemm_args one = args[i];
       int rc;

@@ -61,21 +61,34 @@ __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(const bf16_t* x,
   }
 }
 
-// grid (B), 64 threads: merge the per-block partials in a fixed order (fp64 to avoid cancellation).
+// grid (groups, B), 64 threads: merge the per-block partials of one (batch, group) in a fixed order
+// (lane i sums blocks i, i+64, ...; then a fixed-shape LDS tree) in fp64 to avoid cancellation.
 __global__ void gn_finalize_kernel(const float* ws, float* stats, int nblk, int groups, double count, float eps) {
-  const int b = blockIdx.x, g = threadIdx.x;
-  if (g >= groups) return;
+  __shared__ double sh[2][64];
+  const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   double s = 0.0, q = 0.0;
-  for (int i = 0; i < nblk; ++i) {
+  for (int i = lane; i < nblk; i += 64) {
     const float* o = ws + (((int64_t)b * nblk + i) * groups + g) * 2;
     s += (double)o[0];
     q += (double)o[1];
   }
-  const double mean = s / count;
-  double var = q / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  stats[((int64_t)b * groups + g) * 2 + 0] = (float)mean;
-  stats[((int64_t)b * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  sh[0][lane] = s;
+  sh[1][lane] = q;
+  __syncthreads();
+  for (int off = 32; off >= 1; off >>= 1) {
+    if (lane < off) {
+      sh[0][lane] += sh[0][lane + off];
+      sh[1][lane] += sh[1][lane + off];
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    const double mean = sh[0][0] / count;
+    double var = sh[1][0] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[((int64_t)b * groups + g) * 2 + 0] = (float)mean;
+    stats[((int64_t)b * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x, bf16_t* y, const float* stats,
@@ -167,7 +180,7 @@ extern "C" int fk_groupnorm_stats_nhwc_bf16(const void* x, float* stats, float* 
   hipStream_t stream = (hipStream_t)stream_;
   const int nblk = gn_blocks(HW, C);
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, B), dim3(GN_THREADS), 0, stream, (const bf16_t*)x, ws, HW, C, groups);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, stream, (const float*)ws, stats, nblk, groups,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, stream, (const float*)ws, stats, nblk, groups,
                      (double)HW * (C / groups), eps);
   FK_CHECK_LAUNCH("fk_groupnorm_stats_nhwc_bf16");
   return FK_OK;

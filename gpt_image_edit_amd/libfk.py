@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("FK_LIB_PATH") or os.path.join(_HERE, "libfk_gfx950.so
 
 c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
-FK_EPI_NONE, FK_EPI_GELU_TANH, FK_EPI_SILU, FK_EPI_GATE_RES, FK_EPI_RES, FK_EPI_SCALE = range(6)
+FK_EPI_NONE, FK_EPI_GELU_TANH, FK_EPI_SILU, FK_EPI_GATE_RES, FK_EPI_RES, FK_EPI_SCALE, FK_EPI_QKV = range(7)
 
 
 class Rows(ctypes.Structure):
@@ -30,6 +30,8 @@ class GemmArgs(ctypes.Structure):
         ("gate", c_vp), ("gate_batch_stride", c_i64), ("gate_rows_per_batch", c_i64),
         ("M", c_i32), ("N", c_i32), ("K", c_i32),
         ("epilogue", c_i32), ("out_fp32", c_i32), ("alpha", c_f32),
+        ("q_out", c_vp), ("k_out", c_vp), ("wq", c_vp), ("wk", c_vp), ("rope_cos", c_vp), ("rope_sin", c_vp),
+        ("qkv_s_offset", c_i32), ("qkv_s_total", c_i32), ("qkv_heads", c_i32), ("reserved_", c_i32),
     ]
 
 

@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import libfk
-from .libfk import (FK_EPI_GATE_RES, FK_EPI_GELU_TANH, FK_EPI_NONE, FK_EPI_RES, FK_EPI_SCALE,  # noqa: F401
+from .libfk import (FK_EPI_GATE_RES, FK_EPI_GELU_TANH, FK_EPI_NONE, FK_EPI_QKV, FK_EPI_RES, FK_EPI_SCALE,  # noqa: F401
                     FK_EPI_SILU, GemmArgs, Rows)
 
 BF16 = torch.bfloat16
@@ -40,7 +40,7 @@ def rows_of(t):
     raise ValueError(f"expected a 2-D or 3-D tensor, got {t.dim()}-D")
 
 
-def _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha):
+def _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv=None):
     _need_cuda(a, w, bias, out, res, gate)
     M, ra = rows_of(a)
     N, K = w.shape
@@ -72,15 +72,23 @@ def _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha):
         args.gate_rows_per_batch = a.shape[1]
     args.M, args.N, args.K = M, N, K
     args.epilogue, args.out_fp32, args.alpha = epilogue, int(out_fp32), float(alpha)
+    if epilogue == FK_EPI_QKV:
+        _need_cuda(qkv["q_out"], qkv["k_out"], qkv["wq"], qkv["wk"], qkv["cos"], qkv["sin"])
+        args.q_out, args.k_out = qkv["q_out"].data_ptr(), qkv["k_out"].data_ptr()
+        args.wq, args.wk = qkv["wq"].data_ptr(), qkv["wk"].data_ptr()
+        args.rope_cos, args.rope_sin = qkv["cos"].data_ptr(), qkv["sin"].data_ptr()
+        args.qkv_s_offset, args.qkv_s_total, args.qkv_heads = qkv["s_offset"], qkv["q_out"].shape[2], qkv["q_out"].shape[1]
     return args, out
 
 
-def gemm(a, w, bias=None, out=None, epilogue=FK_EPI_NONE, res=None, gate=None, out_fp32=False, alpha=1.0):
+def gemm(a, w, bias=None, out=None, epilogue=FK_EPI_NONE, res=None, gate=None, out_fp32=False, alpha=1.0, qkv=None):
     """out = epilogue(a @ w.T + bias).  a: [M,K] / [B,R,K] view; w: [N,K]; out likewise (may alias res).
 
     gate: [B, N] view (row stride = batch stride); used with FK_EPI_GATE_RES and a 3-D ``a``.
+    qkv (FK_EPI_QKV): dict(q_out, k_out [B,H,S_total,128], wq, wk [128], cos, sin fp32 [S_total,128], s_offset)
+    -- the fused QKV projection: q / k thirds get RMSNorm + RoPE + head-major layout, the v third lands in out.
     """
-    args, out = _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha)
+    args, out = _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv)
     libfk.check(libfk.load().fk_gemm_bf16(ctypes.byref(args), _stream()), "fk_gemm_bf16")
     return out
 
@@ -93,7 +101,7 @@ def gemm_grouped(problems, epilogue=FK_EPI_NONE):
     outs = []
     for i, pr in enumerate(problems):
         args, out = _gemm_args(pr["a"], pr["w"], pr.get("bias"), pr.get("out"), epilogue, pr.get("res"),
-                               pr.get("gate"), False, 1.0)
+                               pr.get("gate"), False, 1.0, pr.get("qkv"))
         arr[i] = args
         outs.append(out)
     libfk.check(libfk.load().fk_gemm_bf16_grouped(arr, n, _stream()), "fk_gemm_bf16_grouped")

@@ -12,13 +12,14 @@ owns the device buffers.  There is no eager / CPU fallback: without a GPU + libf
 
 Per denoise step the forward issues, on the current HIP stream and with no host sync:
   embedders (skinny GEMMs) -> ONE modulation GEMM for all 57 blocks -> 19 double blocks
-  {joint LN+modulate, grouped fused-QKV GEMM (text+image in one grid), qkv_post, attention, grouped gated
+  {joint LN+modulate, grouped fused-QKV GEMM (text+image in one grid; RMSNorm+RoPE+layout in its epilogue), attention, grouped gated
    out-proj GEMM, joint LN+modulate, grouped MLP-up (GELU) and MLP-down (gated residual) GEMMs} -> 38 single blocks {LN+modulate, QKV GEMM, MLP-up GEMM(+GELU), qkv_post, attention,
    gated proj_out GEMM over [attn | mlp]} -> final LN+modulate -> proj_out.
 Text and image streams live in ONE [B, S, D] residual buffer (text rows first), so the double->single
 transition needs no concatenation and attention always sees one contiguous sequence.
 """
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -27,6 +28,8 @@ from torch import nn
 from . import flux_spec, ops
 
 BF16 = torch.bfloat16
+# FK_FUSE_QKV=0 keeps RMSNorm+RoPE as the separate fk_qkv_post_bf16 pass (A/B measurement, identical results)
+FUSE_QKV = os.environ.get("FK_FUSE_QKV", "1") != "0"
 
 
 def rope_tables(ids, axes_dim=(16, 56, 56), theta=10000.0):
@@ -272,10 +275,19 @@ class HipFluxTransformer2DModel(nn.Module):
             mi, mt = blk.mod_img, blk.mod_txt  # chunks: shift, scale, gate, shift_mlp, scale_mlp, gate_mlp
             # text + image streams share every launch: joint LN+modulate, grouped GEMMs (one grid, two weights)
             ops.ln_modulate2(s, chunk(mt, 0), chunk(mt, 1), chunk(mi, 0), chunk(mi, 1), S_txt, out=n)
-            ops.gemm_grouped([dict(a=n_img, w=blk.wqkv_img, bias=blk.bqkv_img, out=ws.qkv[:, S_txt:]),
-                              dict(a=n_txt, w=blk.wqkv_txt, bias=blk.bqkv_txt, out=ws.qkv[:, :S_txt])])
-            ops.qkv_post(ws.qkv, ws.q, ws.k, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"),
-                         P(p + "attn.norm_added_q.weight"), P(p + "attn.norm_added_k.weight"), cos, sin, S_txt)
+            if FUSE_QKV:  # RMSNorm + RoPE + head-major q / k come out of the projection GEMM's epilogue
+                ops.gemm_grouped([dict(a=n_img, w=blk.wqkv_img, bias=blk.bqkv_img, out=ws.qkv[:, S_txt:],
+                                       qkv=dict(q_out=ws.q, k_out=ws.k, wq=P(p + "attn.norm_q.weight"),
+                                                wk=P(p + "attn.norm_k.weight"), cos=cos, sin=sin, s_offset=S_txt)),
+                                  dict(a=n_txt, w=blk.wqkv_txt, bias=blk.bqkv_txt, out=ws.qkv[:, :S_txt],
+                                       qkv=dict(q_out=ws.q, k_out=ws.k, wq=P(p + "attn.norm_added_q.weight"),
+                                                wk=P(p + "attn.norm_added_k.weight"), cos=cos, sin=sin, s_offset=0))],
+                                 epilogue=ops.FK_EPI_QKV)
+            else:
+                ops.gemm_grouped([dict(a=n_img, w=blk.wqkv_img, bias=blk.bqkv_img, out=ws.qkv[:, S_txt:]),
+                                  dict(a=n_txt, w=blk.wqkv_txt, bias=blk.bqkv_txt, out=ws.qkv[:, :S_txt])])
+                ops.qkv_post(ws.qkv, ws.q, ws.k, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"),
+                             P(p + "attn.norm_added_q.weight"), P(p + "attn.norm_added_k.weight"), cos, sin, S_txt)
             ops.attention(ws.q, ws.k, ws.qkv[:, :, 2 * D:], ws.o)
             ops.gemm_grouped([dict(a=ws.o[:, S_txt:], w=P(p + "attn.to_out.0.weight"), bias=P(p + "attn.to_out.0.bias"),
                                    out=h, res=h, gate=chunk(mi, 2)),
@@ -295,11 +307,16 @@ class HipFluxTransformer2DModel(nn.Module):
             p = f"single_transformer_blocks.{i}."
             m0 = blk.mod  # chunks: shift, scale, gate
             ops.ln_modulate(s, chunk(m0, 0), chunk(m0, 1), out=n)
-            ops.gemm(n, blk.wqkv, blk.bqkv, out=ws.qkv)
+            if FUSE_QKV:
+                ops.gemm(n, blk.wqkv, blk.bqkv, out=ws.qkv, epilogue=ops.FK_EPI_QKV,
+                         qkv=dict(q_out=ws.q, k_out=ws.k, wq=P(p + "attn.norm_q.weight"),
+                                  wk=P(p + "attn.norm_k.weight"), cos=cos, sin=sin, s_offset=0))
+            else:
+                ops.gemm(n, blk.wqkv, blk.bqkv, out=ws.qkv)
+                ops.qkv_post(ws.qkv, ws.q, ws.k, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"), None, None,
+                             cos, sin, 0)
             ops.gemm(n, P(p + "proj_mlp.weight"), P(p + "proj_mlp.bias"), out=ws.cat[:, :, D:],
                      epilogue=ops.FK_EPI_GELU_TANH)
-            ops.qkv_post(ws.qkv, ws.q, ws.k, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"),
-                         None, None, cos, sin, 0)
             ops.attention(ws.q, ws.k, ws.qkv[:, :, 2 * D:], ws.cat[:, :, :D])
             ops.gemm(ws.cat, P(p + "proj_out.weight"), P(p + "proj_out.bias"), out=s,
                      epilogue=ops.FK_EPI_GATE_RES, res=s, gate=chunk(m0, 2))

@@ -43,6 +43,10 @@ enum {
  *   FK_EPI_GATE_RES  : y = bf16(res + bf16(gate[b] * y))   (gate_msa.unsqueeze(1) * attn_out; h + ...)
  *   FK_EPI_RES       : y = bf16(res + y)                   (ResnetBlock2D / VAE attention residual)
  *   FK_EPI_SCALE     : y = bf16(alpha * acc)  (no bias)    (attention scores for the VAE mid block)
+ *   FK_EPI_QKV       : fused QKV projection of FluxAttnProcessor2_0 (N = 3*H*128 = q | k | v): the q and k
+ *                      thirds get per-head RMSNorm(eps 1e-6, weight) + interleaved RoPE and are written
+ *                      head-major to q_out / k_out [B, H, S_total, 128]; the v third is stored like
+ *                      FK_EPI_NONE into C (= the qkv buffer the attention kernel reads V from).
  */
 enum {
   FK_EPI_NONE = 0,
@@ -51,6 +55,7 @@ enum {
   FK_EPI_GATE_RES = 3,
   FK_EPI_RES = 4,
   FK_EPI_SCALE = 5,
+  FK_EPI_QKV = 6,
 };
 
 /* Row addressing used for A, C and the residual: logical row m lives at
@@ -80,6 +85,13 @@ typedef struct fk_gemm_args {
   int32_t epilogue;
   int32_t out_fp32;
   float alpha;                   /* FK_EPI_SCALE */
+  /* FK_EPI_QKV only (row m of this problem is token s = qkv_s_offset + m % c.rows_per_batch of batch
+   * m / c.rows_per_batch; c.rows_per_batch <= 0: one batch): */
+  void* q_out; void* k_out;      /* bf16 [B, H, S_total, 128] */
+  const void* wq; const void* wk;/* bf16 [128] RMSNorm weights of this stream (norm_q/norm_k or norm_added_*) */
+  const float* rope_cos; const float* rope_sin; /* fp32 [S_total, 128] */
+  int32_t qkv_s_offset, qkv_s_total, qkv_heads;
+  int32_t reserved_;
 } fk_gemm_args;
 
 int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream);
