@@ -174,11 +174,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one process per GPU; FK_BENCH_BACKEND=gloo (+ ranks sharing a GPU) exists only to smoke-test the N > 1
+    # code path on a 1-GPU box
+    backend = os.environ.get("FK_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from gpt_image_edit_amd import dp
     pipe = build_pipeline(device)
@@ -203,7 +210,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(out.images.float()).all(), "non-finite output image"

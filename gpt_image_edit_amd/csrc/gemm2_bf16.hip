@@ -15,6 +15,14 @@
 // address and again on the ds_read_b128 side (cdna guide rule 21).  Fragments of k-step kk+1 are read
 // while k-step kk multiplies.
 //
+// Measured on MI355X (tools/): MFMA-only ceiling of this loop (LDS-DMA disabled) is 1.40 PF/s
+// (BN=128) / 1.56 PF/s (BN=256); with the DMA it reaches 1.05 / 1.20.  Fetching the same bytes into registers
+// instead costs only ~7 %, and the L2 -> LDS fill path alone sustains 23 TB/s (tests/probes/probe_fill.hip), so
+// the loss is LDS-port contention between DMA writes and fragment reads, not the fetch.  Dead ends tried and
+// removed (git history): phase-staggered waves ("8-phase", BK=32 ring, setprio): equal at BN=256, -15 % at
+// BN=128; A operand loaded straight to registers in fragment layout: 32-byte row pieces run the TA at half
+// speed (450 TF/s).
+//
 // Up to FK_MAX_GROUP problems with identical (N, K, epilogue) share one launch ("grouped GEMM"): the
 // text- and image-stream linears of a double block become one grid, which fills the 256 CUs at batch 1.
 #include "fk_common.h"

@@ -44,10 +44,11 @@ def all_gather_latents(latents):
     world = dist.get_world_size()
     x = latents.contiguous()
     out = torch.empty((world * x.shape[0], *x.shape[1:]), device=x.device, dtype=x.dtype)
-    if dist.get_backend() == "gloo":  # gloo has no all_gather_into_tensor for every dtype: gather a list
-        parts = [torch.empty_like(x) for _ in range(world)]
-        dist.all_gather(parts, x)
-        return torch.cat(parts, dim=0)
+    if dist.get_backend() == "gloo":  # CPU / smoke-test path: gloo gathers a list of host tensors
+        xc = x.cpu()
+        parts = [torch.empty_like(xc) for _ in range(world)]
+        dist.all_gather(parts, xc)
+        return torch.cat(parts, dim=0).to(x.device)
     dist.all_gather_into_tensor(out, x)
     return out
 

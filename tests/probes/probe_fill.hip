@@ -32,6 +32,28 @@ __global__ __launch_bounds__(512, 2) void fill_lds(const char* src, size_t regio
   if (threadIdx.x == 0) sink[blockIdx.x] = ((unsigned*)smem)[5];
 }
 
+// 16 rows x 64 B per instruction (BK = 32 staging): two consecutive instructions fetch the two halves of a line
+__global__ __launch_bounds__(512, 2) void fill_lds_half(const char* src, size_t region, int iters, unsigned* sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t row_stride = 6144;
+  size_t row = (size_t)(blockIdx.x * 8 + wave) * 64;
+  const int lrow = lane >> 2, slot = lane & 3;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const size_t r = (row + (j >> 1) * 16 + lrow);
+      const char* g = src + ((r * row_stride + (size_t)it * 128) % region) + (j & 1) * 64 + slot * 16;
+      __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)(smem + ((it % 3) * 6 + j) * 8192 + wave * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) sink[blockIdx.x] = ((unsigned*)smem)[5];
+}
+
 __global__ __launch_bounds__(512, 2) void fill_reg(const char* src, size_t region, int iters, unsigned* sink) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -60,18 +82,20 @@ int main() {
   hipFuncSetAttribute((const void*)fill_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
   const int iters = 2000;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int variant = 0; variant < 3; ++variant) {
+  hipFuncSetAttribute((const void*)fill_lds_half, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+  for (int variant = 0; variant < 4; ++variant) {
     for (int rep = 0; rep < 2; ++rep) {
       hipEventRecord(e0);
       if (variant == 0) hipLaunchKernelGGL(fill_lds<0>, dim3(256), dim3(512), 147456, 0, src, region, iters, sink);
       else if (variant == 1) hipLaunchKernelGGL(fill_lds<1>, dim3(256), dim3(512), 147456, 0, src, region, iters, sink);
-      else hipLaunchKernelGGL(fill_reg, dim3(256), dim3(512), 0, 0, src, region, iters, sink);
+      else if (variant == 2) hipLaunchKernelGGL(fill_reg, dim3(256), dim3(512), 0, 0, src, region, iters, sink);
+      else hipLaunchKernelGGL(fill_lds_half, dim3(256), dim3(512), 147456, 0, src, region, iters, sink);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       const double bytes = 256.0 * 8 * 6 * 1024 * iters;
       if (rep == 1)
         printf("%s: %.2f TB/s chip, %.1f GB/s per CU, %.1f B/clk/CU @2.0GHz\n",
-               variant == 0 ? "glds linear" : (variant == 1 ? "glds swizzled-src" : "global_load->reg"),
+               variant == 0 ? "glds linear" : (variant == 1 ? "glds swizzled-src" : (variant == 2 ? "global_load->reg" : "glds 16 rows x 64 B")),
                bytes / ms / 1e9, bytes / ms / 1e6 / 256, bytes / ms / 1e6 / 256 / 2.0);
     }
   }
