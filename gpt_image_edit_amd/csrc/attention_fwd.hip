@@ -149,11 +149,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
         const bf16x8_t kf = *(const bf16x8_t*)(sb + k_rd + kb * 8192 + (((2 * kk + hh) ^ k_sw) << 4));
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
+        // first k-step takes a literal zero C operand (inline constant): no per-tile re-zeroing of 32 registers
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], kk == 0 ? f32x16_t{} : s[kb], 0, 0, 0);
       }
     }
     if constexpr (MASK) {
@@ -189,7 +188,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
 #pragma unroll
     for (int df = 0; df < 4; ++df)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[df][r] *= alpha;
+      for (int r = 0; r < 16; ++r) o[df][r] *= alpha;   // (a conditional skip costs 32 v_mov_b64 of phi copies: worse)
 
     // ---- O^T += V^T P^T --------------------------------------------------------------------------------
 #pragma unroll
