@@ -232,7 +232,7 @@ def main():
         fam = instrumented_edit(pipe, inp)
         gm = fam["gemm"]
         result["roofline"] = {
-            "kernel": "gemm2_kernel<*> + gemm_bf16_kernel<*> (bf16 MFMA GEMM family: all MMDiT / VAE linears)", "bound": "mfma", "achieved": gm["tflops"],
+            "kernel": "gemm2_kernel<*> + gemm5_kernel<*> + gemm_bf16_kernel<*> (bf16 MFMA GEMM family: all MMDiT / VAE linears)", "bound": "mfma", "achieved": gm["tflops"],
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gm["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
             "launches_per_edit": gm["launches"], "ms_per_edit": gm["ms"], "algorithmic_tflop_per_edit": gm["flops"] / 1e12,
             "other_kernels": {k: {"ms_per_edit": v["ms"], "tflops": v["tflops"], "launches": v["launches"]}

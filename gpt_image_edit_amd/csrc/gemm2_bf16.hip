@@ -1,44 +1,51 @@
-// Large-tile bf16 MFMA GEMM for the MMDiT linears (second-generation kernel; same contract as
-// gemm_bf16.hip, used when M is large enough to fill 256-row tiles).
+// Large-tile bf16 MFMA GEMMs for the MMDiT linears (same contract as gemm_bf16.hip, used when M >= 192).
+// v_mfma_f32_32x32x16_bf16, operands swapped like gemm_bf16.hip (W rows -> MFMA A operand) so a lane owns 4
+// consecutive output columns of one row.  Two kernels, chosen per problem by (tile-quantisation efficiency) x
+// (measured steady-state rate):
 //
-//   tile 256(M) x BN(N) x 64(K), 512 threads = 8 waves, v_mfma_f32_32x32x16_bf16, operands swapped like
-//   gemm_bf16.hip (W rows -> MFMA A operand) so a lane owns 4 consecutive output columns of one row.
-//     BN = 128: waves 4(M) x 2(N), 64x64 per wave (2x2 accumulators), 3-stage LDS ring (3 x 48 KiB)
-//     BN = 256: waves 2(M) x 4(N), 128x64 per wave (4x2 accumulators), 2-stage LDS ring (2 x 64 KiB)
+//   gemm2_kernel   256 x 128 x 64, 8 waves (4 x 2, 64 x 64 per wave), LDS-DMA staging into a 3-stage ring
+//   gemm5_kernel   256 x 256 x 64, 4 waves (2 x 2, 128 x 128 per wave, one wave per SIMD, accumulators in AGPRs),
+//                  buffer_load -> VGPR -> ds_write_b128 staging into a 2-stage ring, slot-scheduled k-loop
 //
-// Staging is LDS-DMA (`global_load_lds_dwordx4`: no VGPR round trip, no ds_write pass).  Tile kt+PF
-// (PF = stages-1) is issued while tile kt is multiplied -- the DMA instructions are spread over the four
-// k-steps of the tile, between the MFMA groups, instead of in one burst after the barrier -- and each wave
-// waits with a COUNTED `s_waitcnt vmcnt(N)` so that with 3 stages a whole tile stays in flight across the
-// raw `s_barrier`.  One barrier per K-tile.  The LDS image of a DMA instruction is lane-linear (8 rows x
-// 128 B), so the bank-conflict swizzle (16-byte chunk ^ ((row >> 1) & 7)) is applied to the per-lane SOURCE
-// address and again on the ds_read_b128 side (cdna guide rule 21).  Fragments of k-step kk+1 are read
-// while k-step kk multiplies.
+// What the measurements of round 1 say (tools/pmc_gemm_compare.sh, tools/trace_gemm.py):
+//  * Under sustained MFMA load the chip clocks ~1.4-1.5 GHz, so the at-clock ceiling is ~1.5 PFLOP/s; the vendor
+//    library's hand-written 256x256 kernel keeps the MFMA pipe 90 % busy there (1.48 PF/s on 32768x3072x12288).
+//  * All 8-wave variants tried (LDS-DMA 2/3/4 stages, mid-tile or end-of-tile barrier, register staging, weights
+//    streamed straight into registers from a fragment-packed copy, phase-staggered waves) land on the same
+//    1.0-1.1 PF/s plateau with the pipe ~64 % busy and the waves 26-28 % parked in s_waitcnt/s_barrier; removing
+//    every vmcnt wait changes nothing, i.e. not memory latency.  (Probes that disable the staging run on stale,
+//    constant LDS data and clock higher: their 1.4-1.56 PF/s "ceilings" are not comparable.)
+//  * s_memtime traces of a 4-wave kernel: a k-step of 16 MFMAs + 8 ds_read_b128 takes ~540 cycles (ideal 512), but
+//    each `global_load_lds_dwordx4` adds 54-68 cycles of ISSUE time to its wave -- longer than the 28-cycle shadow
+//    of an MFMA, so the matrix pipe drains behind every piece (8 pieces per 32 MFMAs -> 68 % busy, exactly what
+//    the counters show).  `buffer_load_dwordx4` (one address VGPR) + `ds_write_b128` are two short instructions
+//    that each fit a shadow: gemm5_kernel reaches 75 % busy / 1.20 PF/s with the slots pinned in source order.
 //
-// Measured on MI355X (tools/): MFMA-only ceiling of this loop (LDS-DMA disabled) is 1.40 PF/s
-// (BN=128) / 1.56 PF/s (BN=256); with the DMA it reaches 1.05 / 1.20.  Fetching the same bytes into registers
-// instead costs only ~7 %, and the L2 -> LDS fill path alone sustains 23 TB/s (tests/probes/probe_fill.hip), so
-// the loss is LDS-port contention between DMA writes and fragment reads, not the fetch.  Dead ends tried and
-// removed (git history): phase-staggered waves ("8-phase", BK=32 ring, setprio): equal at BN=256, -15 % at
-// BN=128; A operand loaded straight to registers in fragment layout: 32-byte row pieces run the TA at half
-// speed (450 TF/s).
-//
+// The LDS image of a tile row is 128 B (64 k); the bank-conflict swizzle (16-byte chunk ^ ((row >> 1) & 7)) is
+// applied where the tile is written (DMA source address / ds_write address) and again on the ds_read_b128 side.
 // Up to FK_MAX_GROUP problems with identical (N, K, epilogue) share one launch ("grouped GEMM"): the
-// text- and image-stream linears of a double block become one grid, which fills the 256 CUs at batch 1.
+// text- and image-stream linears of a double block become one grid.
 #include "fk_common.h"
 
 namespace {
 
-constexpr int BM = 256, BK = 64;
+constexpr int BM = 256;
 constexpr int NT = 512;
 #ifndef FK_GROUP_M
 #define FK_GROUP_M 8
 #endif
 constexpr int GROUP_M = FK_GROUP_M;
-#ifndef FK_GEMM_SETPRIO
-#define FK_GEMM_SETPRIO 0
+// steady-state rate of the 256 x 256 kernel relative to the 256 x 128 one (measured)
+#ifndef FK_RATE_256
+#define FK_RATE_256 1.19
 #endif
-constexpr bool SETPRIO = FK_GEMM_SETPRIO;
+#ifndef FK_BSLOT
+#define FK_BSLOT 3
+#endif
+#ifndef FK_TRACE
+#define FK_TRACE 0  // development: s_memtime stamps of gemm5_kernel (tools/trace_gemm.py)
+#endif
+
 
 struct GroupArgs {
   fk_gemm_args p[FK_MAX_GROUP];
@@ -55,39 +62,44 @@ FK_DEV void glds16(const bf16_t* src, char* lds_dst) {
 
 template <int BN>
 struct Cfg {
-  static constexpr int WAVES_M = (BN == 128) ? 4 : 2;
-  static constexpr int WAVES_N = 8 / WAVES_M;
+  static constexpr int NTHREADS = NT;
+  static_assert(BN == 128, "the 8-wave kernel is instantiated for the 256 x 128 tile only");
+  static constexpr int BK = 64;
+  static constexpr int STAGES = 3;
+  static constexpr int KS = BK / 16;                   // MFMA k-steps per tile
+  static constexpr int CH = BK / 8;                    // 16-byte chunks per tile row
+  static constexpr int ROW_BYTES = BK * 2;
+  static constexpr int RPI = 64 / CH;                  // tile rows covered by one DMA instruction (1 KiB)
+  static constexpr int WAVES_M = 4, WAVES_N = 2;
   static constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;  // wave tile
   static constexpr int MF = WTM / 32, NF = WTN / 32;
-  static constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;
+  static constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES;
   static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-  static constexpr int STAGES = (BN == 128) ? 3 : 2;
   static constexpr int PF = STAGES - 1;
-  static constexpr int A_LOADS = BM / 64, W_LOADS = BN / 64;  // DMA instructions per wave per tile
+  static constexpr int A_LOADS = A_BYTES / 1024 / 8, W_LOADS = W_BYTES / 1024 / 8;  // DMA instr. per wave per tile
   static constexpr int LOADS = A_LOADS + W_LOADS;
+  static constexpr int FRAG_STRIDE = 32 * ROW_BYTES;   // LDS distance between 32-row fragments
   static constexpr int CT_LD = BN + 8;
   static constexpr int CT_BYTES = BM * CT_LD * 2;
   static constexpr int SMEM_BYTES = (STAGES * STAGE_BYTES > CT_BYTES) ? STAGES * STAGE_BYTES : CT_BYTES;
+  // bank-conflict swizzle of the 16-byte chunk index, as a function of the tile row
+  static FK_DEV int swz(int row) { return CH == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 };
 
 template <int N>
 FK_DEV void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else static_assert(N == 0, "add the vmcnt literal");
 }
 
-template <int EPI, int BN>
-__global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GroupArgs ga) {
-  using C = Cfg<BN>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave % C::WAVES_M, wn = wave / C::WAVES_M;
-
-  // ---- tile selection: XCD chunking over the whole grid, then problem, then grouped order ------------
+// tile selection: XCD chunking over the whole grid, then problem, then grouped (GROUP_M deep) order
+template <int BN>
+FK_DEV void select_tile(const GroupArgs& ga, int& pi, int& m0, int& n0) {
   int t;
   {
     const int nwg = gridDim.x;
@@ -95,119 +107,31 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GroupArgs ga) {
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  int pi = 0;
+  pi = 0;
 #pragma unroll
   for (int i = 1; i < FK_MAX_GROUP; ++i)
     if (i < ga.n && t >= ga.tiles_before[i]) pi = i;
   const fk_gemm_args& p = ga.p[pi];
   t -= ga.tiles_before[pi];
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  int tm, tn;
-  {
-    const int per_group = GROUP_M * nbn;
-    const int g = t / per_group;
-    const int first_m = g * GROUP_M;
-    const int gm = min(nbm - first_m, GROUP_M);
-    const int rem = t - g * per_group;
-    tm = first_m + rem % gm;
-    tn = rem / gm;
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int per_group = GROUP_M * nbn;
+  const int g = t / per_group;
+  const int first_m = g * GROUP_M;
+  const int gm = min(nbm - first_m, GROUP_M);
+  const int rem = t - g * per_group;
+  m0 = (first_m + rem % gm) * BM;
+  n0 = (rem / gm) * BN;
+}
 
-  // ---- LDS-DMA sources: lane -> (row = base + lane/8, slot = lane%8), source chunk = slot ^ f(row) -----
-  const int lrow = lane >> 3, slot = lane & 7;
-  const bf16_t* a_src[C::A_LOADS];
-  const bf16_t* w_src[C::W_LOADS];
-#pragma unroll
-  for (int j = 0; j < C::A_LOADS; ++j) {
-    const int rl = (wave * C::A_LOADS + j) * 8 + lrow;  // row inside the A tile
-    const int m = min(m0 + rl, p.M - 1);
-    a_src[j] = (const bf16_t*)p.A + fk_row_offset(p.a, m) + ((slot ^ ((rl >> 1) & 7)) << 3);
-  }
-#pragma unroll
-  for (int j = 0; j < C::W_LOADS; ++j) {
-    const int rl = (wave * C::W_LOADS + j) * 8 + lrow;
-    const int n = min(n0 + rl, p.N - 1);
-    w_src[j] = (const bf16_t*)p.W + (int64_t)n * p.ldw + ((slot ^ ((rl >> 1) & 7)) << 3);
-  }
-  // piece i of the tile's DMA list (A pieces first); `koff` = element offset of the K-tile
-  auto issue_piece = [&](int i, int64_t koff, char* sb) {
-    if (i < C::A_LOADS) glds16(a_src[i] + koff, sb + (wave * C::A_LOADS + i) * 1024);
-    else glds16(w_src[i - C::A_LOADS] + koff, sb + C::A_BYTES + (wave * C::W_LOADS + (i - C::A_LOADS)) * 1024);
-  };
-
-  // ---- MFMA operand addressing (same swizzle on the read side) -----------------------------------------
-  const int frow = lane & 31, fhalf = lane >> 5, fsw = (frow >> 1) & 7;
-  const int a_rd = (wm * C::WTM + frow) * 128;               // + mf*4096
-  const int w_rd = C::A_BYTES + (wn * C::WTN + frow) * 128;  // + nf*4096
-
-  f32x16_t acc[C::NF][C::MF];
-#pragma unroll
-  for (int i = 0; i < C::NF; ++i)
-#pragma unroll
-    for (int j = 0; j < C::MF; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = p.K / BK;
-#pragma unroll
-  for (int s = 0; s < C::PF; ++s)
-    if (s < nk) {
-#pragma unroll
-      for (int i = 0; i < C::LOADS; ++i) issue_piece(i, (int64_t)s * BK, smem + s * C::STAGE_BYTES);
-    }
-
-  int st_cur = 0, st_pf = C::PF;  // stage of tile kt, stage receiving tile kt+PF
-  // 3 stages: pieces spread over k-steps 0..2; 2 stages: all pieces in k-steps 0..1 so the last one
-  // still has two k-steps of MFMA work to land under before the next tile's vmcnt(0)
-  constexpr int PER_KK = (C::STAGES == 2) ? (C::LOADS + 1) / 2 : (C::LOADS + 2) / 3;
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed once at most (PF-1) newer tiles of this wave remain outstanding
-    if (kt + C::PF - 1 < nk) wait_vmcnt<(C::PF - 1) * C::LOADS>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-
-    const char* sb = smem + st_cur * C::STAGE_BYTES;
-    char* sb_pf = smem + st_pf * C::STAGE_BYTES;
-    const bool do_pf = kt + C::PF < nk;
-    const int64_t koff_pf = (int64_t)(kt + C::PF) * BK;
-
-    bf16x8_t af[2][C::MF], wf[2][C::NF];
-    {
-      const int coff = ((fhalf ^ fsw) << 4);
-#pragma unroll
-      for (int mf = 0; mf < C::MF; ++mf) af[0][mf] = *(const bf16x8_t*)(sb + a_rd + mf * 4096 + coff);
-#pragma unroll
-      for (int nf = 0; nf < C::NF; ++nf) wf[0][nf] = *(const bf16x8_t*)(sb + w_rd + nf * 4096 + coff);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int cb = kk & 1, nb = cb ^ 1;
-      if (kk < 3) {
-        const int coff = ((((kk + 1) * 2 + fhalf) ^ fsw) << 4);
-#pragma unroll
-        for (int mf = 0; mf < C::MF; ++mf) af[nb][mf] = *(const bf16x8_t*)(sb + a_rd + mf * 4096 + coff);
-#pragma unroll
-        for (int nf = 0; nf < C::NF; ++nf) wf[nb][nf] = *(const bf16x8_t*)(sb + w_rd + nf * 4096 + coff);
-      }
-      if (do_pf) {
-#pragma unroll
-        for (int i = kk * PER_KK; i < (kk + 1) * PER_KK && i < C::LOADS; ++i) issue_piece(i, koff_pf, sb_pf);
-      }
-      if constexpr (SETPRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int nf = 0; nf < C::NF; ++nf)
-#pragma unroll
-        for (int mf = 0; mf < C::MF; ++mf)
-          acc[nf][mf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][nf], af[cb][mf], acc[nf][mf], 0, 0, 0);
-      if constexpr (SETPRIO) __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    st_cur = (st_cur == C::STAGES - 1) ? 0 : st_cur + 1;
-    st_pf = (st_pf == C::STAGES - 1) ? 0 : st_pf + 1;
-  }
-
-  // ---- epilogue (as gemm_bf16.hip): bias/activation -> bf16 -> LDS tile -> coalesced 16-byte rows -------
+// epilogue (as gemm_bf16.hip): bias/activation -> bf16 -> LDS tile -> coalesced 16-byte rows.
+// acc[nf][mf] is the 32x32 block (n-block nf, m-block mf) of wave (wm, wn) in MFMA-output layout with the
+// swapped operands: lane l holds row (l & 31) of the m-block, columns 8*q + 4*(l >> 5) + j of the n-block.
+template <int EPI, int BN, class C>
+FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& p, char* smem, int m0, int n0,
+                       int wm, int wn) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int frow = lane & 31, fhalf = lane >> 5;
   __syncthreads();  // every wave is done reading the last stage before the C tile aliases it
   bf16_t* ct = (bf16_t*)smem;
 #pragma unroll
@@ -245,8 +169,8 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GroupArgs ga) {
   __syncthreads();
   constexpr int CPR = BN / 8;  // 16-byte chunks per tile row
 #pragma unroll
-  for (int j = 0; j < BM * CPR / NT; ++j) {
-    const int id = tid + NT * j;
+  for (int j = 0; j < BM * CPR / C::NTHREADS; ++j) {
+    const int id = tid + C::NTHREADS * j;
     const int ml = id / CPR, cc = id % CPR;
     const int m = m0 + ml, n = n0 + cc * 8;
     if (m >= p.M || n >= p.N) continue;
@@ -314,6 +238,297 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GroupArgs ga) {
   }
 }
 
+
+template <int EPI, int BN>
+__global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GroupArgs ga) {
+  using C = Cfg<BN>;
+  constexpr int BK = C::BK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % C::WAVES_M, wn = wave / C::WAVES_M;
+  int pi, m0, n0;
+  select_tile<BN>(ga, pi, m0, n0);
+  const fk_gemm_args& p = ga.p[pi];
+
+  // ---- LDS-DMA sources: lane -> (row = base + lane/CH, slot = lane%CH), source chunk = slot ^ swz(row) --
+  const int lrow = lane / C::CH, slot = lane % C::CH;
+  const bf16_t* a_src[C::A_LOADS];
+  const bf16_t* w_src[C::W_LOADS];
+#pragma unroll
+  for (int j = 0; j < C::A_LOADS; ++j) {
+    const int rl = (wave * C::A_LOADS + j) * C::RPI + lrow;  // row inside the A tile
+    const int m = min(m0 + rl, p.M - 1);
+    a_src[j] = (const bf16_t*)p.A + fk_row_offset(p.a, m) + ((slot ^ C::swz(rl)) << 3);
+  }
+#pragma unroll
+  for (int j = 0; j < C::W_LOADS; ++j) {
+    const int rl = (wave * C::W_LOADS + j) * C::RPI + lrow;
+    const int n = min(n0 + rl, p.N - 1);
+    w_src[j] = (const bf16_t*)p.W + (int64_t)n * p.ldw + ((slot ^ C::swz(rl)) << 3);
+  }
+  // piece i of the tile's DMA list (A pieces first); `koff` = element offset of the K-tile
+  auto issue_piece = [&](int i, int64_t koff, char* sb) {
+    if (i < C::A_LOADS) glds16(a_src[i] + koff, sb + (wave * C::A_LOADS + i) * 1024);
+    else glds16(w_src[i - C::A_LOADS] + koff, sb + C::A_BYTES + (wave * C::W_LOADS + (i - C::A_LOADS)) * 1024);
+  };
+
+  // ---- MFMA operand addressing (same swizzle on the read side) -----------------------------------------
+  const int frow = lane & 31, fhalf = lane >> 5, fsw = C::swz(frow);
+  const int a_rd = (wm * C::WTM + frow) * C::ROW_BYTES;               // + mf*FRAG_STRIDE
+  const int w_rd = C::A_BYTES + (wn * C::WTN + frow) * C::ROW_BYTES;  // + nf*FRAG_STRIDE
+
+  f32x16_t acc[C::NF][C::MF];
+#pragma unroll
+  for (int i = 0; i < C::NF; ++i)
+#pragma unroll
+    for (int j = 0; j < C::MF; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  bf16x8_t af[2][C::MF], wf[2][C::NF];
+  auto read_frags = [&](int buf, const char* sb, int kk) {
+    const int coff = (((kk * 2 + fhalf) ^ fsw) << 4);
+#pragma unroll
+    for (int mf = 0; mf < C::MF; ++mf) af[buf][mf] = *(const bf16x8_t*)(sb + a_rd + mf * C::FRAG_STRIDE + coff);
+#pragma unroll
+    for (int nf = 0; nf < C::NF; ++nf) wf[buf][nf] = *(const bf16x8_t*)(sb + w_rd + nf * C::FRAG_STRIDE + coff);
+  };
+
+  // Pipeline: tiles kt+1 .. kt+PF are in flight / landed while tile kt multiplies.  The ONE barrier per tile
+  // sits after the MFMAs of the tile's second-to-last k-step: it publishes tile kt+1 (every wave has waited
+  // for its own pieces of it) and retires the reads of tile kt-... so that the last k-step can already fetch
+  // the first fragments of tile kt+1 -- the MFMA stream never waits for an LDS round trip at a tile boundary.
+  const int nk = p.K / BK;
+#pragma unroll
+  for (int s = 0; s < C::PF; ++s)
+    if (s < nk) {
+#pragma unroll
+      for (int i = 0; i < C::LOADS; ++i) issue_piece(i, (int64_t)s * BK, smem + s * C::STAGE_BYTES);
+    }
+  if (nk > C::PF - 1) wait_vmcnt<(C::PF - 1) * C::LOADS>();
+  else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  read_frags(0, smem, 0);
+
+  int st_cur = 0, st_pf = C::PF;  // stage of tile kt, stage receiving tile kt+PF (= stage of tile kt-1)
+  constexpr int DMA_KK = (C::KS > 1) ? C::KS - 1 : 1;            // k-steps that carry DMA pieces (before the barrier)
+  constexpr int PER_KK = (C::LOADS + DMA_KK - 1) / DMA_KK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* sb = smem + st_cur * C::STAGE_BYTES;
+    const int st_nx = (st_cur == C::STAGES - 1) ? 0 : st_cur + 1;
+    const char* sb_nx = smem + st_nx * C::STAGE_BYTES;
+    char* sb_pf = smem + st_pf * C::STAGE_BYTES;
+    const bool do_pf = kt + C::PF < nk;
+    const bool more = kt + 1 < nk;
+    const int64_t koff_pf = (int64_t)(kt + C::PF) * BK;
+#pragma unroll
+    for (int kk = 0; kk < C::KS; ++kk) {
+      const int cb = kk & 1, nb = cb ^ 1;
+      if (do_pf && kk < DMA_KK) {
+#pragma unroll
+        for (int i = kk * PER_KK; i < (kk + 1) * PER_KK && i < C::LOADS; ++i) issue_piece(i, koff_pf, sb_pf);
+      }
+      // first half of the k-step's MFMAs, then the NEXT k-step's fragment reads (they land under the second
+      // half and are never what an `lgkmcnt` in front of an MFMA waits for), then the second half
+#pragma unroll
+      for (int nf = 0; nf < C::NF / 2; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < C::MF; ++mf)
+          acc[nf][mf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][nf], af[cb][mf], acc[nf][mf], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk < C::KS - 1) read_frags(nb, sb, kk + 1);
+      else if (more) read_frags(nb, sb_nx, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nf = C::NF / 2; nf < C::NF; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < C::MF; ++mf)
+          acc[nf][mf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][nf], af[cb][mf], acc[nf][mf], 0, 0, 0);
+      if (kk == C::KS - 2 && more) {
+        // tile kt+1 landed (own pieces) once at most the PF-1 newer tiles remain outstanding
+        const int newer = nk - kt - 2;  // tiles after kt+1 that exist (all issued by now)
+        if (newer >= C::PF - 1) wait_vmcnt<(C::PF - 1) * C::LOADS>();
+        else if (C::PF > 2 && newer == 1) wait_vmcnt<C::LOADS>();
+        else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile kt are complete
+        __builtin_amdgcn_s_barrier();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    st_cur = st_nx;
+    st_pf = (st_pf == C::STAGES - 1) ? 0 : st_pf + 1;
+  }
+
+  store_tile<EPI, BN, C>(acc, p, smem, m0, n0, wm, wn);
+}
+
+// ---- 4 waves, register staged --------------------------------------------------------------------------------
+// s_memtime traces of gemm4_kernel: a k-step of 16 MFMAs + 8 ds_read_b128 runs in ~540 cycles (ideal 512), but
+// every `global_load_lds_dwordx4` adds 54-68 cycles of ISSUE time to the wave -- longer than the 28-cycle shadow
+// of an MFMA, so with one wave per SIMD the matrix pipe drains behind each piece (8 pieces per 32 MFMAs -> 68 %,
+// exactly what the counters show).  Plain `global_load_dwordx4` + `ds_write_b128` are two short instructions that
+// each fit into an MFMA shadow, which is what the vendor kernel does.  Tile t+1 travels global -> registers during
+// tile t-1.., registers -> LDS during tile t (a k-step's worth per k-step), and is multiplied during tile t+1.
+template <int BN>
+struct Cfg5 {
+  static_assert(BN == 256, "the 4-wave kernel is instantiated for the 256 x 256 tile only");
+  static constexpr int NTHREADS = 256;
+  static constexpr int BK = 64, STAGES = 2, KS = 4, CH = 8, ROW_BYTES = 128, RPI = 8;
+  static constexpr int WAVES_M = 2, WAVES_N = 2;
+  static constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  static constexpr int MF = WTM / 32, NF = WTN / 32;
+  static constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES;
+  static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+  static constexpr int A_LOADS = A_BYTES / 1024 / 4, W_LOADS = W_BYTES / 1024 / 4;
+  static constexpr int LOADS = A_LOADS + W_LOADS;
+  static constexpr int PPK = LOADS / KS;
+  static constexpr int GAP = (NF * MF) / PPK;
+  static constexpr int FRAG_STRIDE = 32 * ROW_BYTES;
+  static constexpr int CT_LD = BN + 8;
+  static constexpr int CT_BYTES = BM * CT_LD * 2;
+  static constexpr int SMEM_BYTES = (STAGES * STAGE_BYTES > CT_BYTES) ? STAGES * STAGE_BYTES : CT_BYTES;
+  static_assert(LOADS % KS == 0, "pieces must divide over the k-steps");
+  static FK_DEV int swz(int row) { return (row >> 1) & 7; }
+};
+
+template <int EPI, int BN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm5_kernel(const GroupArgs ga) {
+  using C = Cfg5<BN>;
+  constexpr int BK = C::BK, KS = C::KS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % C::WAVES_M, wn = wave / C::WAVES_M;
+  int pi, m0, n0;
+  select_tile<BN>(ga, pi, m0, n0);
+  const fk_gemm_args& p = ga.p[pi];
+  const int nk = p.K / BK;
+
+  // Buffer loads: one SGPR descriptor per operand (base = first row of the tile), a 32-bit per-lane byte offset
+  // per piece (constant over K) and the K offset in an SGPR -- one address VGPR per load and no VALU address math.
+  // piece i of a tile = 8 rows x 128 B; lane -> (row = lane/8, chunk = lane%8), stored at slot chunk ^ swz(row)
+  const int lrow = lane >> 3, chunk = lane & 7;
+  const bf16_t* a_base = (const bf16_t*)p.A + fk_row_offset(p.a, m0);
+  const bf16_t* w_base = (const bf16_t*)p.W + (int64_t)n0 * p.ldw;
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, 0x7fffffff, 0x00020000);
+  int voff[C::LOADS], dst[C::LOADS];
+#pragma unroll
+  for (int j = 0; j < C::LOADS; ++j) {
+    const bool isA = j < C::A_LOADS;
+    const int rl = (wave * (isA ? C::A_LOADS : C::W_LOADS) + (isA ? j : j - C::A_LOADS)) * C::RPI + lrow;
+    if (isA) voff[j] = (int)((fk_row_offset(p.a, min(m0 + rl, p.M - 1)) - fk_row_offset(p.a, m0)) * 2) + chunk * 16;
+    else voff[j] = (int)((int64_t)(min(n0 + rl, p.N - 1) - n0) * p.ldw * 2) + chunk * 16;
+    dst[j] = (isA ? 0 : C::A_BYTES) + rl * C::ROW_BYTES + ((chunk ^ C::swz(rl)) << 4);
+  }
+  auto gload = [&](int i, int koff_bytes) {
+    return __builtin_amdgcn_raw_buffer_load_b128(i < C::A_LOADS ? rs_a : rs_w, voff[i], koff_bytes, 0);
+  };
+
+  const int frow = lane & 31, fhalf = lane >> 5, fsw = C::swz(frow);
+  const int a_rd = (wm * C::WTM + frow) * C::ROW_BYTES;
+  const int w_rd = C::A_BYTES + (wn * C::WTN + frow) * C::ROW_BYTES;
+
+  f32x16_t acc[C::NF][C::MF];
+#pragma unroll
+  for (int i = 0; i < C::NF; ++i)
+#pragma unroll
+    for (int j = 0; j < C::MF; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  bf16x8_t af[2][C::MF], wf[2][C::NF];
+  auto read_frag = [&](int buf, const char* sb, int kk, int f) {
+    const int coff = (((kk * 2 + fhalf) ^ fsw) << 4);
+    if (f < C::MF) af[buf][f] = *(const bf16x8_t*)(sb + a_rd + f * C::FRAG_STRIDE + coff);
+    else wf[buf][f - C::MF] = *(const bf16x8_t*)(sb + w_rd + (f - C::MF) * C::FRAG_STRIDE + coff);
+  };
+  auto koff_of = [&](int t) { return min(t, nk - 1) * (BK * 2); };  // bytes; clamped: surplus tiles are never multiplied
+
+  // Staging registers.  Pieces [0, PPK) ("quarter 0") run one tile ahead of the others: they are written in the
+  // LAST k-step of an iteration (after its barrier, into the stage that barrier freed).
+  typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned g_t;
+  g_t g[C::LOADS];
+  // fill: tile 0 -> stage 0 entirely; tile 1: quarter 0 -> stage 1, rest in registers; quarter 0 registers <- tile 2
+#pragma unroll
+  for (int i = 0; i < C::LOADS; ++i) g[i] = gload(i, 0);
+#pragma unroll
+  for (int i = 0; i < C::LOADS; ++i) *(g_t*)(smem + dst[i]) = g[i];
+#pragma unroll
+  for (int i = 0; i < C::LOADS; ++i) g[i] = gload(i, koff_of(1));
+#pragma unroll
+  for (int i = 0; i < C::PPK; ++i) {
+    *(g_t*)(smem + C::STAGE_BYTES + dst[i]) = g[i];
+    g[i] = gload(i, koff_of(2));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int f = 0; f < C::MF + C::NF; ++f) read_frag(0, smem, 0, f);
+
+  // One k-step = NM MFMA slots, pinned in source order (every filler must fit the 28-cycle shadow of its MFMA):
+  //   slots R0+1..R0+NFR  one ds_read_b128 of the next k-step's fragments each
+  //   slots W0, W0+2, ..  ds_write_b128 of staging piece q (registers -> LDS), W0 = NM - 2*PPK
+  //   slots W0+1, W0+3,.. buffer_load of the same registers for the next tile
+  // The last k-step of a tile carries the tile's barrier in front of slot R0 = BSLOT instead of at the k-step
+  // boundary: the LDS traffic of k-step KS-2 drains under the first BSLOT MFMAs instead of in front of a waitcnt.
+  auto kstep = [&](int cb, const char* sb_rd, int kk_rd, int p0, char* sb_wr, int koff, int r0, bool barrier) {
+    const int nb = cb ^ 1;
+    constexpr int NM = C::NF * C::MF, NFR = C::MF + C::NF, W0 = NM - 2 * C::PPK;
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      const int nf = i / C::MF, mf = i % C::MF;
+      if (barrier && i == r0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      acc[nf][mf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][nf], af[cb][mf], acc[nf][mf], 0, 0, 0);
+      if (i >= r0 + 1 && i - r0 - 1 < NFR) read_frag(nb, sb_rd, kk_rd, i - r0 - 1);
+      if (i >= W0) {
+        const int pc = p0 + (i - W0) / 2;
+        if (((i - W0) & 1) == 0) *(g_t*)(sb_wr + dst[pc]) = g[pc];
+        else g[pc] = gload(pc, koff);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+#if FK_TRACE
+  int* trace = (int*)(smem + C::SMEM_BYTES) + wave * 256;
+  auto stamp = [&](int j, int ev) {
+    if (j >= 16 && j < 32 && lane == 0) trace[(j - 16) * 8 + ev] = (int)__builtin_amdgcn_s_memtime();
+  };
+#else
+  auto stamp = [&](int, int) {};
+#endif
+  for (int j = 0; j < nk; ++j) {
+    char* sb = smem + (j & 1) * C::STAGE_BYTES;
+    char* sb_nx = smem + ((j + 1) & 1) * C::STAGE_BYTES;
+    const int koff2 = koff_of(j + 2), koff3 = koff_of(j + 3);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      stamp(j, kk);
+      // k-steps 0..2: quarters 1..3 of tile j+1 -> the other stage (free since the previous barrier), registers
+      // <- tile j+2;   k-step 3 (after this iteration's barrier): quarter 0 of tile j+2 -> this stage, <- tile j+3
+      if (kk < KS - 1) kstep(kk & 1, sb, kk + 1, (kk + 1) * C::PPK, sb_nx, koff2, 0, false);
+      else kstep(kk & 1, sb_nx, 0, 0, sb, koff3, FK_BSLOT, true);  // barrier: tile j+1 complete in LDS, reads of tile j done
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#if FK_TRACE
+  __syncthreads();
+  if (p.rope_cos && (blockIdx.x & 63) == 0) {
+    int* gt = (int*)p.rope_cos + ((blockIdx.x >> 6) * 4 + wave) * 128;
+    for (int i = lane; i < 128; i += 64) gt[i] = trace[i];
+  }
+  __syncthreads();
+#endif
+  store_tile<EPI, BN, C>(acc, p, smem, m0, n0, wm, wn);
+}
+
 template <int EPI, int BN>
 int launch(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) {
   int total = 0;
@@ -333,35 +548,61 @@ int launch(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) 
   return FK_OK;
 }
 
+template <int EPI, int BN>
+int launch5(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) {
+  int total = 0;
+  for (int i = 0; i < FK_MAX_GROUP; ++i) {
+    ga.tiles_before[i] = total;
+    if (i < n) total += ((probs[i].M + BM - 1) / BM) * ((probs[i].N + BN - 1) / BN);
+  }
+  ga.tiles_before[FK_MAX_GROUP] = total;
+  auto kern = gemm5_kernel<EPI, BN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg5<BN>::SMEM_BYTES + (FK_TRACE ? 4096 : 0));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(total), dim3(256), Cfg5<BN>::SMEM_BYTES + (FK_TRACE ? 4096 : 0), stream, ga);
+  FK_CHECK_LAUNCH("fk_gemm_bf16 (256-row tile, 4 waves, register staged)");
+  return FK_OK;
+}
+
 template <int EPI>
 int launch_bn(GroupArgs& ga, const fk_gemm_args* probs, int n, int bn, hipStream_t stream) {
-  return bn == 256 ? launch<EPI, 256>(ga, probs, n, stream) : launch<EPI, 128>(ga, probs, n, stream);
+  return bn == 256 ? launch5<EPI, 256>(ga, probs, n, stream) : launch<EPI, 128>(ga, probs, n, stream);
 }
 
 }  // namespace
 
 // Used by fk_gemm_bf16 / fk_gemm_bf16_grouped after argument validation.
-// bn_hint: 128 / 256 force the N tile; 0 = choose per problem.  The 256x256 tile has 1.5x the flop/byte of
-// 256x128 (measured ~1.18x the steady-state rate: the L2 -> LDS fill path is what limits these kernels), but
-// one workgroup per CU means the grid runs in rounds of 256 tiles: pick the tile with the better
-// (quantisation efficiency) x (steady-state rate).
+// bn_hint: 128 / 256 force the N tile; 0 = choose per problem.  The 256 x 256 kernel has the higher steady-state
+// rate (measured 1.19x at K = 12288), but one workgroup per CU means the grid runs in rounds of 256 tiles: pick
+// the tile with the better (quantisation efficiency) x (rate).
 int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t stream) {
   GroupArgs ga;
   ga.n = n;
   long t128 = 0, t256 = 0;
+  bool ok256 = probs[0].N % 256 == 0;
   for (int i = 0; i < FK_MAX_GROUP; ++i) {
     ga.p[i] = probs[i < n ? i : 0];
     if (i < n) {
       const long nbm = (probs[i].M + BM - 1) / BM;
       t128 += nbm * ((probs[i].N + 127) / 128);
       t256 += nbm * ((probs[i].N + 255) / 256);
+      // gemm5_kernel addresses a tile's rows with 32-bit byte offsets from the tile's first row
+      auto span = [](const fk_rows& r) {
+        const long long ld = r.ld < 0 ? -r.ld : r.ld, bs = r.batch_stride < 0 ? -r.batch_stride : r.batch_stride;
+        return (BM * ld + (r.rows_per_batch > 0 ? bs : 0)) * 2;
+      };
+      if (span(probs[i].a) >= (1ll << 31) || (long long)BM * probs[i].ldw * 2 >= (1ll << 31)) ok256 = false;
+      if (probs[i].a.ld < 0 || (probs[i].a.rows_per_batch > 0 && probs[i].a.batch_stride < 0)) ok256 = false;
     }
   }
   int bn = bn_hint;
+  if (bn == 256 && !ok256) bn = 128;
   if (bn != 128 && bn != 256) {
     auto eff = [](long tiles) { return (double)tiles / (double)(((tiles + 255) / 256) * 256); };
-    const bool ok256 = probs[0].N % 256 == 0;
-    bn = (ok256 && 1.18 * eff(t256) > eff(t128)) ? 256 : 128;
+    bn = (ok256 && FK_RATE_256 * eff(t256) > eff(t128)) ? 256 : 128;
   }
   switch (probs[0].epilogue) {
     case FK_EPI_NONE: return launch_bn<FK_EPI_NONE>(ga, probs, n, bn, stream);
