@@ -28,6 +28,22 @@ __global__ __launch_bounds__(256) void add3_kernel(const bf16_t* a, const bf16_t
   }
 }
 
+// true CFG: out = neg + scale * (pos - neg), each bf16 tensor op rounded like the reference graph
+__global__ __launch_bounds__(256) void true_cfg_kernel(const bf16_t* pos, const bf16_t* neg, bf16_t* out, float scale,
+                                                       int64_t nvec) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const u32x4_t pw = *(const u32x4_t*)(pos + i * 8), nw = *(const u32x4_t*)(neg + i * 8);
+    u32x4_t ow;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float n0 = bf_lo(nw[e]), n1 = bf_hi(nw[e]);
+      const float d0 = round_bf(bf_lo(pw[e]) - n0), d1 = round_bf(bf_hi(pw[e]) - n1);
+      ow[e] = pack_bf2(n0 + round_bf(__fmul_rn(scale, d0)), n1 + round_bf(__fmul_rn(scale, d1)));
+    }
+    *(u32x4_t*)(out + i * 8) = ow;
+  }
+}
+
 // Timesteps(256, flip_sin_to_cos=True, shift 0) on bf16(v)*1000 (bf16 multiply): out[b] = [cos | sin]
 __global__ void timestep_proj_kernel(const void* v, int v_is_fp32, const float* freqs, bf16_t* out, int B) {
   const int b = blockIdx.x;
@@ -153,6 +169,17 @@ extern "C" int fk_add3_bf16(const void* a, const void* b, const void* c, void* o
   hipLaunchKernelGGL(add3_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
                      (const bf16_t*)b, (const bf16_t*)c, (bf16_t*)out, n / 8);
   FK_CHECK_LAUNCH("fk_add3_bf16");
+  return FK_OK;
+}
+
+extern "C" int fk_true_cfg_bf16(const void* pos, const void* neg, void* out, float scale, int64_t n,
+                                fk_stream_t stream) {
+  FK_CHECK_ARG(pos && neg && out && n > 0 && n % 8 == 0, "fk_true_cfg_bf16: n must be a positive multiple of 8");
+  FK_CHECK_ARG(((uintptr_t)pos % 16 == 0) && ((uintptr_t)neg % 16 == 0) && ((uintptr_t)out % 16 == 0),
+               "fk_true_cfg_bf16: alignment");
+  hipLaunchKernelGGL(true_cfg_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pos,
+                     (const bf16_t*)neg, (bf16_t*)out, scale, n / 8);
+  FK_CHECK_LAUNCH("fk_true_cfg_bf16");
   return FK_OK;
 }
 

@@ -21,7 +21,7 @@ inline int gn_blocks(int64_t HW, int C) {
 // grid (nblk, B).  Thread t owns channel chunk (t % (C/8)) of pixels (t / (C/8)) + k * ppi.
 __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(const bf16_t* x, float* ws, int64_t HW, int C,
                                                                 int groups) {
-  __shared__ float gsum[64], gsq[64];
+  __shared__ float hs[2 * GN_THREADS], hq[2 * GN_THREADS];
   const int tid = threadIdx.x;
   const int cpr = C / 8;                 // 16-byte chunks per pixel
   const int ppi = GN_THREADS / cpr;      // pixels per iteration
@@ -43,21 +43,28 @@ __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(const bf16_t* x,
       q_hi += (v4 * v4 + v5 * v5) + (v6 * v6 + v7 * v7);
     }
   }
-  if (tid < 64) { gsum[tid] = 0.f; gsq[tid] = 0.f; }
-  __syncthreads();
-  if (prow < ppi) {
-    const int cpg = C / groups;  // channels per group: 4, 8 or 16 (C = 128, 256, 512)
-    const int g_lo = (chunk * 8) / cpg, g_hi = (chunk * 8 + 4) / cpg;
-    atomicAdd(&gsum[g_lo], s_lo);
-    atomicAdd(&gsq[g_lo], q_lo);
-    atomicAdd(&gsum[g_hi], s_hi);
-    atomicAdd(&gsq[g_hi], q_hi);
-  }
+  // In-block merge in a FIXED order (no float atomics: their order, hence the rounding, would vary run to run):
+  // every thread publishes its two half-chunk sums; thread g then adds the 16 entries of group g -- pixel rows
+  // outer, half-chunks inner -- one after the other.
+  hs[tid * 2] = s_lo;
+  hq[tid * 2] = q_lo;
+  hs[tid * 2 + 1] = s_hi;
+  hq[tid * 2 + 1] = q_hi;
   __syncthreads();
   if (tid < groups) {
+    const int cpg = C / groups;   // channels per group: 4, 8 or 16 (C = 128, 256, 512)
+    const int hpg = cpg / 4;      // half-chunks (4 channels) per group
+    float s = 0.f, q = 0.f;
+    for (int pr = 0; pr < ppi; ++pr)
+      for (int h = 0; h < hpg; ++h) {
+        const int hc = tid * hpg + h;                    // half-chunk index inside a pixel
+        const int e = (pr * cpr + (hc >> 1)) * 2 + (hc & 1);
+        s += hs[e];
+        q += hq[e];
+      }
     float* o = ws + (((int64_t)b * nblk + blockIdx.x) * groups + tid) * 2;
-    o[0] = gsum[tid];
-    o[1] = gsq[tid];
+    o[0] = s;
+    o[1] = q;
   }
 }
 
@@ -159,6 +166,53 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const bf16_t* src, T*
   }
 }
 
+// uint8 NHWC pixels (PIL layout) -> NHWC bf16, C zero padded: nearest resize + [-1, 1] normalisation in one gather.
+//   v = ((u / 255) - 0.5) / 0.5 in fp32 (reference cli.py:106-109), optionally 2v - 1 once more
+//   (VaeImageProcessor.preprocess normalises whenever the tensor has no negative value), then bf16
+//   (`image.to(dtype)` in prepare_latents).  Source row/col = min(floor(dst * (float)in / out), in - 1):
+//   torch's `F.interpolate(mode="nearest")`, which is what VaeImageProcessor.resize runs on tensors.
+__global__ __launch_bounds__(256) void pixels_u8_to_nhwc_kernel(const uint8_t* src, bf16_t* dst, int Hin, int Win,
+                                                                int Hout, int Wout, int Cpad, int renorm) {
+  const int b = blockIdx.y;
+  const int64_t total = (int64_t)Hout * Wout * Cpad;
+  const uint8_t* sb = src + (int64_t)b * Hin * Win * 3;
+  bf16_t* db = dst + (int64_t)b * total;
+  const float sy = (float)Hin / (float)Hout, sx = (float)Win / (float)Wout;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % Cpad);
+    const int64_t pix = i / Cpad;
+    float v = 0.f;
+    if (c < 3) {
+      const int y = (int)(pix / Wout), x = (int)(pix - (int64_t)y * Wout);
+      const int yi = min((int)floorf(__fmul_rn((float)y, sy)), Hin - 1);
+      const int xi = min((int)floorf(__fmul_rn((float)x, sx)), Win - 1);
+      const float u = (float)sb[((int64_t)yi * Win + xi) * 3 + c];
+      v = __fdiv_rn(__fsub_rn(__fdiv_rn(u, 255.0f), 0.5f), 0.5f);
+      if (renorm) v = __fsub_rn(__fmul_rn(2.0f, v), 1.0f);
+    }
+    db[i] = f2bf(v);
+  }
+}
+
+// decoder output NCHW (bf16 / fp32, in [-1, 1]) -> uint8 NHWC: VaeImageProcessor.postprocess up to the PIL array,
+//   t = clamp(bf16(bf16(x / 2) + 0.5), 0, 1) in the tensor's dtype, then rint(float(t) * 255) (numpy round = half even)
+template <typename T>
+__global__ __launch_bounds__(256) void image_to_u8_kernel(const T* src, uint8_t* dst, int C, int64_t HW) {
+  const int b = blockIdx.y;
+  const int64_t total = HW * C;
+  const T* sb = src + (int64_t)b * total;
+  uint8_t* db = dst + (int64_t)b * total;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    float t;
+    if constexpr (sizeof(T) == 4) t = __fadd_rn(__fdiv_rn(sb[(int64_t)c * HW + p], 2.0f), 0.5f);
+    else t = round_bf(round_bf(bf2f(sb[(int64_t)c * HW + p]) * 0.5f) + 0.5f);
+    t = fminf(fmaxf(t, 0.f), 1.f);
+    db[i] = (uint8_t)rintf(__fmul_rn(t, 255.0f));
+  }
+}
+
 inline int ew_grid(int64_t n) {
   int64_t g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -222,5 +276,28 @@ extern "C" int fk_nhwc_to_nchw(const void* src, void* dst, int32_t dst_is_fp32, 
   if (dst_is_fp32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, block, 0, s, (const bf16_t*)src, (float*)dst, C, Cpad, HW, add, mul);
   else hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)src, (bf16_t*)dst, C, Cpad, HW, add, mul);
   FK_CHECK_LAUNCH("fk_nhwc_to_nchw");
+  return FK_OK;
+}
+
+extern "C" int fk_pixels_u8_to_nhwc_bf16(const void* src, void* dst, int32_t B, int32_t Hin, int32_t Win, int32_t Hout,
+                                         int32_t Wout, int32_t Cpad, int32_t renorm, fk_stream_t stream_) {
+  FK_CHECK_ARG(src && dst && B > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && Cpad >= 3,
+               "fk_pixels_u8_to_nhwc_bf16: bad arguments");
+  const dim3 grid(ew_grid((int64_t)Hout * Wout * Cpad), B), block(256);
+  hipLaunchKernelGGL(pixels_u8_to_nhwc_kernel, grid, block, 0, (hipStream_t)stream_, (const uint8_t*)src, (bf16_t*)dst,
+                     Hin, Win, Hout, Wout, Cpad, renorm);
+  FK_CHECK_LAUNCH("fk_pixels_u8_to_nhwc_bf16");
+  return FK_OK;
+}
+
+extern "C" int fk_image_to_u8_nhwc(const void* src, int32_t src_is_fp32, void* dst, int32_t B, int32_t C, int32_t H,
+                                   int32_t W, fk_stream_t stream_) {
+  FK_CHECK_ARG(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "fk_image_to_u8_nhwc: bad arguments");
+  const int64_t HW = (int64_t)H * W;
+  const dim3 grid(ew_grid(HW * C), B), block(256);
+  hipStream_t s = (hipStream_t)stream_;
+  if (src_is_fp32) hipLaunchKernelGGL(image_to_u8_kernel<float>, grid, block, 0, s, (const float*)src, (uint8_t*)dst, C, HW);
+  else hipLaunchKernelGGL(image_to_u8_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)src, (uint8_t*)dst, C, HW);
+  FK_CHECK_LAUNCH("fk_image_to_u8_nhwc");
   return FK_OK;
 }

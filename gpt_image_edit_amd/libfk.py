@@ -55,6 +55,7 @@ SIGNATURES = {
     "fk_silu_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "fk_timestep_proj": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp]),
     "fk_add3_bf16": (c_i32, [c_vp] * 4 + [c_i64, c_vp]),
+    "fk_true_cfg_bf16": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_i64, c_vp]),
     "fk_euler_step_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "fk_transpose_bf16": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "fk_softmax_rows": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp]),
@@ -64,6 +65,8 @@ SIGNATURES = {
     "fk_groupnorm_apply_nhwc_bf16": (c_i32, [c_vp] * 5 + [c_i32, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "fk_nchw_to_nhwc_bf16": (c_i32, [c_vp, c_i32, c_vp] + [c_i32] * 5 + [c_f32, c_f32, c_vp]),
     "fk_nhwc_to_nchw": (c_i32, [c_vp, c_vp] + [c_i32] * 6 + [c_f32, c_f32, c_vp]),
+    "fk_pixels_u8_to_nhwc_bf16": (c_i32, [c_vp, c_vp] + [c_i32] * 7 + [c_vp]),
+    "fk_image_to_u8_nhwc": (c_i32, [c_vp, c_i32, c_vp] + [c_i32] * 4 + [c_vp]),
     "fk_last_error": (ctypes.c_char_p, []),
     "fk_version": (ctypes.c_char_p, []),
 }

@@ -193,6 +193,18 @@ def add3(a, b, c, out=None):
     return out
 
 
+def true_cfg(pos, neg, scale, out=None):
+    """out = neg + scale * (pos - neg) with the reference's bf16 rounding points (flux_pipeline.py:1095)."""
+    _need_cuda(pos, neg, out)
+    if pos.shape != neg.shape or pos.dtype != BF16 or neg.dtype != BF16 or not (pos.is_contiguous() and neg.is_contiguous()):
+        raise ValueError("true_cfg takes two contiguous bf16 tensors of one shape")
+    if out is None:
+        out = torch.empty_like(pos)
+    libfk.check(libfk.load().fk_true_cfg_bf16(_ptr(pos), _ptr(neg), _ptr(out), float(scale), pos.numel(), _stream()),
+                "fk_true_cfg_bf16")
+    return out
+
+
 def timestep_proj(v, freqs, out=None):
     """[B] (bf16 or fp32) -> [B,256] bf16 sinusoid of bf16(v)*1000 (cos first)."""
     _need_cuda(v, freqs)
@@ -294,4 +306,29 @@ def nhwc_to_nchw(x, c, add=0.0, mul=1.0, dtype=BF16):
     out = torch.empty((B, c, H, W), device=x.device, dtype=dtype)
     libfk.check(libfk.load().fk_nhwc_to_nchw(_ptr(x), _ptr(out), int(dtype == torch.float32), B, c, cpad, H, W,
                                              float(add), float(mul), _stream()), "fk_nhwc_to_nchw")
+    return out
+
+
+def pixels_to_nhwc(u8, out_h, out_w, cpad=32, renorm=False):
+    """uint8 NHWC pixels [B,Hin,Win,3] -> NHWC bf16 [B,out_h,out_w,cpad] in [-1,1]: cli.py:106-109 normalisation,
+    VaeImageProcessor tensor resize (nearest) and the bf16 cast, one gather kernel."""
+    _need_cuda(u8)
+    if u8.dtype != torch.uint8 or u8.dim() != 4 or u8.shape[3] != 3 or not u8.is_contiguous():
+        raise TypeError("pixels_to_nhwc takes a contiguous uint8 [B, H, W, 3] tensor")
+    B, Hin, Win, _ = u8.shape
+    out = torch.empty((B, out_h, out_w, cpad), device=u8.device, dtype=BF16)
+    libfk.check(libfk.load().fk_pixels_u8_to_nhwc_bf16(_ptr(u8), _ptr(out), B, Hin, Win, out_h, out_w, cpad,
+                                                       int(bool(renorm)), _stream()), "fk_pixels_u8_to_nhwc_bf16")
+    return out
+
+
+def image_to_u8(img):
+    """decoder output [B,C,H,W] (bf16/fp32, [-1,1]) -> uint8 [B,H,W,C] (VaeImageProcessor.postprocess, 'pil' array)."""
+    _need_cuda(img)
+    if img.dtype not in (BF16, torch.float32) or img.dim() != 4 or not img.is_contiguous():
+        raise TypeError("image_to_u8 takes a contiguous fp32/bf16 NCHW tensor")
+    B, C, H, W = img.shape
+    out = torch.empty((B, H, W, C), device=img.device, dtype=torch.uint8)
+    libfk.check(libfk.load().fk_image_to_u8_nhwc(_ptr(img), int(img.dtype == torch.float32), _ptr(out), B, C, H, W,
+                                                 _stream()), "fk_image_to_u8_nhwc")
     return out

@@ -12,15 +12,16 @@ over ONE persistent token buffer [B, S_tgt + S_cond, 64] (target tokens first, c
 the reference's per-step ``torch.cat([latents, image_latents], dim=1)`` disappears), with all per-step
 scalars prepared before the loop so the 28 steps enqueue without a host sync.
 
-Host-side pre/post-processing of pixels (resize of the condition image, uint8/PIL conversion) is the
-"next row" of SURVEY.md section 8(f) and still uses torch ops; it is outside the timed hot path.
+Pixels either side of the path: ``image_processor.VaeImageProcessor`` restates the
+diffusers helper the reference pipeline calls; uint8 pixels (PIL / numpy / uint8 tensors) take two fused HIP kernels
+(normalise + nearest resize + cast in front of the VAE encoder, clamp + quantise behind the decoder).
 """
 from types import SimpleNamespace
 
 import numpy as np
 import torch
 
-from . import helpers, ops
+from . import helpers, image_processor, ops
 from .scheduler import FlowMatchEulerDiscreteScheduler
 
 BF16 = torch.bfloat16
@@ -41,6 +42,7 @@ class FluxKontextPipeline:
         self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1)
         self.latent_channels = vae.config.latent_channels
         self.default_sample_size = 128
+        self.image_processor = image_processor.VaeImageProcessor(vae_scale_factor=self.vae_scale_factor * 2)
         self._interrupt = False
         self._guidance_scale = None
         self._num_timesteps = 0
@@ -89,10 +91,11 @@ class FluxKontextPipeline:
         if max_sequence_length is not None and max_sequence_length > 512:
             raise ValueError(f"`max_sequence_length` cannot be greater than 512 but is {max_sequence_length}")
 
-    def _encode_vae_image(self, image):
+    def _encode_vae_image(self, image, nhwc=False):
         """(mode(vae.encode(image)) - shift) * scale, the affine fused into the layout kernel (:600-613)."""
         cfg = self.vae.config
-        return self.vae.encode(image, post_add=-cfg.shift_factor, post_mul=cfg.scaling_factor).latent_dist.mode()
+        return self.vae.encode(image, post_add=-cfg.shift_factor, post_mul=cfg.scaling_factor,
+                               nhwc=nhwc).latent_dist.mode()
 
     def prepare_latents(self, image, batch_size, num_channels_latents, height, width, dtype, device,
                         generator=None, latents=None):
@@ -106,7 +109,9 @@ class FluxKontextPipeline:
         image_latents = image_ids = None
         if image is not None:
             image = image.to(device=device)
-            if image.shape[1] != self.latent_channels:
+            if image.dim() == 4 and image.shape[3] == 32 and image.dtype == BF16:  # fused pixel route: NHWC bf16
+                image_latents = self._encode_vae_image(image, nhwc=True)
+            elif image.shape[1] != self.latent_channels:
                 image_latents = self._encode_vae_image(image)
             else:
                 image_latents = image.to(dtype)
@@ -154,9 +159,7 @@ class FluxKontextPipeline:
         self._guidance_scale = guidance_scale
         self._interrupt = False
         has_neg = negative_prompt_embeds is not None and negative_pooled_prompt_embeds is not None
-        if true_cfg_scale > 1 and has_neg:
-            raise NotImplementedError("true-CFG (second transformer pass) is a later row of SURVEY.md 8(f); "
-                                      "no reference caller enables it")
+        do_true_cfg = true_cfg_scale > 1 and has_neg  # :928
         batch_size = prompt_embeds.shape[0] * num_images_per_prompt
         prompt_embeds = prompt_embeds.to(device=device, dtype=BF16)
         pooled_prompt_embeds = pooled_prompt_embeds.to(device=device, dtype=BF16)
@@ -164,16 +167,39 @@ class FluxKontextPipeline:
             prompt_embeds = prompt_embeds.repeat_interleave(num_images_per_prompt, dim=0)
             pooled_prompt_embeds = pooled_prompt_embeds.repeat_interleave(num_images_per_prompt, dim=0)
         text_ids = torch.zeros(prompt_embeds.shape[1], 3, device=device, dtype=BF16)  # :436
+        if do_true_cfg:
+            # The reference runs a second transformer call per step on the negative embeddings (:1080-1095).  Samples
+            # are independent in the MMDiT, so here the positive and the negative pass are ONE call on a batch of 2B
+            # (twice the GEMM rows per weight read), followed by the fused combine kernel.
+            neg_e = negative_prompt_embeds.to(device=device, dtype=BF16)
+            neg_p = negative_pooled_prompt_embeds.to(device=device, dtype=BF16)
+            if num_images_per_prompt > 1:
+                neg_e = neg_e.repeat_interleave(num_images_per_prompt, dim=0)
+                neg_p = neg_p.repeat_interleave(num_images_per_prompt, dim=0)
+            if neg_e.shape != prompt_embeds.shape:
+                raise NotImplementedError("true CFG needs negative_prompt_embeds of the positive embeddings' shape "
+                                          "(pad the shorter prompt; the joint pass shares one text length)")
+            model_embeds = torch.cat([prompt_embeds, neg_e], dim=0)
+            model_pooled = torch.cat([pooled_prompt_embeds, neg_p], dim=0)
+        else:
+            model_embeds, model_pooled = prompt_embeds, pooled_prompt_embeds
+        model_batch = model_embeds.shape[0]
 
         # 3. condition image: preferred-resolution snap + nearest resize (VaeImageProcessor tensor path)
-        if image is not None and not (isinstance(image, torch.Tensor) and image.size(1) == self.latent_channels):
+        u8 = image_processor.as_uint8_nhwc(image) if image is not None else None
+        if u8 is not None:
+            # uint8 pixels: cli.prepare_condition_images + resize + preprocess + .to(bf16) as ONE HIP gather
+            ih, iw = self.image_processor.get_default_height_width(u8.permute(0, 3, 1, 2))
+            ih, iw = helpers.preferred_condition_size(ih, iw, multiple_of, _auto_resize)
+            image = image_processor.pixels_to_latent_input(u8, ih, iw, device)
+        elif image is not None and not (isinstance(image, torch.Tensor) and image.size(1) == self.latent_channels):
             if not isinstance(image, torch.Tensor) or image.dim() != 4:
-                raise NotImplementedError("pass the condition image as a [N,3,H,W] tensor in [-1,1] (cli.py:99-116)")
-            ih, iw = helpers.preferred_condition_size(image.shape[2], image.shape[3], multiple_of, _auto_resize)
-            if (ih, iw) != tuple(image.shape[2:]):
-                image = torch.nn.functional.interpolate(image.float(), size=(ih, iw))
-            if image.min() >= 0:  # VaeImageProcessor.preprocess: normalise only [0,1] inputs
-                image = 2.0 * image - 1.0
+                raise NotImplementedError("pass the condition image as a [N,3,H,W] tensor in [-1,1] (cli.py:99-116) "
+                                          "or as uint8 pixels (PIL / numpy / uint8 tensor [N,H,W,3])")
+            ih, iw = self.image_processor.get_default_height_width(image)
+            ih, iw = helpers.preferred_condition_size(ih, iw, multiple_of, _auto_resize)
+            image = self.image_processor.resize(image.float(), ih, iw) if (ih, iw) != tuple(image.shape[2:]) else image
+            image = self.image_processor.preprocess(image, ih, iw)
 
         # 4. latents
         num_channels_latents = self.transformer.config.in_channels // 4
@@ -195,23 +221,29 @@ class FluxKontextPipeline:
         timesteps = self.scheduler.timesteps
         self._num_timesteps = len(timesteps)
         # `t.expand(B).to(bf16)` then `/ 1000` (flux_pipeline.py:1065,1069): all steps prepared up front
-        t_model = (timesteps.to(BF16) / 1000)[:, None].expand(-1, batch_size).contiguous().to(device)
+        t_model = (timesteps.to(BF16) / 1000)[:, None].expand(-1, model_batch).contiguous().to(device)
         guidance = None
         if self.transformer.config.guidance_embeds:
-            guidance = torch.full([batch_size], guidance_scale, device=device, dtype=torch.float32)
+            guidance = torch.full([model_batch], guidance_scale, device=device, dtype=torch.float32)
         self.scheduler.set_begin_index(0)
         if hasattr(self.transformer, "prepare_conditioning"):  # all steps' modulation vectors in one pass
-            self.transformer.prepare_conditioning(t_model, guidance, pooled_prompt_embeds)
+            self.transformer.prepare_conditioning(t_model, guidance, model_pooled)
+        model_tokens = torch.empty((model_batch, *tokens.shape[1:]), device=device, dtype=BF16) if do_true_cfg else tokens
 
         # 6. denoising loop: no allocation, no host sync
         for i in range(len(timesteps)):
             if self._interrupt:
                 continue
+            if do_true_cfg:
+                model_tokens[:batch_size].copy_(tokens)
+                model_tokens[batch_size:].copy_(tokens)
             noise_pred = self.transformer(
-                hidden_states=tokens, timestep=t_model[i], guidance=guidance,
-                pooled_projections=pooled_prompt_embeds, encoder_hidden_states=prompt_embeds,
+                hidden_states=model_tokens, timestep=t_model[i], guidance=guidance,
+                pooled_projections=model_pooled, encoder_hidden_states=model_embeds,
                 txt_ids=text_ids, img_ids=latent_ids, joint_attention_kwargs=joint_attention_kwargs or {},
                 return_dict=False)[0]
+            if do_true_cfg:
+                noise_pred = ops.true_cfg(noise_pred[:batch_size], noise_pred[batch_size:], true_cfg_scale)
             ops.euler_step(tokens, noise_pred, S_tgt, self.scheduler.dsigma(i))
             if callback_on_step_end is not None:
                 out = callback_on_step_end(self, i, timesteps[i], {"latents": tokens[:, :S_tgt]})
@@ -232,15 +264,5 @@ class FluxKontextPipeline:
 
     @staticmethod
     def postprocess(image, output_type="pil"):
-        """VaeImageProcessor.postprocess: denormalise, clamp; 'pt' tensor, 'np' float NHWC, 'pil' images."""
-        if output_type == "pt_raw":
-            return image
-        x = (image / 2 + 0.5).clamp(0, 1)
-        if output_type == "pt":
-            return x
-        arr = x.cpu().permute(0, 2, 3, 1).float().numpy()
-        if output_type == "np":
-            return arr
-        from PIL import Image
-        arr = (arr * 255).round().astype("uint8")
-        return [Image.fromarray(a) for a in arr]
+        """VaeImageProcessor.postprocess (flux_pipeline.py:1130); 'pil' / 'np_uint8' quantise on the GPU."""
+        return image_processor.VaeImageProcessor.postprocess(image, output_type)

@@ -1,0 +1,162 @@
+"""Command-line front end of the HIP path -- counterpart of the reference's ``univa/serve/cli.py``.
+
+Same flags and defaults (``cli.py:271-283``), same helper names and semantics (``update_size`` :82-97,
+``prepare_condition_images`` :99-116, ``load_pipe`` :58-76) and the same generation call (:239-248); what changes
+is what sits behind ``pipe``: ``HipFluxTransformer2DModel`` + ``HipAutoencoderKL`` filled from the same checkpoints
+(``gpt_image_edit_amd.checkpoint``).
+
+Prompt understanding (Qwen2.5-VL + task head, T5/CLIP: SURVEY.md rows a13/a14) is reused as-is from the reference
+package when it is importable next to this one (``univa.models...``); offline, ``--prompt_embeds FILE`` feeds the
+generation half from saved embeddings (a ``torch.save``d dict with ``prompt_embeds`` [1,L,4096] and
+``pooled_prompt_embeds`` [1,768]), which is also how the parity tests drive it.
+"""
+import argparse
+import os
+
+import numpy as np
+import torch
+
+from .. import checkpoint, flux_spec
+from ..anyres_util import dynamic_resize
+from ..pipeline import FluxKontextPipeline
+from ..scheduler import FlowMatchEulerDiscreteScheduler
+from ..transformer import HipFluxTransformer2DModel
+from ..vae import HipAutoencoderKL
+
+seed = 42  # cli.py:20-26 seeds everything with 42 and draws the edit's noise from Generator("cuda").manual_seed(seed)
+generate_image_temp = "./generate_image_{}.png"
+
+
+def load_pipe(denoiser, flux_path, device):
+    """``FluxKontextPipeline.from_pretrained(flux_path, transformer=denoiser, torch_dtype=bf16).to(device)``.
+
+    ``denoiser``: a ``HipFluxTransformer2DModel``, or a checkpoint directory (a UniWorld model directory with
+    ``denoise_tower.denoiser.*`` keys, cli.py:127, or a diffusers FLUX directory), or None = ``flux_path``'s own
+    transformer.  Returns (pipe, tokenizers, text_encoders) like the reference; the T5/CLIP encoders are loaded
+    with ``transformers`` when ``flux_path`` holds them, else the two lists contain None."""
+    if not isinstance(denoiser, HipFluxTransformer2DModel):
+        src = denoiser or flux_path
+        cfg = checkpoint.flux_transformer_config(flux_path) if os.path.isdir(os.path.join(flux_path, "transformer")) else None
+        model = HipFluxTransformer2DModel(cfg, device=device)
+        checkpoint.load_flux_transformer(model, src)
+        denoiser = model
+    vae = HipAutoencoderKL(device=device)
+    checkpoint.load_vae(vae, flux_path)
+    sched = FlowMatchEulerDiscreteScheduler(**checkpoint.scheduler_config(flux_path))
+    tokenizers, text_encoders = [None, None], [None, None]
+    try:  # reused as-is; absent offline
+        from transformers import CLIPTextModel, CLIPTokenizer, T5EncoderModel, T5TokenizerFast
+        if os.path.isdir(os.path.join(flux_path, "text_encoder")):
+            tokenizers = [CLIPTokenizer.from_pretrained(flux_path, subfolder="tokenizer"),
+                          T5TokenizerFast.from_pretrained(flux_path, subfolder="tokenizer_2")]
+            text_encoders = [CLIPTextModel.from_pretrained(flux_path, subfolder="text_encoder", torch_dtype=torch.bfloat16).to(device),
+                             T5EncoderModel.from_pretrained(flux_path, subfolder="text_encoder_2", torch_dtype=torch.bfloat16).to(device)]
+    except Exception as e:  # pragma: no cover
+        print(f"text encoders not loaded ({type(e).__name__}: {e}); pass --prompt_embeds")
+    pipe = FluxKontextPipeline(denoiser, vae, sched, text_encoder=text_encoders[0], tokenizer=tokenizers[0],
+                               text_encoder_2=text_encoders[1], tokenizer_2=tokenizers[1])
+    return pipe, tokenizers, text_encoders
+
+
+def update_size(i1, i2, anyres="any_11ratio", anchor_pixels=1024 * 1024):
+    """(new_h, new_w) for the edit from the (mean) size of up to two input images (cli.py:82-97)."""
+    from PIL import Image
+    shapes = []
+    for p in (i1, i2):
+        if p:
+            w, h = Image.open(p).size
+            shapes.append((w, h))
+    if not shapes:
+        return int(anchor_pixels ** 0.5), int(anchor_pixels ** 0.5)
+    if len(shapes) == 1:
+        w, h = shapes[0]
+    else:
+        w = sum(s[0] for s in shapes) / len(shapes)
+        h = sum(s[1] for s in shapes) / len(shapes)
+    return dynamic_resize(int(h), int(w), anyres, anchor_pixels=anchor_pixels)
+
+
+def prepare_condition_images(image_paths, device):
+    """float32 [-1,1] condition tensor [N,3,H,W] exactly as the reference builds it (cli.py:99-116)."""
+    from PIL import Image
+    if not image_paths:
+        return None
+    cond = []
+    for p in image_paths:
+        img = Image.open(p).convert("RGB")
+        t = torch.tensor(np.array(img), dtype=torch.float32) / 255.0
+        cond.append((t.permute(2, 0, 1) - 0.5) / 0.5)
+    return torch.stack(cond).to(device, dtype=torch.float32)
+
+
+def prepare_condition_pixels(image_paths):
+    """The same images as uint8 [N,H,W,3]: the pipeline then normalises / resizes / casts them in one HIP kernel
+    (bit-identical to the float route; tests/test_hip_pixels.py)."""
+    from PIL import Image
+    if not image_paths:
+        return None
+    arrs = [np.asarray(Image.open(p).convert("RGB"), dtype=np.uint8) for p in image_paths]
+    return torch.from_numpy(np.stack(arrs))
+
+
+def generate_image(pipe, prompt_embeds, pooled_prompt_embeds, history_image_paths, new_h, new_w, args, fused_pixels=True):
+    """The generation call of cli.py:236-248."""
+    cond = prepare_condition_pixels(history_image_paths) if fused_pixels else prepare_condition_images(history_image_paths, pipe.device)
+    return pipe(
+        image=cond,
+        prompt_embeds=prompt_embeds,
+        pooled_prompt_embeds=pooled_prompt_embeds,
+        height=new_h,
+        width=new_w,
+        num_inference_steps=args.num_inference_steps,
+        guidance_scale=args.guidance_scale,
+        generator=torch.Generator(device="cuda").manual_seed(seed),
+    ).images[0]
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description="Model and component paths")
+    parser.add_argument("--model_path", type=str, required=True)
+    parser.add_argument("--flux_path", type=str, required=True)
+    parser.add_argument("--no_auto_hw", action="store_true")
+    parser.add_argument("--height", type=int, default=1024)
+    parser.add_argument("--width", type=int, default=1024)
+    parser.add_argument("--num_inference_steps", type=int, default=28)
+    parser.add_argument("--guidance_scale", type=float, default=3.5)
+    parser.add_argument("--ocr_enhancer", action="store_true")
+    parser.add_argument("--no_joint_with_t5", action="store_true")
+    # additions of this front end
+    parser.add_argument("--prompt_embeds", type=str, default=None,
+                        help="torch-saved dict(prompt_embeds, pooled_prompt_embeds): skip the VLM / T5 / CLIP stage")
+    parser.add_argument("--images", type=str, default="", help="comma-separated condition images (with --prompt_embeds)")
+    parser.add_argument("--output", type=str, default=generate_image_temp.format(0))
+    return parser
+
+
+def main(args):
+    device = torch.device("cuda")
+    pipe, tokenizers, text_encoders = load_pipe(args.model_path, args.flux_path, device)
+    if args.prompt_embeds:
+        blob = torch.load(args.prompt_embeds, map_location="cpu", weights_only=True)
+        urls = [u.strip() for u in args.images.split(",") if u.strip()]
+        new_h, new_w = args.height, args.width
+        if urls and not args.no_auto_hw:
+            new_h, new_w = update_size(urls[0], urls[1] if len(urls) > 1 else None, "any_11ratio",
+                                       anchor_pixels=args.height * args.width)
+        img = generate_image(pipe, blob["prompt_embeds"], blob["pooled_prompt_embeds"], urls, new_h, new_w, args)
+        img.save(args.output)
+        print(f"Assistant: generate image at {args.output}")
+        return
+    try:  # the interactive loop needs the reference's VLM wrapper and prompt encoders (reused as-is)
+        from univa.serve import cli as ref_cli  # noqa: F401
+    except Exception as e:
+        raise SystemExit("the interactive chat needs the reference package (UnivaQwen2p5VLForConditionalGeneration, "
+                         f"encode_prompt) importable next to this one: {type(e).__name__}: {e}\n"
+                         "offline: pass --prompt_embeds FILE [--images a.png,b.png]")
+    # With the reference importable its own loop is used unchanged, with `load_pipe` swapped for this module's:
+    ref_cli.load_pipe = lambda denoiser, flux_path, dev: load_pipe(args.model_path, flux_path, dev)
+    ref_cli.main(args)
+
+
+if __name__ == "__main__":
+    main(build_parser().parse_args())

@@ -190,11 +190,17 @@ class HipAutoencoderKL(nn.Module):
         return SimpleNamespace(sample=img)
 
     @torch.no_grad()
-    def encode(self, x, return_dict=True, post_add=0.0, post_mul=1.0):
-        """image [B,3,H,W] (fp32 or bf16, in [-1,1]) -> latent distribution with [B,16,H/8,W/8] moments."""
+    def encode(self, x, return_dict=True, post_add=0.0, post_mul=1.0, nhwc=False):
+        """image [B,3,H,W] (fp32 or bf16, in [-1,1]) -> latent distribution with [B,16,H/8,W/8] moments.
+        ``nhwc=True``: x is already the internal layout, NHWC bf16 [B,H,W,32] (``image_processor.pixels_to_latent_input``)."""
         if not x.is_cuda:
             raise RuntimeError("HipAutoencoderKL needs GPU tensors: there is no CPU fallback")
-        t = ops.nchw_to_nhwc(x.contiguous(), 32)
+        if nhwc:
+            if x.dtype != BF16 or x.dim() != 4 or x.shape[3] != 32 or not x.is_contiguous():
+                raise ValueError("nhwc input must be contiguous bf16 [B, H, W, 32]")
+            t = x
+        else:
+            t = ops.nchw_to_nhwc(x.contiguous(), 32)
         t = self._conv("encoder.conv_in", t)
         n_down = len(self.config.block_out_channels)
         for i in range(n_down):

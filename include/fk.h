@@ -147,6 +147,10 @@ int fk_timestep_proj(const void* v, int32_t v_is_fp32, const float* freqs, void*
                      fk_stream_t stream);
 /* out = bf16(bf16(a + b) + c) over n elements: temb = (T + G) + P. */
 int fk_add3_bf16(const void* a, const void* b, const void* c, void* out, int64_t n, fk_stream_t stream);
+/* True classifier-free guidance, `noise_pred = neg + true_cfg_scale * (noise_pred - neg)`
+ * (univa/utils/flux_pipeline.py:1095): out = bf16(neg + bf16(scale * bf16(pos - neg))) over n elements
+ * (the python-float scale stays fp32, as on the GPU the reference runs on); out may alias pos or neg. */
+int fk_true_cfg_bf16(const void* pos, const void* neg, void* out, float scale, int64_t n, fk_stream_t stream);
 /* FlowMatchEulerDiscreteScheduler.step fused with the pipeline's `noise_pred[:, :S_tgt]` slice:
  *   x[b, s, :] = bf16(float(x) + float(bf16(bf16(dsigma) * v[b, s, :])))   for s < S_tgt
  * x rows at x + b*x_batch_stride + s*C, v rows at v + b*v_batch_stride + s*C.
@@ -197,6 +201,20 @@ int fk_nchw_to_nhwc_bf16(const void* src, int32_t src_is_fp32, void* dst, int32_
  * y = bf16(bf16(x + add) * mul)  (`(z - shift) * scaling` of flux_pipeline.py:611). */
 int fk_nhwc_to_nchw(const void* src, void* dst, int32_t dst_is_fp32, int32_t B, int32_t C, int32_t Cpad,
                     int32_t H, int32_t W, float add, float mul, fk_stream_t stream);
+
+/* Pixels in: uint8 NHWC [B, Hin, Win, 3] (PIL / numpy layout) -> NHWC bf16 [B, Hout, Wout, Cpad] (channels >= 3 zero),
+ * fusing the three host steps the reference runs in front of vae.encode:
+ *   `(img / 255 - 0.5) / 0.5` in fp32                    (univa/serve/cli.py:106-109),
+ *   VaeImageProcessor.resize on a tensor = F.interpolate(mode="nearest"): src = min(floor(dst * in/out), in - 1)
+ *   and VaeImageProcessor.preprocess, which normalises (2x - 1) once more iff the tensor has no negative value
+ *   (renorm != 0: the caller checks min(u8) >= 128)      (univa/utils/flux_pipeline.py:960-972),
+ *   `image.to(dtype)` = bf16                             (flux_pipeline.py prepare_latents). */
+int fk_pixels_u8_to_nhwc_bf16(const void* src, void* dst, int32_t B, int32_t Hin, int32_t Win, int32_t Hout,
+                              int32_t Wout, int32_t Cpad, int32_t renorm, fk_stream_t stream);
+/* Pixels out: decoder output NCHW (bf16 or fp32) -> uint8 NHWC, VaeImageProcessor.postprocess up to the PIL array
+ * (flux_pipeline.py:1130): clamp(x / 2 + 0.5, 0, 1) in the tensor dtype, then rint(float * 255). */
+int fk_image_to_u8_nhwc(const void* src, int32_t src_is_fp32, void* dst, int32_t B, int32_t C, int32_t H, int32_t W,
+                        fk_stream_t stream);
 
 const char* fk_last_error(void);
 /* Build identification: "fk <version> gfx950". */

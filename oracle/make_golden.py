@@ -9,6 +9,8 @@ G1-G3  the four pure helpers of the reference pipeline driver, executed from the
        module cannot be imported -- it needs diffusers) and exec'd with only ``torch`` in scope.
 G4     ``univa/utils/anyres_util.py`` imported normally from the reference tree.
 G5     torch's own CPU definitions of the building-block ops the HIP kernels implement.
+G7     ``prepare_condition_images`` and ``update_size`` of ``univa/serve/cli.py`` (:82-116), lifted with ``ast`` like
+       G1-G3 (the module imports diffusers/flash-attn models) and executed on PNG files written here.
 G6     end-to-end outputs of THIS repo's oracle on tiny configs (self-pinned, labelled as such;
        guards the oracle against accidental edits -- it is not evidence about diffusers).
 
@@ -63,6 +65,47 @@ def g_helpers():
     out["shift_mu_custom"] = np.array(
         [ns["calculate_shift"](int(s), 256, 4096, 0.5, 1.16) for s in seqs], dtype=np.float64)
     np.savez(os.path.join(OUT, "helpers.npz"), **out)
+
+
+def g_cli():
+    import tempfile
+
+    from PIL import Image
+    sys.path.insert(0, REF)
+    from univa.utils.anyres_util import dynamic_resize  # the lifted functions' only non-stdlib dependency
+    src = open(os.path.join(REF, "univa/serve/cli.py")).read()
+    wanted = {"prepare_condition_images", "update_size"}
+    ns = {"torch": torch, "np": np, "Image": Image, "dynamic_resize": dynamic_resize}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name in wanted:
+            exec(compile(ast.Module(body=[node], type_ignores=[]), "<reference>", "exec"), ns)
+    assert wanted <= set(ns)
+    rng = np.random.default_rng(77)
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        imgs = rng.integers(0, 256, size=(2, 12, 20, 3), dtype=np.uint8)
+        paths = []
+        for i, a in enumerate(imgs):
+            fn = os.path.join(d, f"c{i}.png")
+            Image.fromarray(a).save(fn)
+            paths.append(fn)
+        out["cond_u8"] = imgs
+        out["cond_f32"] = ns["prepare_condition_images"](paths, "cpu").numpy()
+        # update_size(i1, i2, anyres, anchor_pixels): (h, w) for 0 / 1 / 2 images
+        sizes = [(333, 500), (1024, 768)]       # (w, h) of the two files
+        spaths = []
+        for i, (w, h) in enumerate(sizes):
+            fn = os.path.join(d, f"s{i}.png")
+            Image.fromarray(np.zeros((h, w, 3), dtype=np.uint8)).save(fn)
+            spaths.append(fn)
+        rows = []
+        for anchor in (512 * 512, 1024 * 1024):
+            rows.append([0, anchor, *ns["update_size"](None, None, "any_11ratio", anchor)])
+            rows.append([1, anchor, *ns["update_size"](spaths[0], None, "any_11ratio", anchor)])
+            rows.append([2, anchor, *ns["update_size"](spaths[0], spaths[1], "any_11ratio", anchor)])
+        out["update_size_wh"] = np.array(sizes, dtype=np.int64)
+        out["update_size_rows"] = np.array(rows, dtype=np.int64)   # n_images, anchor, new_h, new_w
+    np.savez(os.path.join(OUT, "cli.npz"), **out)
 
 
 def g_anyres():
@@ -152,6 +195,7 @@ if __name__ == "__main__":
     torch.set_num_threads(1)  # deterministic reductions for the committed numbers
     g_helpers()
     g_anyres()
+    g_cli()
     g_torch_ops()
     g_oracle_selfpin()
     for f in sorted(os.listdir(OUT)):

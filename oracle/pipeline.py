@@ -12,7 +12,8 @@ from . import helpers, mmdit, scheduler, vae
 
 
 def kontext_edit(sd_flux, sd_vae, cond_image, prompt_embeds, pooled, noise, height, width,
-                 num_inference_steps=28, guidance_scale=3.5, flux_config=None, decode=True):
+                 num_inference_steps=28, guidance_scale=3.5, flux_config=None, decode=True,
+                 negative_prompt_embeds=None, negative_pooled=None, true_cfg_scale=1.0):
     """cond_image [B,3,Hc,Wc] in [-1,1] (already at its final size); noise [B,16,height/8,width/8].
 
     Returns dict(latents=[B,S_tgt,64], image=[B,3,height,width] or None, per_step=[...]).
@@ -41,6 +42,11 @@ def kontext_edit(sd_flux, sd_vae, cond_image, prompt_embeds, pooled, noise, heig
         v = mmdit.flux_forward(sd_flux, model_in, prompt_embeds, pooled, timestep / 1000, ids, txt_ids, guidance,
                                config=flux_config)
         v = v[:, :S_tgt]
+        if true_cfg_scale > 1 and negative_prompt_embeds is not None and negative_pooled is not None:  # :928, :1080-1095
+            neg_txt_ids = torch.zeros(negative_prompt_embeds.shape[1], 3, dtype=dtype)
+            vn = mmdit.flux_forward(sd_flux, model_in, negative_prompt_embeds, negative_pooled, timestep / 1000, ids,
+                                    neg_txt_ids, guidance, config=flux_config)[:, :S_tgt]
+            v = vn + vae._scalar_op(v - vn, "mul", true_cfg_scale)
         latents = scheduler.euler_step(v, sigmas[i], sigmas[i + 1], latents)
         per_step.append(latents)
     image = None

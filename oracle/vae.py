@@ -116,3 +116,18 @@ def postprocess_uint8(image):
     x = (image / 2 + 0.5).clamp(0, 1)
     x = x.cpu().permute(0, 2, 3, 1).float().numpy()
     return (x * 255).round().astype("uint8")
+
+
+def preprocess_uint8(u8_nhwc, out_h, out_w):
+    """uint8 [N,H,W,3] pixels -> the bf16 NCHW tensor the reference hands to vae.encode:
+    ``cli.prepare_condition_images`` (univa/serve/cli.py:99-116: ``/255``, ``(x-0.5)/0.5`` in fp32), then the pipeline's
+    ``image_processor.resize`` (tensor => ``F.interpolate`` nearest) and ``preprocess`` (``2x-1`` iff nothing is negative;
+    univa/utils/flux_pipeline.py:960-972), then ``image.to(dtype)`` in prepare_latents."""
+    x = u8_nhwc.to(torch.float32) / 255.0
+    x = x.permute(0, 3, 1, 2)
+    x = (x - 0.5) / 0.5
+    if tuple(x.shape[2:]) != (out_h, out_w):
+        x = F.interpolate(x, size=(out_h, out_w))
+    if x.min() >= 0:
+        x = 2.0 * x - 1.0
+    return x.to(torch.bfloat16)

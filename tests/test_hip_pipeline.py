@@ -93,3 +93,51 @@ def test_full_size_properties():
     a = x.clone(); ops.euler_step(a, v, 1024, -0.0625)
     b = x.clone(); ops.euler_step(b, v, 1024, -0.03125); ops.euler_step(b, v, 1024, -0.03125)
     assert (a.float() - b.float()).abs().max().item() <= 2 ** -6 * (1 + x.float().abs().max().item())
+
+
+def test_true_cfg_matches_oracle_and_two_pass():
+    """true_cfg_scale > 1 with negative embeddings (flux_pipeline.py:928,1080-1095): the HIP pipeline runs the
+    positive and negative pass as one batch of 2B + the fused combine kernel; the oracle runs the reference's two
+    separate calls."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd import flux_spec, ops
+    from gpt_image_edit_amd.pipeline import FluxKontextPipeline
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    from gpt_image_edit_amd.vae import HipAutoencoderKL
+    from oracle import pipeline as opipe
+
+    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=1, num_single_layers=1)
+    sd_f = {k: v.to(BF) for k, v in flux_spec.synthetic_state(flux_spec.flux_param_shapes(cfg), seed=41).items()}
+    sd_v = {k: v.to(BF) for k, v in flux_spec.synthetic_state(flux_spec.vae_param_shapes(), seed=42).items()}
+    tr = HipFluxTransformer2DModel(cfg, device="cuda"); tr.load_state_dict(sd_f)
+    vae = HipAutoencoderKL(device="cuda"); vae.load_state_dict(sd_v)
+    pipe = FluxKontextPipeline(tr, vae)
+    g = torch.Generator().manual_seed(17)
+    B, H, W = 1, 64, 64
+    cond = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    emb, nemb = torch.randn(B, 24, 4096, generator=g).to(BF), torch.randn(B, 24, 4096, generator=g).to(BF)
+    pooled, npooled = torch.randn(B, 768, generator=g).to(BF), torch.randn(B, 768, generator=g).to(BF)
+    noise = torch.randn(B, 16, H // 8, W // 8, generator=g).to(BF)
+    kw = dict(image=cond.cuda(), prompt_embeds=emb.cuda(), pooled_prompt_embeds=pooled.cuda(), height=H, width=W,
+              num_inference_steps=2, guidance_scale=4.0, latents=pipe._pack_latents(noise, B, 16, H // 8, W // 8).cuda(),
+              output_type="latent", max_area=H * W, _auto_resize=False)
+    out = pipe(negative_prompt_embeds=nemb.cuda(), negative_pooled_prompt_embeds=npooled.cuda(), true_cfg_scale=2.5, **kw)
+    plain = pipe(**kw)
+    assert not torch.equal(out.latents, plain.latents), "true CFG had no effect"
+    # scale <= 1 or missing negatives: the reference's do_true_cfg is False
+    same = pipe(negative_prompt_embeds=nemb.cuda(), negative_pooled_prompt_embeds=npooled.cuda(), true_cfg_scale=1.0, **kw)
+    assert torch.equal(same.latents, plain.latents)
+    ref = opipe.kontext_edit(sd_f, sd_v, cond, emb, pooled, noise, H, W, num_inference_steps=2, guidance_scale=4.0,
+                             flux_config=cfg, decode=False, negative_prompt_embeds=nemb, negative_pooled=npooled,
+                             true_cfg_scale=2.5)
+    f32 = lambda d: {k: v.float() for k, v in d.items()}  # noqa: E731
+    ref32 = opipe.kontext_edit(f32(sd_f), f32(sd_v), cond.to(BF).float(), emb.float(), pooled.float(), noise.float(), H, W,
+                               num_inference_steps=2, guidance_scale=4.0, flux_config=cfg, decode=False,
+                               negative_prompt_embeds=nemb.float(), negative_pooled=npooled.float(), true_cfg_scale=2.5)
+    d32 = report("true-CFG latents vs fp32-oracle", out.latents, ref32["latents"])
+    floor = report("true-CFG latents bf16-oracle vs fp32-oracle (floor)", ref["latents"], ref32["latents"])
+    assert d32.max().item() <= max(2.5 * floor.max().item(), 3e-2 * ref32["latents"].abs().max().item())
+    # the combine kernel alone, bit-exact against the torch expression on the GPU
+    a, b = torch.randn(4, 1024, 64, generator=g).to(BF).cuda(), torch.randn(4, 1024, 64, generator=g).to(BF).cuda()
+    assert torch.equal(ops.true_cfg(a, b, 2.5), b + 2.5 * (a - b))

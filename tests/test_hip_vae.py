@@ -143,3 +143,19 @@ def test_vae_encode_matches_oracle():
     scale = ref32.abs().max().item()
     assert d32.max().item() <= max(2.0 * floor.max().item(), 2e-2 * scale)
     assert d32.mean().item() <= max(2.0 * floor.mean().item(), 2e-3 * scale)
+
+
+def test_vae_is_deterministic_at_ragged_sizes():
+    """Same input, same bits: GroupNorm statistics are merged in a fixed order (no float atomics), also when the
+    pixel count does not divide the block / tile sizes (48 x 80 image -> 6 x 10 latent)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd.vae import HipAutoencoderKL
+    vae = HipAutoencoderKL(device="cuda", init="synthetic", seed=32)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(2, 3, 48, 80, generator=g) * 2 - 1).cuda()
+    z = [vae.encode(x).latent_dist.mode().clone() for _ in range(4)]
+    assert all(torch.equal(z[0], t) for t in z[1:])
+    lat = torch.randn(2, 16, 6, 10, generator=g).to(torch.bfloat16).cuda()
+    im = [vae.decode(lat, return_dict=False)[0].clone() for _ in range(4)]
+    assert all(torch.equal(im[0], t) for t in im[1:])

@@ -179,3 +179,44 @@ def test_param_layout_matches_checkpoint_names():
     a = flux_spec.synthetic_state({"x.weight": (4, 4), "x.bias": (4,)}, seed=1)
     b = flux_spec.synthetic_state({"x.bias": (4,), "x.weight": (4, 4)}, seed=1)
     assert torch.equal(a["x.weight"], b["x.weight"]) and torch.equal(a["x.bias"], b["x.bias"])
+
+
+# ---- G7: the reference cli's own pixel / size helpers (univa/serve/cli.py:82-116), executed by make_golden.py ------
+def _write_pngs(tmp_path, arrays, prefix):
+    from PIL import Image
+    paths = []
+    for i, a in enumerate(arrays):
+        fn = str(tmp_path / f"{prefix}{i}.png")
+        Image.fromarray(a).save(fn)
+        paths.append(fn)
+    return paths
+
+
+def test_cli_prepare_condition_images_matches_reference(golden_dir, tmp_path):
+    from gpt_image_edit_amd.serve import cli
+    from oracle import vae as ovae
+    g = _load(golden_dir, "cli.npz")
+    u8, want = g["cond_u8"], torch.from_numpy(g["cond_f32"])
+    got = cli.prepare_condition_images(_write_pngs(tmp_path, u8, "c"), "cpu")
+    assert got.dtype == torch.float32 and torch.equal(got, want)
+    px = cli.prepare_condition_pixels(_write_pngs(tmp_path, u8, "d"))
+    assert px.dtype == torch.uint8 and np.array_equal(px.numpy(), u8)
+    # the oracle's restatement of the whole float route, at native size: same numbers, rounded to bf16
+    assert torch.equal(ovae.preprocess_uint8(torch.from_numpy(u8), 12, 20), want.to(torch.bfloat16))
+
+
+def test_cli_update_size_matches_reference(golden_dir, tmp_path):
+    from gpt_image_edit_amd.serve import cli
+    g = _load(golden_dir, "cli.npz")
+    files = _write_pngs(tmp_path, [np.zeros((h, w, 3), dtype=np.uint8) for w, h in g["update_size_wh"]], "s")
+    for n, anchor, nh, nw in g["update_size_rows"]:
+        args = [None, None] if n == 0 else ([files[0], None] if n == 1 else files)
+        assert cli.update_size(args[0], args[1], "any_11ratio", int(anchor)) == (nh, nw)
+
+
+def test_cli_flags_match_reference_defaults():
+    """univa/serve/cli.py:271-283"""
+    from gpt_image_edit_amd.serve import cli
+    a = cli.build_parser().parse_args(["--model_path", "m", "--flux_path", "f"])
+    assert (a.height, a.width, a.num_inference_steps, a.guidance_scale) == (1024, 1024, 28, 3.5)
+    assert not (a.no_auto_hw or a.ocr_enhancer or a.no_joint_with_t5)
