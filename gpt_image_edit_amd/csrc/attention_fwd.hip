@@ -257,6 +257,9 @@ int launch(const AttnParams& p, hipStream_t stream) {
 
 }  // namespace
 
+int fk_attention4_launch(const void* q, const void* k, const void* v, void* o, int B, int H, int S, int64_t v_ld,
+                         int64_t v_bs, int64_t o_ld, int64_t o_bs, float scale, hipStream_t stream);  // attention4_fwd.hip
+
 extern "C" int fk_attention_fwd_bf16(const void* q, const void* k, const void* v, void* o, int32_t B,
                                      int32_t H, int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld,
                                      int64_t o_batch_stride, float scale, fk_stream_t stream_) {
@@ -276,6 +279,8 @@ extern "C" int fk_attention_fwd_bf16(const void* q, const void* k, const void* v
     const char* e = getenv("FK_ATTN_VARIANT");
     variant = e ? atoi(e) : 8;
   }
+  if (variant == 44)
+    return fk_attention4_launch(q, k, v, o, B, H, S, v_ld, v_batch_stride, o_ld, o_batch_stride, scale, (hipStream_t)stream_);
   if (variant == 4) return launch<4, 2>(p, (hipStream_t)stream_);
   return launch<8, 3>(p, (hipStream_t)stream_);
 }

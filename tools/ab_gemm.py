@@ -12,6 +12,10 @@ SHAPES = [(2560, 9216, 3072, 0), (2560, 3072, 15360, 3), (2560, 12288, 3072, 1),
           (8704, 12288, 3072, 1)]
 
 
+if os.environ.get("FK_AB_SHAPES"):   # "M,N,K,epi;M,N,K,epi;..."
+    SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["FK_AB_SHAPES"].split(";")]
+
+
 def child(tag):
     sys.path.insert(0, ROOT)
     from gpt_image_edit_amd import ops
