@@ -235,6 +235,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
   }
 }
 
+// One-wave-per-SIMD schedules (experimental/attention4_fwd.hip: two query blocks per wave half a tile apart;
+// experimental/attention5_fwd.hip: one block, softmax of tile u+1 under the MFMAs of tile u; both with a fixed
+// exponent reference instead of the running rescale, padded LDS rows and register staging) are correct but slower
+// (630-830 and 540-660 TF/s against 790-1060 here): the softmax costs >= 4 VALU instructions per score element,
+// i.e. 7-8 issue slots per MFMA once S read-out, LDS reads and staging are added, more than the 5 that fit an MFMA
+// shadow -- with two waves per SIMD the hardware overlaps one wave's VALU with the other's MFMAs at no issue cost.
+// Not built; kept as a starting point for a hand-allocated version.
+//
 // Measured dead ends (kept out of the tree, see git history): (1) issuing QK^T of tile t+1 before the softmax
 // of tile t inside one wave (register pressure -> spills, compiler does not interleave: 760 TF vs 844);
 // (2) rotating waves 4..7 by one phase so that softmax of one wave meets MFMA of its SIMD partner
@@ -257,9 +265,6 @@ int launch(const AttnParams& p, hipStream_t stream) {
 
 }  // namespace
 
-int fk_attention4_launch(const void* q, const void* k, const void* v, void* o, int B, int H, int S, int64_t v_ld,
-                         int64_t v_bs, int64_t o_ld, int64_t o_bs, float scale, hipStream_t stream);  // attention4_fwd.hip
-
 extern "C" int fk_attention_fwd_bf16(const void* q, const void* k, const void* v, void* o, int32_t B,
                                      int32_t H, int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld,
                                      int64_t o_batch_stride, float scale, fk_stream_t stream_) {
@@ -279,8 +284,6 @@ extern "C" int fk_attention_fwd_bf16(const void* q, const void* k, const void* v
     const char* e = getenv("FK_ATTN_VARIANT");
     variant = e ? atoi(e) : 8;
   }
-  if (variant == 44)
-    return fk_attention4_launch(q, k, v, o, B, H, S, v_ld, v_batch_stride, o_ld, o_batch_stride, scale, (hipStream_t)stream_);
   if (variant == 4) return launch<4, 2>(p, (hipStream_t)stream_);
   return launch<8, 3>(p, (hipStream_t)stream_);
 }
