@@ -47,8 +47,14 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
-FK_DEV void glds16(const bf16_t* src, char* lds_dst) {
-  __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_dst, 16, 0, 0);
+// buffer form of the LDS-DMA load (descriptor in SGPRs, one 32-bit offset VGPR, SGPR tile offset).  The builtin
+// exists for the device target only; seen by the host pass it silently suppresses the kernel's host stub.
+FK_DEV void buffer_lds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 16, voffset, soffset, 0, 0);
+#else
+  (void)rsrc; (void)lds_dst; (void)voffset; (void)soffset;
+#endif
 }
 FK_DEV s16x4_t lds_tr16(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
@@ -101,15 +107,26 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
 
   // ---- LDS-DMA pieces: one instruction = 4 key rows x 256 B; lane -> (row = lane/16, 16-byte slot = lane%16)
   const int prow = lane >> 4, pslot = lane & 15;
+  // Buffer form of the LDS-DMA load: descriptor in SGPRs, ONE 32-bit offset VGPR per piece (constant over the
+  // tiles), the tile offset in an SGPR.  Rows >= S lie beyond num_records and are fetched as zeros (they are masked).
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, p.S * HD * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v =
+      __builtin_amdgcn_make_buffer_rsrc((void*)Vg, 0, (int)(((int64_t)(p.S - 1) * p.v_ld + HD) * 2), 0x00020000);
+  int k_voff[KL], v_voff[KL];
+#pragma unroll
+  for (int i = 0; i < KL; ++i) {
+    const int r = (wave * KL + i) * 4 + prow;                       // key row inside the tile
+    k_voff[i] = (r * HD + ((pslot ^ (r & 15)) << 3)) * 2;
+    const int vcol = ((((pslot >> 2) ^ (r & 3)) << 5) + ((pslot & 3) << 3));
+    v_voff[i] = (int)((r * p.v_ld + vcol) * 2);
+  }
+  const int k_tile_bytes = KVBLK * HD * 2, v_tile_bytes = (int)(KVBLK * p.v_ld * 2);
   auto issue_tile = [&](int kt, int stage) {
     char* sb = smem + stage * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < KL; ++i) {
-      const int r = (wave * KL + i) * 4 + prow;                     // key row inside the tile
-      const int key = min(kt * KVBLK + r, p.S - 1);                 // clamp: rows >= S are masked / weightless
-      glds16(Kg + (int64_t)key * HD + ((pslot ^ (r & 15)) << 3), sb + (wave * KL + i) * 1024);
-      const int vcol = ((((pslot >> 2) ^ (r & 3)) << 5) + ((pslot & 3) << 3));
-      glds16(Vg + (int64_t)key * p.v_ld + vcol, sb + K_TILE_BYTES + (wave * KL + i) * 1024);
+      buffer_lds16(rs_k, sb + (wave * KL + i) * 1024, k_voff[i], kt * k_tile_bytes);
+      buffer_lds16(rs_v, sb + K_TILE_BYTES + (wave * KL + i) * 1024, v_voff[i], kt * v_tile_bytes);
     }
   };
 
@@ -122,101 +139,191 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
   const int v_rd = K_TILE_BYTES + (4 * hh + tj) * 256 + tdh * 32 + tq * 8;  // + (16 st + 8 part)*256 + ((df ^ tj) << 6)
 
   f32x16_t o[4];
-#pragma unroll
-  for (int df = 0; df < 4; ++df)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[df][r] = 0.f;
-  float m_run = -1.0e30f, l_run = 0.f;
+  // Exponent reference.  The textbook online softmax rescales O by exp(m_old - m_new) on every tile (64 multiplies
+  // per wave and tile, on the critical VALU path: the counters show this kernel's MFMA and VALU phases added, not
+  // overlapped).  Here every row keeps a FIXED reference m_ref = its row maximum over the FIRST KV tile, so
+  // p = exp2(s - m_ref) may exceed 1 when later tiles hold larger scores -- harmless for the fp32 sums and for the
+  // bf16 P fragments (same relative precision) while the excess stays below 2^TAU.  If some row ever outgrows its
+  // reference by more than TAU (adversarial inputs; the tests build one) the workgroup finishes the pass and
+  // repeats it with the exact row maxima from a K-only pre-pass: the result is then the plain two-pass softmax.
+  constexpr float TAU = 40.0f;   // log2 units: p <= 2^40, row sums <= 2^55 for 32768 keys
+  float m_ref = 0.f, l_run = 0.f;
+  bool overflow = false;         // wave-uniform
 
   const int nkt = (p.S + KVBLK - 1) / KVBLK;
-#pragma unroll
-  for (int s = 0; s < PF; ++s)
-    if (s < nkt) issue_tile(s, s);
   int st_cur = 0, st_pf = PF;
-
-  // one KV tile; MASK = the tile holds keys >= S (only ever the last tile): compiled as a separate copy so
-  // the steady-state loop carries no select instructions
-  auto do_tile = [&](int kt, auto mask_tag) {
-    constexpr bool MASK = decltype(mask_tag)::value;
+  auto fill = [&]() {
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+      if (s < nkt) issue_tile(s, s);
+    st_cur = 0;
+    st_pf = PF;
+  };
+  // ring bookkeeping shared by the main loop and the pre-pass: wait for tile kt, publish it, request tile kt+PF
+  auto acquire_tile = [&](int kt) {
     if (kt + PF - 1 < nkt) wait_vmcnt<(PF - 1) * LOADS>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (kt + PF < nkt) issue_tile(kt + PF, st_pf);
-    const char* sb = smem + st_cur * STAGE_BYTES;
-
-    // ---- S^T = K Q^T for the two 32-key blocks -------------------------------------------------------
-    f32x16_t s[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        const bf16x8_t kf = *(const bf16x8_t*)(sb + k_rd + kb * 8192 + (((2 * kk + hh) ^ k_sw) << 4));
-        // first k-step takes a literal zero C operand (inline constant): no per-tile re-zeroing of 32 registers
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], kk == 0 ? f32x16_t{} : s[kb], 0, 0, 0);
-      }
-    }
-    if constexpr (MASK) {
-      const int kbase = kt * KVBLK + 4 * hh;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kbase + 32 * kb + (r & 3) + 8 * (r >> 2);
-          if (key >= p.S) s[kb][r] = -1.0e30f;
-        }
-    }
-    // ---- online softmax (log2 domain; raw v_exp_f32: arguments are <= 0, denormal results may flush) ----
-    float mx = s[0][0];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx * p.scale_log2);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2, -m_new));
-        s[kb][r] = pv;
-        psum += pv;
-      }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int df = 0; df < 4; ++df)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[df][r] *= alpha;   // (a conditional skip costs 32 v_mov_b64 of phi copies: worse)
-
-    // ---- O^T += V^T P^T --------------------------------------------------------------------------------
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      const int kb = st >> 1, r0 = 8 * (st & 1);
-      u32x4_t pw;
-      pw[0] = pack_bf2(s[kb][r0 + 0], s[kb][r0 + 1]);
-      pw[1] = pack_bf2(s[kb][r0 + 2], s[kb][r0 + 3]);
-      pw[2] = pack_bf2(s[kb][r0 + 4], s[kb][r0 + 5]);
-      pw[3] = pack_bf2(s[kb][r0 + 6], s[kb][r0 + 7]);
-      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
-#pragma unroll
-      for (int df = 0; df < 4; ++df) {
-        const char* vp = sb + v_rd + st * 4096 + ((df ^ tj) << 6);
-        const s16x4_t lo = lds_tr16(vp);          // keys 16 st + 4 hh + 0..3
-        const s16x4_t hi = lds_tr16(vp + 2048);   // keys 16 st + 8 + 4 hh + 0..3
-        bf16x8_t vf;
-        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-        o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[df], 0, 0, 0);
-      }
-    }
+    return smem + st_cur * STAGE_BYTES;
+  };
+  auto release_tile = [&]() {
     st_cur = (st_cur == STAGES - 1) ? 0 : st_cur + 1;
     st_pf = (st_pf == STAGES - 1) ? 0 : st_pf + 1;
   };
-  for (int kt = 0; kt < nkt - 1; ++kt) do_tile(kt, std::false_type{});
-  if (p.S % KVBLK != 0) do_tile(nkt - 1, std::true_type{});
-  else do_tile(nkt - 1, std::false_type{});
+  // Operand fragments.  The reads are issued PF_DEPTH MFMAs ahead of their use and the order is pinned
+  // (sched_group_barrier: one DS read, then one MFMA): left alone, hipcc issues every ds_read right in front of
+  // its MFMA and the wave waits for an LDS round trip 32 times per tile.
+  auto k_frag = [&](const char* sb, int kb, int kk) {
+    return *(const bf16x8_t*)(sb + k_rd + kb * 8192 + (((2 * kk + hh) ^ k_sw) << 4));
+  };
+  auto v_frag = [&](const char* sb, int st, int df) {   // keys 16 st + {0, 8} + 4 hh + 0..3, d block df
+    const char* vp = sb + v_rd + st * 4096 + ((df ^ tj) << 6);
+    const s16x4_t lo = lds_tr16(vp);
+    const s16x4_t hi = lds_tr16(vp + 2048);
+    bf16x8_t vf;
+    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+    return vf;
+  };
+  // S^T block kb (32 keys x 32 queries) of the tile at sb, masked beyond S in the ragged last tile
+  auto scores = [&](const char* sb, int kb, int kt, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    f32x16_t s;
+    bf16x8_t kf[3];
+    kf[0] = k_frag(sb, kb, 0);
+    kf[1] = k_frag(sb, kb, 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // the two leading reads
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      if (kk + 2 < 8) kf[(kk + 2) % 3] = k_frag(sb, kb, kk + 2);
+      // first k-step takes a literal zero C operand (inline constant): no per-tile re-zeroing of the accumulator
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk % 3], qf[kk], kk == 0 ? f32x16_t{} : s, 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the DS read of this slot first ...
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // ... then its MFMA
+    }
+    if constexpr (MASK) {
+      const int kbase = kt * KVBLK + 32 * kb + 4 * hh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kbase + (r & 3) + 8 * (r >> 2) >= p.S) s[r] = -1.0e30f;
+    }
+    return s;
+  };
+  auto block_max = [&](const f32x16_t& s) {   // row maximum over one 32-key block, in log2 units
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    return fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2;
+  };
+
+  // One KV tile = two 32-key halves, each: 8 QK MFMAs -> exp2 (fixed reference: no dependence on the tile's
+  // maximum) -> pack -> 8 PV MFMAs.  Only one 32 x 32 score block is live at a time.
+  // MASK = the tile holds keys >= S (only ever the last tile), FIRST = tile 0 of the first attempt (sets the
+  // exponent reference): compiled as separate copies so the steady-state loop carries no selects.
+  auto do_tile = [&](int kt, auto mask_tag, auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const char* sb = acquire_tile(kt);
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16_t s = scores(sb, kb, kt, mask_tag);
+      const float mx = block_max(s);
+      if constexpr (FIRST) {
+        if (kb == 0) m_ref = mx;   // reference = row maximum over the first 32 keys
+        else overflow = overflow || (__builtin_amdgcn_ballot_w64(mx > m_ref + TAU) != 0);
+      } else {
+        overflow = overflow || (__builtin_amdgcn_ballot_w64(mx > m_ref + TAU) != 0);
+      }
+      const float nm = -m_ref;
+      // ---- softmax numerators (log2 domain; raw v_exp_f32, denormal results may flush) ----------------------
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, nm));
+        s[r] = pv;
+        psum += pv;
+      }
+      // ---- O^T += V^T P^T for the two 16-key steps of this half ------------------------------------------------
+      bf16x8_t vf[3];
+      vf[0] = v_frag(sb, 2 * kb, 0);
+      vf[1] = v_frag(sb, 2 * kb, 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the leading reads (two transpose reads per fragment)
+      bf16x8_t pf;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int st = 2 * kb + (i >> 2), df = i & 3;
+        if (df == 0) {
+          const int r0 = 8 * (i >> 2);
+          u32x4_t pw;
+          pw[0] = pack_bf2(s[r0 + 0], s[r0 + 1]);
+          pw[1] = pack_bf2(s[r0 + 2], s[r0 + 3]);
+          pw[2] = pack_bf2(s[r0 + 4], s[r0 + 5]);
+          pw[3] = pack_bf2(s[r0 + 6], s[r0 + 7]);
+          pf = __builtin_bit_cast(bf16x8_t, pw);
+        }
+        if (i + 2 < 8) vf[(i + 2) % 3] = v_frag(sb, 2 * kb + ((i + 2) >> 2), (i + 2) & 3);
+        o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % 3], pf, o[df], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the two transpose reads of this slot first ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // ... then its MFMA
+      }
+    }
+    l_run += psum;
+    release_tile();
+  };
+
+  using TT = std::true_type;
+  using FF = std::false_type;
+  const bool ragged = p.S % KVBLK != 0;
+  int* const wg_flag = (int*)(smem + STAGES * STAGE_BYTES);   // one word past the ring (allocated by the launcher)
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (attempt == 1) {
+      // exact row maxima: K-only pre-pass over all tiles (V rides along in the ring)
+      fill();
+      m_ref = -3.0e38f;
+      for (int kt = 0; kt < nkt; ++kt) {
+        const char* sb = acquire_tile(kt);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          if (ragged && kt == nkt - 1) m_ref = fmaxf(m_ref, block_max(scores(sb, kb, kt, TT{})));
+          else m_ref = fmaxf(m_ref, block_max(scores(sb, kb, kt, FF{})));
+        }
+        release_tile();
+      }
+      __syncthreads();   // every wave is done with the ring before it is refilled
+    }
+    fill();
+    l_run = 0.f;
+    overflow = false;
+#pragma unroll
+    for (int df = 0; df < 4; ++df)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[df][r] = 0.f;
+    if (attempt == 0) {
+      if (nkt == 1) {
+        if (ragged) do_tile(0, TT{}, TT{});
+        else do_tile(0, FF{}, TT{});
+      } else {
+        do_tile(0, FF{}, TT{});
+      }
+    } else {
+      if (nkt == 1 && ragged) do_tile(0, TT{}, FF{});
+      else do_tile(0, FF{}, FF{});
+    }
+    for (int kt = 1; kt < nkt - 1; ++kt) do_tile(kt, FF{}, FF{});
+    if (nkt > 1) {
+      if (ragged) do_tile(nkt - 1, TT{}, FF{});
+      else do_tile(nkt - 1, FF{}, FF{});
+    }
+    // the waves share the K/V ring and its barriers: they repeat the pass together or not at all
+    if (attempt == 0) {
+      __syncthreads();
+      if (tid == 0) *wg_flag = 0;
+      __syncthreads();
+      if (overflow && lane == 0) atomicOr(wg_flag, 1);
+      __syncthreads();
+      if (*wg_flag == 0) break;
+    }
+  }
 
   // ---- finalize: O = O^T / l ; lane (q = ql) holds d = 32 df + 8 (r>>2) + 4 hh + (r&3) ---------------
   const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -250,7 +357,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
 
 template <int NW, int STAGES>
 int launch(const AttnParams& p, hipStream_t stream) {
-  constexpr int SMEM = STAGES * STAGE_BYTES;
+  constexpr int SMEM = STAGES * STAGE_BYTES + 16;   // ring + the restart flag word
   auto kern = attention_fwd_kernel<NW, STAGES>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -279,11 +386,5 @@ extern "C" int fk_attention_fwd_bf16(const void* q, const void* k, const void* v
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o;
   p.B = B; p.H = H; p.S = S; p.v_ld = v_ld; p.v_bs = v_batch_stride; p.o_ld = o_ld; p.o_bs = o_batch_stride;
   p.scale_log2 = scale * 1.4426950408889634f;
-  static int variant = -1;  // FK_ATTN_VARIANT=4 -> 4-wave blocks (2 per CU, 2 stages); default 8 waves, 3 stages
-  if (variant < 0) {
-    const char* e = getenv("FK_ATTN_VARIANT");
-    variant = e ? atoi(e) : 8;
-  }
-  if (variant == 4) return launch<4, 2>(p, (hipStream_t)stream_);
   return launch<8, 3>(p, (hipStream_t)stream_);
 }

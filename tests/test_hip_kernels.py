@@ -315,3 +315,25 @@ def test_small_kernels(ops):
         s = torch.randn(5, n, generator=torch.Generator().manual_seed(n)) * 4
         got = ops.softmax_rows(s.cuda())
         assert_bf16_close(f"softmax n={n}", got, torch.softmax(s, -1).to(BF), max_ulp=1, max_bad_frac=1e-3)
+
+
+def test_attention_restart_on_late_large_logit(ops):
+    """The kernel keeps a fixed exponent reference per row (row max of the first KV tile) and repeats the pass with
+    exact row maxima when a later tile outgrows it by > 2^40: build exactly that case and compare with fp32 SDPA."""
+    B, H, S = 1, 2, 640
+    g = torch.Generator().manual_seed(77)
+    q = torch.randn(B, H, S, 128, generator=g).to(BF)
+    k = torch.randn(B, H, S, 128, generator=g).to(BF)
+    qkv = torch.randn(B, S, 3 * H * 128, generator=g).to(BF)
+    k[0, 0, 600] = q[0, 0, 5] * 6.0          # logit ~ 6 * |q|^2 / sqrt(128) ~ 68 nats ~ 98 log2 units, in the last tile
+    k[0, 1, 321] = q[0, 1, 400] * 5.0
+    v = qkv[:, :, 2 * H * 128:].reshape(B, S, H, 128).transpose(1, 2)
+    out = torch.empty(B, S, H * 128, device="cuda", dtype=BF)
+    ops.attention(q.cuda(), k.cuda(), qkv.cuda()[:, :, 2 * H * 128:], out)
+    ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())
+    ref = ref.transpose(1, 2).reshape(B, S, H * 128)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= 3e-2 * ref.abs().max().item()
+    # the hit rows copy (almost exactly) one V row
+    assert (got[0, 5, :128] - v[0, 0, 600].float()).abs().max().item() <= 2e-2 * v.abs().max().item()
