@@ -59,6 +59,8 @@ FK_DEV int64_t fk_row_offset(const fk_rows& r, int64_t m) {
   return b * r.batch_stride + (m - b * r.rows_per_batch) * r.ld;
 }
 
+// internal: returned by fk_gemm2_launch when a 256-row tile's rows are not addressable with 32-bit byte offsets
+constexpr int FK_E2BIG_STRIDES = -100;
 int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t stream);  // gemm2_bf16.hip
 
 // host side ---------------------------------------------------------------------------------------

@@ -56,8 +56,14 @@ struct GroupArgs {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
-FK_DEV void glds16(const bf16_t* src, char* lds_dst) {
-  __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_dst, 16, 0, 0);
+// buffer form of the LDS-DMA load.  The builtin exists for the device target only; seen by the host pass it silently
+// suppresses the kernel's host stub.
+FK_DEV void buffer_lds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 16, voffset, soffset, 0, 0);
+#else
+  (void)rsrc; (void)lds_dst; (void)voffset; (void)soffset;
+#endif
 }
 
 template <int BN>
@@ -253,25 +259,33 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GroupArgs ga) {
   const fk_gemm_args& p = ga.p[pi];
 
   // ---- LDS-DMA sources: lane -> (row = base + lane/CH, slot = lane%CH), source chunk = slot ^ swz(row) --
+  // Buffer form (`buffer_load_dwordx4 ... lds`): one SGPR descriptor per operand based at the tile's first row,
+  // a 32-bit byte offset VGPR per piece (constant over K) and the K offset in an SGPR.  Besides saving the 64-bit
+  // address arithmetic this keeps hipcc's LDS wait counts exact: `global_load_lds` is a FLAT-class instruction,
+  // and while one is pending every `lgkmcnt` wait degrades to lgkmcnt(0), i.e. also waits for the fragment reads
+  // issued for the NEXT k-step.
   const int lrow = lane / C::CH, slot = lane % C::CH;
-  const bf16_t* a_src[C::A_LOADS];
-  const bf16_t* w_src[C::W_LOADS];
+  const __amdgpu_buffer_rsrc_t rs_a =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.A + fk_row_offset(p.a, m0)), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.W + (int64_t)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
+  int a_voff[C::A_LOADS], w_voff[C::W_LOADS];
 #pragma unroll
   for (int j = 0; j < C::A_LOADS; ++j) {
     const int rl = (wave * C::A_LOADS + j) * C::RPI + lrow;  // row inside the A tile
     const int m = min(m0 + rl, p.M - 1);
-    a_src[j] = (const bf16_t*)p.A + fk_row_offset(p.a, m) + ((slot ^ C::swz(rl)) << 3);
+    a_voff[j] = (int)((fk_row_offset(p.a, m) - fk_row_offset(p.a, m0)) * 2) + ((slot ^ C::swz(rl)) << 4);
   }
 #pragma unroll
   for (int j = 0; j < C::W_LOADS; ++j) {
     const int rl = (wave * C::W_LOADS + j) * C::RPI + lrow;
     const int n = min(n0 + rl, p.N - 1);
-    w_src[j] = (const bf16_t*)p.W + (int64_t)n * p.ldw + ((slot ^ C::swz(rl)) << 3);
+    w_voff[j] = (int)((int64_t)(n - n0) * p.ldw * 2) + ((slot ^ C::swz(rl)) << 4);
   }
-  // piece i of the tile's DMA list (A pieces first); `koff` = element offset of the K-tile
-  auto issue_piece = [&](int i, int64_t koff, char* sb) {
-    if (i < C::A_LOADS) glds16(a_src[i] + koff, sb + (wave * C::A_LOADS + i) * 1024);
-    else glds16(w_src[i - C::A_LOADS] + koff, sb + C::A_BYTES + (wave * C::W_LOADS + (i - C::A_LOADS)) * 1024);
+  // piece i of the tile's DMA list (A pieces first); `koff` = byte offset of the K-tile
+  auto issue_piece = [&](int i, int koff, char* sb) {
+    if (i < C::A_LOADS) buffer_lds16(rs_a, sb + (wave * C::A_LOADS + i) * 1024, a_voff[i], koff);
+    else buffer_lds16(rs_w, sb + C::A_BYTES + (wave * C::W_LOADS + (i - C::A_LOADS)) * 1024, w_voff[i - C::A_LOADS], koff);
   };
 
   // ---- MFMA operand addressing (same swizzle on the read side) -----------------------------------------
@@ -298,60 +312,51 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GroupArgs ga) {
 
   // Pipeline: tiles kt+1 .. kt+PF are in flight / landed while tile kt multiplies.  The ONE barrier per tile
   // sits after the MFMAs of the tile's second-to-last k-step: it publishes tile kt+1 (every wave has waited
-  // for its own pieces of it) and retires the reads of tile kt-... so that the last k-step can already fetch
+  // for its own pieces of it) and retires the reads of tile kt, so that the last k-step can already fetch
   // the first fragments of tile kt+1 -- the MFMA stream never waits for an LDS round trip at a tile boundary.
+  // The loop body is straight-line code: every DMA piece and fragment read is issued unconditionally (tile indices
+  // are clamped; the surplus requests are never consumed), so the wait counts are exact constants and hipcc keeps
+  // `lgkmcnt(N)` waits that let the just-issued reads of the NEXT k-step stay in flight under this one's MFMAs.
   const int nk = p.K / BK;
 #pragma unroll
-  for (int s = 0; s < C::PF; ++s)
-    if (s < nk) {
+  for (int s = 0; s < C::PF; ++s) {
+    const int koff = min(s, nk - 1) * (BK * 2);
 #pragma unroll
-      for (int i = 0; i < C::LOADS; ++i) issue_piece(i, (int64_t)s * BK, smem + s * C::STAGE_BYTES);
-    }
-  if (nk > C::PF - 1) wait_vmcnt<(C::PF - 1) * C::LOADS>();
-  else wait_vmcnt<0>();
+    for (int i = 0; i < C::LOADS; ++i) issue_piece(i, koff, smem + s * C::STAGE_BYTES);
+  }
+  wait_vmcnt<(C::PF - 1) * C::LOADS>();
   __builtin_amdgcn_s_barrier();
   read_frags(0, smem, 0);
 
   int st_cur = 0, st_pf = C::PF;  // stage of tile kt, stage receiving tile kt+PF (= stage of tile kt-1)
-  constexpr int DMA_KK = (C::KS > 1) ? C::KS - 1 : 1;            // k-steps that carry DMA pieces (before the barrier)
+  constexpr int DMA_KK = C::KS - 1;                               // k-steps that carry DMA pieces (before the barrier)
   constexpr int PER_KK = (C::LOADS + DMA_KK - 1) / DMA_KK;
   for (int kt = 0; kt < nk; ++kt) {
     const char* sb = smem + st_cur * C::STAGE_BYTES;
     const int st_nx = (st_cur == C::STAGES - 1) ? 0 : st_cur + 1;
     const char* sb_nx = smem + st_nx * C::STAGE_BYTES;
     char* sb_pf = smem + st_pf * C::STAGE_BYTES;
-    const bool do_pf = kt + C::PF < nk;
-    const bool more = kt + 1 < nk;
-    const int64_t koff_pf = (int64_t)(kt + C::PF) * BK;
+    const int koff_pf = min(kt + C::PF, nk - 1) * (BK * 2);
 #pragma unroll
     for (int kk = 0; kk < C::KS; ++kk) {
       const int cb = kk & 1, nb = cb ^ 1;
-      if (do_pf && kk < DMA_KK) {
+      // the NEXT k-step's fragments first (they have this k-step's MFMAs to land), then this k-step's DMA pieces
+      if (kk < C::KS - 1) read_frags(nb, sb, kk + 1);
+      else read_frags(nb, sb_nx, 0);
+      if (kk < DMA_KK) {
 #pragma unroll
         for (int i = kk * PER_KK; i < (kk + 1) * PER_KK && i < C::LOADS; ++i) issue_piece(i, koff_pf, sb_pf);
       }
-      // first half of the k-step's MFMAs, then the NEXT k-step's fragment reads (they land under the second
-      // half and are never what an `lgkmcnt` in front of an MFMA waits for), then the second half
 #pragma unroll
-      for (int nf = 0; nf < C::NF / 2; ++nf)
+      for (int nf = 0; nf < C::NF; ++nf)
 #pragma unroll
         for (int mf = 0; mf < C::MF; ++mf)
           acc[nf][mf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][nf], af[cb][mf], acc[nf][mf], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (kk < C::KS - 1) read_frags(nb, sb, kk + 1);
-      else if (more) read_frags(nb, sb_nx, 0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int nf = C::NF / 2; nf < C::NF; ++nf)
-#pragma unroll
-        for (int mf = 0; mf < C::MF; ++mf)
-          acc[nf][mf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][nf], af[cb][mf], acc[nf][mf], 0, 0, 0);
-      if (kk == C::KS - 2 && more) {
-        // tile kt+1 landed (own pieces) once at most the PF-1 newer tiles remain outstanding
-        const int newer = nk - kt - 2;  // tiles after kt+1 that exist (all issued by now)
-        if (newer >= C::PF - 1) wait_vmcnt<(C::PF - 1) * C::LOADS>();
-        else if (C::PF > 2 && newer == 1) wait_vmcnt<C::LOADS>();
-        else wait_vmcnt<0>();
+      __builtin_amdgcn_sched_group_barrier(0x100, C::MF + C::NF, 0);   // the fragment reads of this slot first ...
+      __builtin_amdgcn_sched_group_barrier(0x008, C::MF * C::NF, 0);   // ... then its MFMAs
+      if (kk == C::KS - 2) {
+        // tile kt+1 landed (own pieces) once only the PF-1 newer tiles (all issued by now) remain outstanding
+        wait_vmcnt<(C::PF - 1) * C::LOADS>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile kt are complete
         __builtin_amdgcn_s_barrier();
       }
@@ -360,6 +365,7 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GroupArgs ga) {
     st_cur = st_nx;
     st_pf = (st_pf == C::STAGES - 1) ? 0 : st_pf + 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus (clamped) requests must not land in the C tile
 
   store_tile<EPI, BN, C>(acc, p, smem, m0, n0, wm, wn);
 }
@@ -582,22 +588,23 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t s
   GroupArgs ga;
   ga.n = n;
   long t128 = 0, t256 = 0;
-  bool ok256 = probs[0].N % 256 == 0;
+  bool ok256 = probs[0].N % 256 == 0, ok32 = true;   // ok32: a tile's rows are addressable with 32-bit byte offsets
   for (int i = 0; i < FK_MAX_GROUP; ++i) {
     ga.p[i] = probs[i < n ? i : 0];
     if (i < n) {
       const long nbm = (probs[i].M + BM - 1) / BM;
       t128 += nbm * ((probs[i].N + 127) / 128);
       t256 += nbm * ((probs[i].N + 255) / 256);
-      // gemm5_kernel addresses a tile's rows with 32-bit byte offsets from the tile's first row
+      // both kernels address a tile's rows with 32-bit byte offsets from the tile's first row
       auto span = [](const fk_rows& r) {
         const long long ld = r.ld < 0 ? -r.ld : r.ld, bs = r.batch_stride < 0 ? -r.batch_stride : r.batch_stride;
         return (BM * ld + (r.rows_per_batch > 0 ? bs : 0)) * 2;
       };
-      if (span(probs[i].a) >= (1ll << 31) || (long long)BM * probs[i].ldw * 2 >= (1ll << 31)) ok256 = false;
-      if (probs[i].a.ld < 0 || (probs[i].a.rows_per_batch > 0 && probs[i].a.batch_stride < 0)) ok256 = false;
+      if (span(probs[i].a) >= (1ll << 31) || (long long)BM * probs[i].ldw * 2 >= (1ll << 31)) ok32 = false;
+      if (probs[i].a.ld < 0 || (probs[i].a.rows_per_batch > 0 && probs[i].a.batch_stride < 0)) ok32 = false;
     }
   }
+  if (!ok32) return FK_E2BIG_STRIDES;   // caller falls back to the 128 x 128 kernel (64-bit addressing)
   int bn = bn_hint;
   if (bn == 256 && !ok256) bn = 128;
   if (bn != 128 && bn != 256) {

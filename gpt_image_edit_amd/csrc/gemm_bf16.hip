@@ -352,7 +352,14 @@ extern "C" int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream_) {
     }
   }
   const int ov = gemm_impl_override();
-  if (ov == 2 || p.epilogue == FK_EPI_QKV || (ov == 0 && p.M >= 192)) return fk_gemm2_launch(&p, 1, gemm_bn_override(), stream);
+  if (ov == 2 || p.epilogue == FK_EPI_QKV || (ov == 0 && p.M >= 192)) {
+    const int rc2 = fk_gemm2_launch(&p, 1, gemm_bn_override(), stream);
+    if (rc2 != FK_E2BIG_STRIDES) return rc2;   // row strides beyond 32-bit tile offsets: 64-bit-addressing kernel below
+    if (p.epilogue == FK_EPI_QKV) {
+      fk_set_error("fk_gemm_bf16: FK_EPI_QKV needs row strides that keep a 256-row tile within 2 GiB");
+      return FK_EUNSUPPORTED;
+    }
+  }
   switch (p.epilogue) {
     case FK_EPI_NONE: return launch<FK_EPI_NONE, false>(p, stream);
     case FK_EPI_GELU_TANH: return launch<FK_EPI_GELU_TANH, false>(p, stream);
@@ -374,7 +381,16 @@ extern "C" int fk_gemm_bf16_grouped(const fk_gemm_args* args, int32_t n, fk_stre
                  "fk_gemm_bf16_grouped: all problems must share N, K and the epilogue");
   }
   hipStream_t stream = (hipStream_t)stream_;
-  if (gemm_impl_override() == 1 && args[0].epilogue != FK_EPI_QKV) {  // A/B: one 128x128 launch per problem
+  int rc2 = FK_E2BIG_STRIDES;
+  if (gemm_impl_override() != 1 || args[0].epilogue == FK_EPI_QKV) {
+    rc2 = fk_gemm2_launch(args, n, gemm_bn_override(), stream);
+    if (rc2 != FK_E2BIG_STRIDES) return rc2;
+    if (args[0].epilogue == FK_EPI_QKV) {
+      fk_set_error("fk_gemm_bf16_grouped: FK_EPI_QKV needs row strides that keep a 256-row tile within 2 GiB");
+      return FK_EUNSUPPORTED;
+    }
+  }
+  {  // one 128x128 launch per problem (A/B override, or strides beyond 32-bit tile offsets)
     for (int i = 0; i < n; ++i) {
       fk_gemm_args one = args[i];
       int rc;
@@ -390,7 +406,6 @@ extern "C" int fk_gemm_bf16_grouped(const fk_gemm_args* args, int32_t n, fk_stre
     }
     return FK_OK;
   }
-  return fk_gemm2_launch(args, n, gemm_bn_override(), stream);
 }
 
 // Conv2d over NHWC bf16 as an implicit GEMM on the same MFMA main loop (A rows gathered per filter tap,
