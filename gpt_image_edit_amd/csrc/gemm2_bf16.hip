@@ -37,7 +37,7 @@ constexpr int NT = 512;
 constexpr int GROUP_M = FK_GROUP_M;
 // steady-state rate of the 256 x 256 kernel relative to the 256 x 128 one (measured)
 #ifndef FK_RATE_256
-#define FK_RATE_256 1.19
+#define FK_RATE_256 1.12
 #endif
 #ifndef FK_BSLOT
 #define FK_BSLOT 3
@@ -582,7 +582,7 @@ int launch_bn(GroupArgs& ga, const fk_gemm_args* probs, int n, int bn, hipStream
 
 // Used by fk_gemm_bf16 / fk_gemm_bf16_grouped after argument validation.
 // bn_hint: 128 / 256 force the N tile; 0 = choose per problem.  The 256 x 256 kernel has the higher steady-state
-// rate (measured 1.19x at K = 12288), but one workgroup per CU means the grid runs in rounds of 256 tiles: pick
+// rate (measured 1.1-1.2x for large grids), but one workgroup per CU means the grid runs in rounds of 256 tiles: pick
 // the tile with the better (quantisation efficiency) x (rate).
 int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t stream) {
   GroupArgs ga;
