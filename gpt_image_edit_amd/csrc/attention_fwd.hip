@@ -147,6 +147,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
   // reference by more than TAU (adversarial inputs; the tests build one) the workgroup finishes the pass and
   // repeats it with the exact row maxima from a K-only pre-pass: the result is then the plain two-pass softmax.
   constexpr float TAU = 40.0f;   // log2 units: p <= 2^40, row sums <= 2^55 for 32768 keys
+  // The reference sits REF_BIAS above the first block's maximum: later scores may then grow by TAU + REF_BIAS = 64 log2
+  // units (44 nats) before a restart is needed, and the first block's own probabilities (>= 2^-24 at its maximum)
+  // are still far from fp32 / bf16 underflow.
+  constexpr float REF_BIAS = 24.0f;
   float m_ref = 0.f, l_run = 0.f;
   bool overflow = false;         // wave-uniform
 
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
       f32x16_t s = scores(sb, kb, kt, mask_tag);
       const float mx = block_max(s);
       if constexpr (FIRST) {
-        if (kb == 0) m_ref = mx;   // reference = row maximum over the first 32 keys
+        if (kb == 0) m_ref = mx + REF_BIAS;   // reference = row maximum over the first 32 keys + bias
         else overflow = overflow || (__builtin_amdgcn_ballot_w64(mx > m_ref + TAU) != 0);
       } else {
         overflow = overflow || (__builtin_amdgcn_ballot_w64(mx > m_ref + TAU) != 0);
