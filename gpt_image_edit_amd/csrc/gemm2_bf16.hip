@@ -3,7 +3,8 @@
 // consecutive output columns of one row.  Two kernels, chosen per problem by (tile-quantisation efficiency) x
 // (measured steady-state rate):
 //
-//   gemm2_kernel   256 x 128 x 64, 8 waves (4 x 2, 64 x 64 per wave), LDS-DMA staging into a 3-stage ring
+//   gemm2_kernel   256 x 128 x 64, 8 waves (4 x 2, 64 x 64 per wave), buffer-form LDS-DMA staging into a 3-stage ring,
+//                  straight-line k-loop with the next k-step's fragment reads pinned in front of this one's MFMAs
 //   gemm5_kernel   256 x 256 x 64, 4 waves (2 x 2, 128 x 128 per wave, one wave per SIMD, accumulators in AGPRs),
 //                  buffer_load -> VGPR -> ds_write_b128 staging into a 2-stage ring, slot-scheduled k-loop
 //
@@ -20,6 +21,10 @@
 //    of an MFMA, so the matrix pipe drains behind every piece (8 pieces per 32 MFMAs -> 68 % busy, exactly what
 //    the counters show).  `buffer_load_dwordx4` (one address VGPR) + `ds_write_b128` are two short instructions
 //    that each fit a shadow: gemm5_kernel reaches 75 % busy / 1.20 PF/s with the slots pinned in source order.
+//  * `global_load_lds` is a FLAT-class instruction: while one is pending hipcc turns every `lgkmcnt(N)` wait into
+//    `lgkmcnt(0)`, so the wait in front of an MFMA also waits for the reads just issued for the NEXT k-step.  The
+//    MUBUF form (`buffer_load_dwordx4 ... lds`) keeps the counts exact; with it, unconditional (clamped) requests
+//    and sched_group_barrier-pinned read/MFMA order gemm2_kernel gained 4-15 % (68 % busy).
 //
 // The LDS image of a tile row is 128 B (64 k); the bank-conflict swizzle (16-byte chunk ^ ((row >> 1) & 7)) is
 // applied where the tile is written (DMA source address / ds_write address) and again on the ds_read_b128 side.
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GroupArgs ga) {
 }
 
 // ---- 4 waves, register staged --------------------------------------------------------------------------------
-// s_memtime traces of gemm4_kernel: a k-step of 16 MFMAs + 8 ds_read_b128 runs in ~540 cycles (ideal 512), but
+// s_memtime traces of an LDS-DMA 4-wave variant: a k-step of 16 MFMAs + 8 ds_read_b128 runs in ~540 cycles (ideal 512), but
 // every `global_load_lds_dwordx4` adds 54-68 cycles of ISSUE time to the wave -- longer than the 28-cycle shadow
 // of an MFMA, so with one wave per SIMD the matrix pipe drains behind each piece (8 pieces per 32 MFMAs -> 68 %,
 // exactly what the counters show).  Plain `global_load_dwordx4` + `ds_write_b128` are two short instructions that

@@ -1,5 +1,6 @@
 """A/B two builds/modes of the GEMM: run with env A and env B in subprocesses, compare outputs bitwise, and
-print TF/s of both.  Usage: python tools/ab_gemm.py "FK_GEMM_PHASED=0" "FK_GEMM_PHASED=1" [--bn 128|256]"""
+print TF/s of both.  Usage: python tools/ab_gemm.py "FK_LIB_PATH=build_ab/libfk_prev.so" "" (an older build against the
+current one), or "FK_GEMM_BN=128" "FK_GEMM_BN=256" (tile override).  FK_AB_SHAPES="M,N,K,epi;..." replaces the shape list."""
 import os
 import subprocess
 import sys
