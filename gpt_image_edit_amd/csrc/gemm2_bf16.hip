@@ -75,14 +75,8 @@ template <int BN>
 struct Cfg {
   static constexpr int NTHREADS = NT;
   static_assert(BN == 128, "the 8-wave kernel is instantiated for the 256 x 128 tile only");
-#ifndef FK_G2_BK
-#define FK_G2_BK 64
-#endif
-#ifndef FK_G2_STAGES
-#define FK_G2_STAGES 3
-#endif
-  static constexpr int BK = FK_G2_BK;
-  static constexpr int STAGES = FK_G2_STAGES;
+  static constexpr int BK = 64;
+  static constexpr int STAGES = 3;
   static constexpr int KS = BK / 16;                   // MFMA k-steps per tile
   static constexpr int CH = BK / 8;                    // 16-byte chunks per tile row
   static constexpr int ROW_BYTES = BK * 2;
@@ -107,7 +101,6 @@ template <int N>
 FK_DEV void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
