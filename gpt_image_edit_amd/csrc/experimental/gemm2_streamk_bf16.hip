@@ -1,3 +1,12 @@
+// NOT BUILT -- record of the round-1 stream-K experiment (see README.md in this directory and DESIGN.md section 4).
+// This is gemm2_bf16.hip as it stood with `gemm5sk_kernel`: the 256 x 256 4-wave kernel as a persistent grid of one
+// workgroup per CU that shares the K-iterations of the tiles of the last, partly filled round (fp32 partials and
+// ticket counters in a caller-owned workspace, last arriver finishes the tile, partials re-read in K order).
+// Correct (its GPU tests passed: 5 shapes x 4 runs bit-identical, gated-residual / GELU epilogues), but slower:
+// cfg 2 edit 2028 ms against 1026 ms for the data-parallel kernels.  Every tile of the shared round is cut (a share
+// is shorter than a tile), so ~0.5 MB of fp32 partials per tile cross the fabric at the end of every launch, and the
+// device-scope fences (`buffer_wbl2 sc1` / `buffer_inv sc1`) drop the operand tiles the XCD's other workgroups are
+// streaming.  Replacing the fences by sc1 loads / stores was still 1.37x slower and no longer correct.
 // Large-tile bf16 MFMA GEMMs for the MMDiT linears (same contract as gemm_bf16.hip, used when M >= 192).
 // v_mfma_f32_32x32x16_bf16, operands swapped like gemm_bf16.hip (W rows -> MFMA A operand) so a lane owns 4
 // consecutive output columns of one row.  Two kernels, chosen per problem by (tile-quantisation efficiency) x
@@ -174,10 +183,47 @@ FK_DEV void select_tile(const GroupArgs& ga, int& pi, int& m0, int& n0) {
 // chunk made the epilogue ~15 % of a K = 3072 tile).  All global reads are therefore issued unconditionally with
 // clamped indices, a batch of EPI_BATCH chunks at a time, ahead of the arithmetic of the batch; only the final
 // store is predicated.
-template <int EPI, int BN, class C>
-FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& p, char* smem, int m0, int n0,
-                       int wm, int wn) {
-  const int tid = threadIdx.x;
+// Where the epilogue takes the fp32 sums from: the MFMA accumulators ...
+template <class C>
+struct AccSource {
+  const f32x16_t (&acc)[C::NF][C::MF];
+  // xs[q][mf] = columns 8q + 4*(lane >> 5) .. +3 of row (lane & 31) of block (nf, mf)
+  FK_DEV void gather(int nf, f32x4_t (&xs)[4][C::MF]) const {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int mf = 0; mf < C::MF; ++mf)
+        xs[q][mf] = f32x4_t{acc[nf][mf][4 * q], acc[nf][mf][4 * q + 1], acc[nf][mf][4 * q + 2], acc[nf][mf][4 * q + 3]};
+  }
+};
+// ... or the stream-K workspace: the partial sums of the tile's segments, added in K order (segment `first` .. `last`
+// of the iteration space; `slot(w)` = workspace slot of workgroup-place w's segment of this tile).  `base` points at
+// this lane's first 16-byte chunk of slot 0; chunk (nf, mf, q) of a slot is ((nf*MF + mf)*4 + q) * 256 floats on.
+template <class C>
+struct PartialSource {
+  const float* base;
+  int first, last, ts, c, nk;
+  static constexpr int64_t SLOT_FLOATS = (int64_t)BM * C::WAVES_N * C::WTN;
+  FK_DEV int slot(int w) const { return 2 * w + (((w * c) / nk == ts) ? 0 : 1); }
+  FK_DEV void gather(int nf, f32x4_t (&xs)[4][C::MF]) const {
+    for (int w = first; w <= last; ++w) {
+      const float* src = base + slot(w) * SLOT_FLOATS + nf * C::MF * 4 * 256;
+      f32x4_t v[4][C::MF];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mf = 0; mf < C::MF; ++mf) v[q][mf] = *(const f32x4_t*)(src + (mf * 4 + q) * 256);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mf = 0; mf < C::MF; ++mf) xs[q][mf] = (w == first) ? v[q][mf] : xs[q][mf] + v[q][mf];
+    }
+  }
+};
+
+template <int EPI, int BN, class C, class Source>
+FK_DEV void store_tile(const Source& sums, const fk_gemm_args& p, char* smem, int m0, int n0,
+                       int wm, int wn, int tid = threadIdx.x) {
   const int lane = tid & 63;
   const int frow = lane & 31, fhalf = lane >> 5;
   // bias of this lane's 4-column quads (all loads in flight before the barrier below)
@@ -201,6 +247,8 @@ FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& 
   bf16_t* ct = (bf16_t*)smem;
 #pragma unroll
   for (int nf = 0; nf < C::NF; ++nf) {
+    f32x4_t xs[4][C::MF];
+    sums.gather(nf, xs);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int nl = wn * C::WTN + nf * 32 + 8 * q + 4 * fhalf;
@@ -210,7 +258,7 @@ FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& 
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float x = acc[nf][mf][q * 4 + j];
+          const float x = xs[q][mf][j];
           if constexpr (EPI == FK_EPI_SCALE) v[j] = x * p.alpha;
           else v[j] = x + b[j];
         }
@@ -473,7 +521,7 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GroupArgs ga) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus (clamped) requests must not land in the C tile
 
-  store_tile<EPI, BN, C>(acc, p, smem, m0, n0, wm, wn);
+  store_tile<EPI, BN, C>(AccSource<C>{acc}, p, smem, m0, n0, wm, wn);
 }
 
 // ---- 4 waves, register staged --------------------------------------------------------------------------------
@@ -506,6 +554,7 @@ struct Cfg5 {
 };
 
 // k-loop of one work item of the 4-wave kernel: acc = A[m0.., kb*BK ..] x W[n0.., kb*BK ..]^T over `nit` K-tiles.
+// Shared by gemm5_kernel (one whole tile per workgroup) and gemm5sk_kernel (persistent, stream-K).
 template <int BN>
 FK_DEV void gemm5_mainloop(const fk_gemm_args& p, int m0, int n0, int kb, int nit, char* smem,
                            f32x16_t (&acc)[Cfg5<BN>::NF][Cfg5<BN>::MF], int wave, int lane, int wm, int wn) {
@@ -651,7 +700,127 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();
   }
 #endif
-  store_tile<EPI, BN, C>(acc, p, smem, m0, n0, wm, wn);
+  store_tile<EPI, BN, C>(AccSource<C>{acc}, p, smem, m0, n0, wm, wn);
+}
+
+// ---- stream-K form of the 4-wave kernel -------------------------------------------------------------------------
+// One workgroup per CU means a grid of T tiles runs in ceil(T / G) rounds of G = #CUs tiles, and the FLUX shapes
+// (multiples of 3 * 2^k) never fill the last round: 2560 x 9216 is 360 tiles of 256 x 256 -> 2 rounds at 70 %.
+// Here the grid is G persistent workgroups: each takes R = T / G whole tiles ("data-parallel" part, identical to
+// gemm5_kernel) and then an equal share of the K-iterations of the remaining Ts = T - R*G tiles, cut wherever the
+// share ends.  A tile cut into segments is finished by whichever workgroup arrives last (ticket counter): the others
+// leave their fp32 partial accumulators in the workspace, the last one (which has parked its own as well) re-reads
+// them all in K order inside the epilogue -- nobody ever waits, and the sum does not depend on the arrival order.
+struct SkArgs {
+  int G, R, nk;          // persistent workgroups, whole tiles per workgroup, K-tiles per output tile
+  int c, I;              // stream-K iterations per workgroup, and in total (= Ts * nk)
+  int* tickets;          // [Ts] zero on entry, zero again on exit
+  float* partials;       // [G][2] slots of BM*BN floats: slot 2w = w's first segment, 2w+1 = its last
+};
+
+// linear tile id (all problems of the group, grouped GROUP_M-deep order inside a problem) -> problem, tile origin
+template <int BN>
+FK_DEV void tile_coords(const GroupArgs& ga, int t, int& pi, int& m0, int& n0) {
+  pi = 0;
+#pragma unroll
+  for (int i = 1; i < FK_MAX_GROUP; ++i)
+    if (i < ga.n && t >= ga.tiles_before[i]) pi = i;
+  const fk_gemm_args& p = ga.p[pi];
+  t -= ga.tiles_before[pi];
+  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  const int per_group = GROUP_M * nbn;
+  const int g = t / per_group;
+  const int first_m = g * GROUP_M;
+  const int gm = min(nbm - first_m, GROUP_M);
+  const int rem = t - g * per_group;
+  m0 = (first_m + rem % gm) * BM;
+  n0 = (rem / gm) * BN;
+}
+
+// position of workgroup `b` of `n` in XCD-chunked order (workgroups are dealt round-robin to the 8 XCDs: neighbours
+// in the returned order share an XCD, i.e. an L2)
+FK_DEV int xcd_chunked(int b, int n) {
+  const int q = n >> 3, r = n & 7;
+  const int xcd = b & 7, idx = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int EPI, int BN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm5sk_kernel(const GroupArgs ga_,
+                                                                                                const SkArgs sk) {
+  using C = Cfg5<BN>;
+  // The problem is re-selected per work item: read the (first) kernel argument in place.  Through the by-value
+  // parameter hipcc copies the whole struct to scratch once the selection sits in a loop.
+  const GroupArgs& ga = *(const GroupArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)ga_;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nk = sk.nk;
+  const int wp = xcd_chunked(blockIdx.x, sk.G);      // this workgroup's place in the stream-K iteration space
+  int it = wp * sk.c;
+  const int it_end = min(it + sk.c, sk.I);
+
+  f32x16_t acc[C::NF][C::MF];
+  for (int item = 0;; ++item) {
+    // Re-derive every lane constant per item from an opaque copy of the thread id: hoisted out of this loop they
+    // would have to live across the k-loop, which has no VGPR to spare (they end up in scratch).
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % C::WAVES_M, wn = wave / C::WAVES_M;
+    int t, kb, nit, ts = 0;
+    if (item < sk.R) {
+      t = xcd_chunked(item * sk.G + blockIdx.x, sk.R * sk.G);
+      kb = 0;
+      nit = nk;
+    } else {
+      if (it >= it_end) break;
+      ts = it / nk;
+      kb = it - ts * nk;
+      nit = min(nk - kb, it_end - it);
+      t = sk.R * sk.G + ts;
+      it += nit;
+    }
+    if (item) __syncthreads();   // the previous item's LDS reads (fragments / C tile) are done before the refill
+    int pi, m0, n0;
+    tile_coords<BN>(ga, t, pi, m0, n0);
+    const fk_gemm_args& p = ga.p[pi];
+    gemm5_mainloop<BN>(p, m0, n0, kb, nit, smem, acc, wave, lane, wm, wn);
+    if (nit != nk) {
+      // (keeps hipcc from hoisting the accumulator reads of both branches above the test, all 256 into VGPRs at once)
+#pragma unroll
+      for (int nf = 0; nf < C::NF; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < C::MF; ++mf) asm volatile("" : "+a"(acc[nf][mf]));
+      // segment of a cut tile: contributors are the workgroups at places lo..hi of the iteration space
+      const int lo = (ts * nk) / sk.c, hi = min((ts + 1) * nk - 1, sk.I - 1) / sk.c;
+      const float* lane_base = sk.partials + (wave * (C::NF * C::MF * 4) * 64 + lane) * 4;
+      const PartialSource<C> parts{lane_base, lo, hi, ts, sk.c, nk};
+      {  // park this segment's sums: chunk (nf, mf, q) = one 16-byte store per lane, 1 KiB per wave
+        float* dst = const_cast<float*>(lane_base) + parts.slot(wp) * PartialSource<C>::SLOT_FLOATS;
+#pragma unroll
+        for (int nf = 0; nf < C::NF; ++nf)
+#pragma unroll
+          for (int mf = 0; mf < C::MF; ++mf)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *(f32x4_t*)(dst + ((nf * C::MF + mf) * 4 + q) * 256) = f32x4_t{
+                  acc[nf][mf][4 * q], acc[nf][mf][4 * q + 1], acc[nf][mf][4 * q + 2], acc[nf][mf][4 * q + 3]};
+      }
+      __threadfence();            // partial visible device-wide (other XCDs' L2s) before the ticket is taken
+      __syncthreads();
+      int* flag = (int*)(smem + C::SMEM_BYTES);
+      if (tid == 0) *flag = atomicAdd(sk.tickets + ts, 1);
+      __syncthreads();
+      const int ticket = *flag;
+      if (ticket != hi - lo) continue;    // not the last arriver: the tile is someone else's to finish
+      __threadfence();
+      if (tid == 0) sk.tickets[ts] = 0;   // every contributor has arrived: leave the counter clean for the next launch
+      store_tile<EPI, BN, C>(parts, p, smem, m0, n0, wm, wn, tid);
+      continue;
+    }
+    store_tile<EPI, BN, C>(AccSource<C>{acc}, p, smem, m0, n0, wm, wn, tid);
+  }
 }
 
 template <int EPI, int BN>
@@ -692,8 +861,30 @@ int launch5(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream)
   return FK_OK;
 }
 
+template <int EPI, int BN>
+int launch5sk(GroupArgs& ga, const fk_gemm_args* probs, int n, const SkArgs& sk, hipStream_t stream) {
+  int total = 0;
+  for (int i = 0; i < FK_MAX_GROUP; ++i) {
+    ga.tiles_before[i] = total;
+    if (i < n) total += ((probs[i].M + BM - 1) / BM) * ((probs[i].N + BN - 1) / BN);
+  }
+  ga.tiles_before[FK_MAX_GROUP] = total;
+  auto kern = gemm5sk_kernel<EPI, BN>;
+  constexpr int SMEM = Cfg5<BN>::SMEM_BYTES + 16;   // + the ticket broadcast word
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(sk.G), dim3(256), SMEM, stream, ga, sk);
+  FK_CHECK_LAUNCH("fk_gemm_bf16 (256 x 256 tile, stream-K)");
+  return FK_OK;
+}
+
+// bn: 128 / 256 = the two data-parallel kernels, 257 = the 256 x 256 kernel in stream-K form
 template <int EPI>
-int launch_bn(GroupArgs& ga, const fk_gemm_args* probs, int n, int bn, hipStream_t stream) {
+int launch_bn(GroupArgs& ga, const fk_gemm_args* probs, int n, int bn, const SkArgs& sk, hipStream_t stream) {
+  if (bn == 257) return launch5sk<EPI, 256>(ga, probs, n, sk, stream);
   return bn == 256 ? launch5<EPI, 256>(ga, probs, n, stream) : launch<EPI, 128>(ga, probs, n, stream);
 }
 
@@ -707,17 +898,23 @@ int cu_count() {
   }
   return cus;
 }
+constexpr int64_t SK_TICKET_BYTES = 4096;
+constexpr int SK_MIN_ITERS = 16;      // shortest stream-K share worth a pipeline fill (K-tiles of 64)
+constexpr int SK_FIXUP_ITERS = 3;     // cost model: parking + adding a partial ~ this many K-tiles
+
 }  // namespace
 
 static thread_local int g_last_variant = 0;
-// 128 / 256: the 256 x 128 / 256 x 256 kernel, 0: none of the large-tile kernels yet
+// 128 / 256: data-parallel 256 x 128 / 256 x 256 kernel, 257: stream-K, 0: none of the large-tile kernels yet
 int fk_gemm_last_variant(void) { return g_last_variant; }
 
+int64_t fk_gemm_workspace_bytes(void) { return SK_TICKET_BYTES + (int64_t)cu_count() * 2 * BM * 256 * 4; }
+
 // Used by fk_gemm_bf16 / fk_gemm_bf16_grouped after argument validation.
-// bn_hint: 128 / 256 force the N tile; 0 = choose per problem.  The 256 x 256 kernel has the higher steady-state
-// rate (measured 1.1-1.2x for large grids), but one workgroup per CU means the grid runs in rounds of #CUs tiles:
-// pick the tile with the better (quantisation efficiency) x (rate).  (A stream-K form of the 256 x 256 kernel that
-// shares the last round's K-iterations among all CUs was built and measured slower: experimental/README.md.)
+// bn_hint: 128 / 256 force the N tile of the data-parallel kernels, 257 forces stream-K (when it applies), 0 = choose
+// per problem.  The 256 x 256 kernel has the higher steady-state rate (measured 1.1-1.2x for large grids), but one
+// workgroup per CU means a data-parallel grid runs in rounds of #CUs tiles: pick the variant with the best
+// (rate) x (fraction of the CU-rounds that do useful work), stream-K's fix-up priced in K-tiles.
 int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t stream) {
   GroupArgs ga;
   ga.n = n;
@@ -747,22 +944,41 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t s
   }
   if (!ok32) return FK_E2BIG_STRIDES;   // caller falls back to the 128 x 128 kernel (64-bit addressing)
 
-  const int G = cu_count();
+  // stream-K plan for the 256 x 256 tiling: R whole tiles per workgroup + an equal share of the rest's K-tiles
+  const int G = cu_count(), nk = probs[0].K / 64;
+  SkArgs sk{};
+  double eff_sk = 0.0;
+  const void* ws = probs[0].sk_ws;
+  const int64_t ws_bytes = probs[0].sk_ws_bytes;
+  if (ok256 && ws && ws_bytes >= SK_TICKET_BYTES + (int64_t)G * 2 * BM * 256 * 4 && t256 % G != 0 &&
+      t256 < (1l << 30) / nk) {
+    long R = t256 / G, Ts = t256 - R * G;
+    if (R > 0 && Ts * nk < (long)SK_MIN_ITERS * G) { R -= 1; Ts += G; }   // a sliver: share out one more round
+    const long I = Ts * nk, c = (I + G - 1) / G;
+    if (c >= SK_MIN_ITERS && Ts * 4 <= SK_TICKET_BYTES) {
+      sk.G = G; sk.R = (int)R; sk.nk = nk; sk.c = (int)c; sk.I = (int)I;
+      sk.tickets = (int*)ws;
+      sk.partials = (float*)((char*)ws + SK_TICKET_BYTES);
+      eff_sk = (double)(t256 * nk) / ((double)G * (double)(R * nk + c + SK_FIXUP_ITERS));
+    }
+  }
   int bn = bn_hint;
-  if (bn == 256 && !ok256) bn = 128;
-  if (bn != 128 && bn != 256) {
+  if ((bn == 256 || bn == 257) && !ok256) bn = 128;
+  if (bn == 257 && eff_sk == 0.0) bn = 256;
+  if (bn != 128 && bn != 256 && bn != 257) {
     auto eff = [G](long tiles) { return (double)tiles / (double)(((tiles + G - 1) / G) * G); };
-    bn = (ok256 && FK_RATE_256 * eff(t256) > eff(t128)) ? 256 : 128;
+    const double e128 = eff(t128), e256 = ok256 ? FK_RATE_256 * eff(t256) : 0.0, esk = FK_RATE_256 * eff_sk;
+    bn = (esk > e256 && esk > e128) ? 257 : (e256 > e128 ? 256 : 128);
   }
   g_last_variant = bn;
   switch (probs[0].epilogue) {
-    case FK_EPI_NONE: return launch_bn<FK_EPI_NONE>(ga, probs, n, bn, stream);
-    case FK_EPI_GELU_TANH: return launch_bn<FK_EPI_GELU_TANH>(ga, probs, n, bn, stream);
-    case FK_EPI_SILU: return launch_bn<FK_EPI_SILU>(ga, probs, n, bn, stream);
-    case FK_EPI_GATE_RES: return launch_bn<FK_EPI_GATE_RES>(ga, probs, n, bn, stream);
-    case FK_EPI_RES: return launch_bn<FK_EPI_RES>(ga, probs, n, bn, stream);
-    case FK_EPI_SCALE: return launch_bn<FK_EPI_SCALE>(ga, probs, n, bn, stream);
-    case FK_EPI_QKV: return launch_bn<FK_EPI_QKV>(ga, probs, n, bn, stream);
+    case FK_EPI_NONE: return launch_bn<FK_EPI_NONE>(ga, probs, n, bn, sk, stream);
+    case FK_EPI_GELU_TANH: return launch_bn<FK_EPI_GELU_TANH>(ga, probs, n, bn, sk, stream);
+    case FK_EPI_SILU: return launch_bn<FK_EPI_SILU>(ga, probs, n, bn, sk, stream);
+    case FK_EPI_GATE_RES: return launch_bn<FK_EPI_GATE_RES>(ga, probs, n, bn, sk, stream);
+    case FK_EPI_RES: return launch_bn<FK_EPI_RES>(ga, probs, n, bn, sk, stream);
+    case FK_EPI_SCALE: return launch_bn<FK_EPI_SCALE>(ga, probs, n, bn, sk, stream);
+    case FK_EPI_QKV: return launch_bn<FK_EPI_QKV>(ga, probs, n, bn, sk, stream);
     default: fk_set_error("fk_gemm_bf16: unknown epilogue %d", probs[0].epilogue); return FK_EUNSUPPORTED;
   }
 }

@@ -36,6 +36,12 @@ FK_DEV uint32_t pack_bf2(float lo, float hi) {
 
 FK_DEV float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 FK_DEV float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+// round two floats to bf16 precision in place: one v_cvt_pk_bf16_f32 + two unpacks instead of two integer sequences
+FK_DEV void round_bf_pair(float& a, float& b) {
+  const uint32_t w = pack_bf2(a, b);
+  a = bf_lo(w);
+  b = bf_hi(w);
+}
 
 FK_DEV float gelu_tanh_f(float x) {
   // torch: 0.5 * x * (1 + tanh(u)), u = sqrt(2/pi) * (x + 0.044715 x^3).  Since 0.5 * (1 + tanh(u)) = sigmoid(2u):

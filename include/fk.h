@@ -95,6 +95,9 @@ typedef struct fk_gemm_args {
 } fk_gemm_args;
 
 int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream);
+/* Which large-tile kernel the calling thread's last fk_gemm_bf16[_grouped] used: 128 = 256 x 128 tile (8 waves),
+ * 256 = 256 x 256 tile (4 waves), 0 = neither so far (tests, profiling). */
+int fk_gemm_last_variant(void);
 
 /* n (<= FK_MAX_GROUP) independent problems that share N, K and the epilogue in ONE launch: the text- and
  * image-stream linears of a FluxTransformerBlock (different weights, different row counts) fill the GPU

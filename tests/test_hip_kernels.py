@@ -124,6 +124,31 @@ def test_gemm_large_tile_kernel(ops, M, N, K):
     assert_bf16_close(f"gemm_large {M}x{N}x{K}", got, ref, max_ulp=1, max_bad_frac=1e-4)
 
 
+def _last_variant():
+    from gpt_image_edit_amd import libfk
+    return libfk.load().fk_gemm_last_variant()
+
+
+@pytest.mark.parametrize("B,S,N,K,want", [(1, 2560, 12288, 3072, 256), (1, 2560, 9216, 3072, 128),
+                                          (3, 100, 512, 128, 128), (2, 1200, 3072, 1024, 128)])
+def test_gemm_tile_choice_and_batched_epilogue(ops, B, S, N, K, want):
+    # the launcher picks the 256 x 256 (4-wave) kernel only where its higher rate survives the round quantisation;
+    # both kernels address batched [B, S, :] operands per tile (one division per tile, a compare per row; batches
+    # shorter than a tile take the reciprocal path) -- gated residual in place, like the blocks use it
+    x = randn(B, S, K, seed=64)
+    w, bias = randn(N, K, seed=65, scale=0.02), randn(N, seed=66, scale=0.1)
+    res = randn(B, S, N, seed=67)
+    mod = randn(B, 3 * N, seed=68, scale=0.5)
+    xd, rd, md = x.cuda(), res.cuda(), mod.cuda()
+    ops.gemm(xd, w.cuda(), bias.cuda(), out=rd, epilogue=ops.FK_EPI_GATE_RES, res=rd, gate=md[:, N:2 * N])
+    assert _last_variant() == want
+    y = (x.float() @ w.float().T + bias.float()).to(BF)
+    ref = res + mod[:, None, N:2 * N] * y
+    assert_bf16_close(f"gate_res B{B} S{S} N{N}", rd, ref, max_ulp=1, max_bad_frac=2e-3)
+    got = ops.gemm(xd, w.cuda(), bias.cuda(), epilogue=ops.FK_EPI_GELU_TANH)
+    assert_bf16_close(f"gelu B{B} S{S} N{N}", got, F.gelu(y, approximate="tanh"), max_ulp=1, max_bad_frac=1e-4)
+
+
 def test_gemm_grouped(ops):
     # text + image stream linears of a double block in one launch: different weights and row counts
     B, S_txt, S_img, D, K = 2, 100, 412, 384, 256
