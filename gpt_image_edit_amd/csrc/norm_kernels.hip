@@ -20,15 +20,28 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16_t* x, fk_ro
   if (row >= M) return;
   constexpr int D = NV * 512;
   const bf16_t* xp = x + fk_row_offset(xr, row) + lane * 8;
+  // every global read of the row's work is issued up front (the modulation vectors do not depend on the statistics):
+  // one memory latency per row instead of two
+  const int64_t b = row / mod_rpb;
+  const bool second = (row - b * mod_rpb) >= split;  // rows >= split of each batch use the second vector set
+  const bf16_t* sc = (second ? scale_b : scale) + b * mod_bs + lane * 8;
+  const bf16_t* sh = (second ? shift_b : shift) + b * mod_bs + lane * 8;
+  u32x4_t xw[NV], scw[NV], shw[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) xw[i] = *(const u32x4_t*)(xp + i * 512);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    scw[i] = *(const u32x4_t*)(sc + i * 512);
+    shw[i] = *(const u32x4_t*)(sh + i * 512);
+  }
   float v[NV][8];
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const u32x4_t w = *(const u32x4_t*)(xp + i * 512);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      v[i][2 * e] = bf_lo(w[e]);
-      v[i][2 * e + 1] = bf_hi(w[e]);
+      v[i][2 * e] = bf_lo(xw[i][e]);
+      v[i][2 * e + 1] = bf_hi(xw[i][e]);
       sum += v[i][2 * e] + v[i][2 * e + 1];
     }
   }
@@ -47,25 +60,21 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16_t* x, fk_ro
   for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
   const float rstd = rsqrtf(sq * (1.0f / D) + eps);
 
-  const int64_t b = row / mod_rpb;
-  const bool second = (row - b * mod_rpb) >= split;  // rows >= split of each batch use the second vector set
-  const bf16_t* sc = (second ? scale_b : scale) + b * mod_bs + lane * 8;
-  const bf16_t* sh = (second ? shift_b : shift) + b * mod_bs + lane * 8;
   bf16_t* op = out + fk_row_offset(outr, row) + lane * 8;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const u32x4_t scw = *(const u32x4_t*)(sc + i * 512);
-    const u32x4_t shw = *(const u32x4_t*)(sh + i * 512);
     u32x4_t ow;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float y0 = round_bf((v[i][2 * e] - mean) * rstd);
-      float y1 = round_bf((v[i][2 * e + 1] - mean) * rstd);
-      const float g0 = round_bf(1.0f + bf_lo(scw[e]));
-      const float g1 = round_bf(1.0f + bf_hi(scw[e]));
-      y0 = round_bf(y0 * g0);
-      y1 = round_bf(y1 * g1);
-      ow[e] = pack_bf2(y0 + bf_lo(shw[e]), y1 + bf_hi(shw[e]));
+      // rounding points of the reference graph: LN -> bf16, (1 + scale) -> bf16, product -> bf16, sum -> bf16
+      float y0 = (v[i][2 * e] - mean) * rstd, y1 = (v[i][2 * e + 1] - mean) * rstd;
+      round_bf_pair(y0, y1);
+      float g0 = 1.0f + bf_lo(scw[i][e]), g1 = 1.0f + bf_hi(scw[i][e]);
+      round_bf_pair(g0, g1);
+      y0 *= g0;
+      y1 *= g1;
+      round_bf_pair(y0, y1);
+      ow[e] = pack_bf2(y0 + bf_lo(shw[i][e]), y1 + bf_hi(shw[i][e]));
     }
     *(u32x4_t*)(op + i * 512) = ow;
   }
