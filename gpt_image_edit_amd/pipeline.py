@@ -42,6 +42,7 @@ class FluxKontextPipeline:
         self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1)
         self.latent_channels = vae.config.latent_channels
         self.default_sample_size = 128
+        self.tokenizer_max_length = tokenizer.model_max_length if tokenizer is not None else 77   # :253-255
         self.image_processor = image_processor.VaeImageProcessor(vae_scale_factor=self.vae_scale_factor * 2)
         self._interrupt = False
         self._guidance_scale = None
@@ -90,6 +91,59 @@ class FluxKontextPipeline:
                              "generate `prompt_embeds`.")
         if max_sequence_length is not None and max_sequence_length > 512:
             raise ValueError(f"`max_sequence_length` cannot be greater than 512 but is {max_sequence_length}")
+
+    # flux_pipeline.py:266-438 (the encoders are transformers' CLIPTextModel / T5EncoderModel, reused as they are)
+    def _get_t5_prompt_embeds(self, prompt, num_images_per_prompt=1, max_sequence_length=512, device=None, dtype=None):
+        if self.text_encoder_2 is None or self.tokenizer_2 is None:
+            raise ValueError("string prompts need `text_encoder_2` / `tokenizer_2` (T5); pass `prompt_embeds` instead")
+        device = device or self.device
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        ids = self.tokenizer_2(prompt, padding="max_length", max_length=max_sequence_length, truncation=True,
+                               return_length=False, return_overflowing_tokens=False, return_tensors="pt").input_ids
+        untruncated = self.tokenizer_2(prompt, padding="longest", return_tensors="pt").input_ids
+        if untruncated.shape[-1] >= ids.shape[-1] and not torch.equal(ids, untruncated):
+            removed = self.tokenizer_2.batch_decode(untruncated[:, self.tokenizer_max_length - 1:-1])
+            print(f"The following part of your input was truncated because `max_sequence_length` is set to "
+                  f" {max_sequence_length} tokens: {removed}")
+        enc_device = next(self.text_encoder_2.parameters()).device
+        embeds = self.text_encoder_2(ids.to(enc_device), output_hidden_states=False)[0]
+        embeds = embeds.to(dtype=self.text_encoder_2.dtype, device=device)
+        n, seq_len, _ = embeds.shape
+        return embeds.repeat(1, num_images_per_prompt, 1).view(n * num_images_per_prompt, seq_len, -1)
+
+    def _get_clip_prompt_embeds(self, prompt, num_images_per_prompt=1, device=None):
+        if self.text_encoder is None or self.tokenizer is None:
+            raise ValueError("string prompts need `text_encoder` / `tokenizer` (CLIP); pass `pooled_prompt_embeds` "
+                             "instead")
+        device = device or self.device
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        ids = self.tokenizer(prompt, padding="max_length", max_length=self.tokenizer_max_length, truncation=True,
+                             return_overflowing_tokens=False, return_length=False, return_tensors="pt").input_ids
+        untruncated = self.tokenizer(prompt, padding="longest", return_tensors="pt").input_ids
+        if untruncated.shape[-1] >= ids.shape[-1] and not torch.equal(ids, untruncated):
+            removed = self.tokenizer.batch_decode(untruncated[:, self.tokenizer_max_length - 1:-1])
+            print(f"The following part of your input was truncated because CLIP can only handle sequences up to"
+                  f" {self.tokenizer_max_length} tokens: {removed}")
+        enc_device = next(self.text_encoder.parameters()).device
+        pooled = self.text_encoder(ids.to(enc_device), output_hidden_states=False).pooler_output
+        pooled = pooled.to(dtype=self.text_encoder.dtype, device=device)
+        n = pooled.shape[0]
+        return pooled.repeat(1, num_images_per_prompt).view(n * num_images_per_prompt, -1)
+
+    def encode_prompt(self, prompt, prompt_2=None, device=None, num_images_per_prompt=1, prompt_embeds=None,
+                      pooled_prompt_embeds=None, max_sequence_length=512, lora_scale=None):
+        """(prompt_embeds, pooled_prompt_embeds, text_ids): CLIP pooled output of ``prompt``, T5 last hidden state of
+        ``prompt_2 or prompt``; given embeddings pass through untouched (flux_pipeline.py:361-438)."""
+        device = device or self.device
+        if prompt_embeds is None:
+            prompt = [prompt] if isinstance(prompt, str) else prompt
+            prompt_2 = prompt_2 or prompt
+            prompt_2 = [prompt_2] if isinstance(prompt_2, str) else prompt_2
+            pooled_prompt_embeds = self._get_clip_prompt_embeds(prompt, num_images_per_prompt, device)
+            prompt_embeds = self._get_t5_prompt_embeds(prompt_2, num_images_per_prompt, max_sequence_length, device)
+        dtype = self.text_encoder.dtype if self.text_encoder is not None else self.transformer.dtype
+        text_ids = torch.zeros(prompt_embeds.shape[1], 3).to(device=device, dtype=dtype)
+        return prompt_embeds, pooled_prompt_embeds, text_ids
 
     def _encode_vae_image(self, image, nhwc=False):
         """(mode(vae.encode(image)) - shift) * scale, the affine fused into the layout kernel (:600-613)."""
@@ -143,10 +197,18 @@ class FluxKontextPipeline:
                  output_type="pil", return_dict=True, joint_attention_kwargs=None, callback_on_step_end=None,
                  callback_on_step_end_tensor_inputs=("latents",), max_sequence_length=512,
                  max_area=1024 ** 2, _auto_resize=True):
-        if prompt is not None or prompt_2 is not None or negative_prompt is not None:
-            raise NotImplementedError("string prompts need the T5/CLIP encoders (reused as-is from transformers); "
-                                      "pass prompt_embeds / pooled_prompt_embeds like every reference caller does")
         device = self.device
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError(f"Cannot forward both `prompt`: {prompt} and `prompt_embeds`: {prompt_embeds}. Please make "
+                             "sure to only forward one of the two.")   # :510-514
+        if prompt is not None:
+            # string prompts: the pipeline's own CLIP / T5 encoders (:899-906); every caller in the reference passes
+            # embeddings instead (VLM tokens and/or T5), which skip this
+            prompt_embeds, pooled_prompt_embeds, _ = self.encode_prompt(
+                prompt, prompt_2, device=device, max_sequence_length=max_sequence_length)
+        if negative_prompt is not None and negative_prompt_embeds is None and true_cfg_scale > 1:
+            negative_prompt_embeds, negative_pooled_prompt_embeds, _ = self.encode_prompt(
+                negative_prompt, negative_prompt_2, device=device, max_sequence_length=max_sequence_length)
         height = height or self.default_sample_size * self.vae_scale_factor
         width = width or self.default_sample_size * self.vae_scale_factor
         multiple_of = self.vae_scale_factor * 2

@@ -114,6 +114,34 @@ def generate_image(pipe, prompt_embeds, pooled_prompt_embeds, history_image_path
     ).images[0]
 
 
+def run_t5_only(pipe, text_encoders, tokenizers, text, image1=None, image2=None, args=None):
+    """One edit conditioned on T5 (256 tokens) + CLIP only, no VLM -- ``run_model_and_return_samples`` of the
+    reference's ``univa/eval/imgedit/step1_gen_samples_T5_only.py:140-183``: size from ``update_size`` with
+    ``anchor_pixels = height * width``, the first image resized to that size (PIL bilinear, which is what
+    torchvision's ``Resize`` does for a PIL input) and normalised to [-1, 1], ``encode_prompt(..., 256, device, 1)``,
+    then the pipeline call with its default generator."""
+    from PIL import Image
+
+    from ..prompt_embedding import encode_prompt
+    new_h, new_w = update_size(image1, image2, "any_11ratio", anchor_pixels=args.height * args.width)
+    pipeline_image = None
+    if image1:
+        cond = Image.open(image1).convert("RGB").resize((new_w, new_h), Image.BILINEAR)
+        pipeline_image = torch.from_numpy(np.asarray(cond).copy()).unsqueeze(0)      # uint8 [1, H, W, 3]: fused HIP route
+    with torch.no_grad():
+        t5_prompt_embeds, pooled_prompt_embeds = encode_prompt(text_encoders, tokenizers, text, 256, pipe.device, 1)
+    return pipe(
+        image=pipeline_image,
+        prompt_embeds=t5_prompt_embeds,
+        pooled_prompt_embeds=pooled_prompt_embeds,
+        height=new_h,
+        width=new_w,
+        num_inference_steps=args.num_inference_steps,
+        guidance_scale=args.guidance_scale,
+        num_images_per_prompt=getattr(args, "num_images_per_prompt", 1),
+    ).images
+
+
 def build_parser():
     parser = argparse.ArgumentParser(description="Model and component paths")
     parser.add_argument("--model_path", type=str, required=True)
@@ -130,6 +158,8 @@ def build_parser():
                         help="torch-saved dict(prompt_embeds, pooled_prompt_embeds): skip the VLM / T5 / CLIP stage")
     parser.add_argument("--images", type=str, default="", help="comma-separated condition images (with --prompt_embeds)")
     parser.add_argument("--output", type=str, default=generate_image_temp.format(0))
+    parser.add_argument("--t5_only", type=str, default=None, metavar="INSTRUCTION",
+                        help="one edit from T5 + CLIP embeddings of INSTRUCTION only (no VLM), with --images")
     return parser
 
 
@@ -145,6 +175,14 @@ def main(args):
                                        anchor_pixels=args.height * args.width)
         img = generate_image(pipe, blob["prompt_embeds"], blob["pooled_prompt_embeds"], urls, new_h, new_w, args)
         img.save(args.output)
+        print(f"Assistant: generate image at {args.output}")
+        return
+    if args.t5_only:
+        if text_encoders[0] is None or text_encoders[1] is None:
+            raise SystemExit(f"--t5_only needs the text_encoder / text_encoder_2 folders under {args.flux_path}")
+        urls = [u.strip() for u in args.images.split(",") if u.strip()] + [None, None]
+        imgs = run_t5_only(pipe, text_encoders, tokenizers, args.t5_only, urls[0], urls[1], args)
+        imgs[0].save(args.output)
         print(f"Assistant: generate image at {args.output}")
         return
     try:  # the interactive loop needs the reference's VLM wrapper and prompt encoders (reused as-is)

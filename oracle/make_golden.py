@@ -11,6 +11,8 @@ G4     ``univa/utils/anyres_util.py`` imported normally from the reference tree.
 G5     torch's own CPU definitions of the building-block ops the HIP kernels implement.
 G7     ``prepare_condition_images`` and ``update_size`` of ``univa/serve/cli.py`` (:82-116), lifted with ``ast`` like
        G1-G3 (the module imports diffusers/flash-attn models) and executed on PNG files written here.
+G8     ``encode_prompt`` of ``univa/utils/denoiser_prompt_embedding_flux.py`` (imported normally) on the tiny seeded
+       T5 / CLIP models of ``tests/tiny_text_encoders.py``: both encoders, T5 only, CLIP only.
 G6     end-to-end outputs of THIS repo's oracle on tiny configs (self-pinned, labelled as such;
        guards the oracle against accidental edits -- it is not evidence about diffusers).
 
@@ -108,6 +110,27 @@ def g_cli():
     np.savez(os.path.join(OUT, "cli.npz"), **out)
 
 
+def g_prompt():
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    from tiny_text_encoders import build
+    from univa.utils.denoiser_prompt_embedding_flux import encode_prompt, tokenize_prompt
+    encoders, tokenizers = build()
+    prompts = ["replace the sky with a sunset", "make it snow"]
+    out = {}
+    with torch.no_grad():
+        pe, pp = encode_prompt(encoders, tokenizers, prompts, 24, device="cpu", num_images_per_prompt=2)
+        out["both_prompt_embeds"], out["both_pooled"] = pe.numpy(), pp.numpy()
+        pe, pp = encode_prompt([None, encoders[1]], [None, tokenizers[1]], prompts[0], 256, device="cpu")
+        assert pp is None
+        out["t5only_prompt_embeds"] = pe.numpy()
+        pe, pp = encode_prompt([encoders[0], None], [tokenizers[0], None], prompts[1], 256, device="cpu")
+        assert pe is None
+        out["cliponly_pooled"] = pp.numpy()
+        out["ids_t5_24"] = tokenize_prompt(tokenizers[1], prompts, 24).numpy()
+    np.savez(os.path.join(OUT, "prompt.npz"), **out)
+
+
 def g_anyres():
     sys.path.insert(0, REF)
     from univa.utils import anyres_util as ref  # importable: needs only PIL + math
@@ -196,6 +219,7 @@ if __name__ == "__main__":
     g_helpers()
     g_anyres()
     g_cli()
+    g_prompt()
     g_torch_ops()
     g_oracle_selfpin()
     for f in sorted(os.listdir(OUT)):

@@ -141,3 +141,48 @@ def test_true_cfg_matches_oracle_and_two_pass():
     # the combine kernel alone, bit-exact against the torch expression on the GPU
     a, b = torch.randn(4, 1024, 64, generator=g).to(BF).cuda(), torch.randn(4, 1024, 64, generator=g).to(BF).cuda()
     assert torch.equal(ops.true_cfg(a, b, 2.5), b + 2.5 * (a - b))
+
+
+def test_string_prompt_path_equals_embedding_path():
+    # `prompt="..."` runs the pipeline's own CLIP / T5 encoders (transformers' classes, tiny random stand-ins of the
+    # right widths here) and must produce exactly what passing their embeddings does
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from tiny_text_encoders import ToyTokenizer
+    from transformers import CLIPTextConfig, CLIPTextModel, T5Config, T5EncoderModel
+
+    from gpt_image_edit_amd import flux_spec
+    from gpt_image_edit_amd.pipeline import FluxKontextPipeline
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    from gpt_image_edit_amd.vae import HipAutoencoderKL
+
+    torch.manual_seed(5)
+    clip = CLIPTextModel(CLIPTextConfig(vocab_size=64, hidden_size=768, intermediate_size=64, num_hidden_layers=1,
+                                        num_attention_heads=4, max_position_embeddings=77, eos_token_id=61,
+                                        bos_token_id=62, pad_token_id=0)).eval().to(BF).cuda()
+    t5 = T5EncoderModel(T5Config(vocab_size=64, d_model=4096, d_kv=8, d_ff=64, num_layers=1, num_heads=4)).eval().to(BF).cuda()
+    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=1, num_single_layers=1)
+    sd_f = {k: v.to(BF) for k, v in flux_spec.synthetic_state(flux_spec.flux_param_shapes(cfg), seed=31).items()}
+    sd_v = {k: v.to(BF) for k, v in flux_spec.synthetic_state(flux_spec.vae_param_shapes(), seed=32).items()}
+    tr = HipFluxTransformer2DModel(cfg, device="cuda"); tr.load_state_dict(sd_f)
+    vae = HipAutoencoderKL(device="cuda"); vae.load_state_dict(sd_v)
+    pipe = FluxKontextPipeline(tr, vae, text_encoder=clip, tokenizer=ToyTokenizer(), text_encoder_2=t5,
+                               tokenizer_2=ToyTokenizer(model_max_length=512))
+    H = W = 64
+    g = torch.Generator().manual_seed(9)
+    cond = (torch.rand(1, 3, H, W, generator=g) * 2 - 1).cuda()
+    lat = pipe._pack_latents(torch.randn(1, 16, H // 8, W // 8, generator=g).to(BF), 1, 16, H // 8, W // 8).cuda()
+    kw = dict(image=cond, height=H, width=W, num_inference_steps=2, latents=lat, output_type="pt_raw", max_area=H * W,
+              _auto_resize=False, max_sequence_length=32)
+    text = "turn the car red"
+    with torch.no_grad():
+        a = pipe(prompt=text, **kw)
+        pe, pp, ids = pipe.encode_prompt(text, None, max_sequence_length=32)
+        b = pipe(prompt_embeds=pe, pooled_prompt_embeds=pp, **kw)
+    assert pe.shape == (1, 32, 4096) and pp.shape == (1, 768) and ids.shape == (32, 3)
+    assert torch.equal(a.latents, b.latents) and torch.equal(a.images, b.images)
+    with pytest.raises(ValueError, match="Cannot forward both"):
+        pipe(prompt=text, prompt_embeds=pe, pooled_prompt_embeds=pp, **kw)
