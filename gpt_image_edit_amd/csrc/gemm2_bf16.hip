@@ -232,7 +232,9 @@ FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& 
   __syncthreads();
   constexpr int CPR = BN / 8;  // 16-byte chunks per tile row
   constexpr int ITERS = BM * CPR / C::NTHREADS;
-  constexpr int U = EPI == FK_EPI_QKV ? 4 : 8;   // chunks per batch (EPI_BATCH)
+  // chunks per batch; the fused QKV epilogue keeps 16 table registers per chunk, so the 4-wave kernel (32 chunks per
+  // thread, VGPRs full) batches 4 and the 8-wave kernel takes all 8 of a thread's chunks at once
+  constexpr int U = (EPI == FK_EPI_QKV && ITERS > 8) ? 4 : 8;
   static_assert(ITERS % U == 0 && C::NTHREADS % CPR == 0, "epilogue batching");
   // per-tile (scalar) row addressing of the output, the residual and the gate
   const TileRows crow(p.c, m0);
