@@ -13,6 +13,10 @@ G7     ``prepare_condition_images`` and ``update_size`` of ``univa/serve/cli.py`
        G1-G3 (the module imports diffusers/flash-attn models) and executed on PNG files written here.
 G8     ``encode_prompt`` of ``univa/utils/denoiser_prompt_embedding_flux.py`` (imported normally) on the tiny seeded
        T5 / CLIP models of ``tests/tiny_text_encoders.py``: both encoders, T5 only, CLIP only.
+G9     the pure pieces of the training step, lifted out of ``train_denoiser.py`` with ``ast`` (the script imports
+       diffusers / deepspeed): ``get_trainable_params`` + ``check_param_is_in_components`` (:70-122) applied to the full
+       FLUX key list, the nested ``calculate_shift`` / ``apply_flux_schedule_shift`` (:960-986) and ``get_sigmas``
+       (:779-788) with stub scheduler / accelerator objects.
 G6     end-to-end outputs of THIS repo's oracle on tiny configs (self-pinned, labelled as such;
        guards the oracle against accidental edits -- it is not evidence about diffusers).
 
@@ -131,6 +135,48 @@ def g_prompt():
     np.savez(os.path.join(OUT, "prompt.npz"), **out)
 
 
+def g_train():
+    import math
+    import types
+    from typing import List
+    from gpt_image_edit_amd import flux_spec
+    tree = ast.parse(open(os.path.join(REF, "train_denoiser.py")).read())
+    want = {"get_trainable_params", "check_param_is_in_components", "calculate_shift", "apply_flux_schedule_shift", "get_sigmas"}
+    sched_cfg = types.SimpleNamespace(base_image_seq_len=256, max_image_seq_len=4096, base_shift=0.5, max_shift=1.15,
+                                      num_train_timesteps=1000)
+    sched = types.SimpleNamespace(config=sched_cfg, timesteps=torch.arange(1000, 0, -1, dtype=torch.float32),
+                                  sigmas=torch.linspace(1.0, 0.001, 1000) ** 1.5)
+    ns = {"torch": torch, "math": math, "List": List, "noise_scheduler_copy": sched,
+          "accelerator": types.SimpleNamespace(device="cpu")}
+    found = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in want and node.name not in found:
+            found[node.name] = node
+    assert set(found) == want, sorted(found)
+    for name in ("calculate_shift", "get_trainable_params", "check_param_is_in_components", "apply_flux_schedule_shift", "get_sigmas"):
+        exec(compile(ast.Module(body=[found[name]], type_ignores=[]), "<reference>", "exec"), ns)
+    out = {}
+    keys = sorted(flux_spec.flux_param_shapes(flux_spec.FLUX_KONTEXT_CONFIG))
+    for tag, kw in (("img", dict(only_img_branch=True)), ("all", dict(only_img_branch=False)),
+                    ("img_layers_0_1_12_19_30", dict(layers_to_train=[0, 1, 12, 19, 30], only_img_branch=True))):
+        comps = ns["get_trainable_params"](**kw)
+        mask = [ns["check_param_is_in_components"]("denoise_tower.denoiser." + k, comps) for k in keys]
+        out[f"trainable_{tag}"] = np.array(mask, dtype=np.bool_)
+        out[f"n_components_{tag}"] = np.array(len(comps))
+    out["n_keys"] = np.array(len(keys))
+    g = torch.Generator().manual_seed(11)
+    sig = torch.sigmoid(torch.randn(16, generator=g))
+    rows = []
+    for (h, w) in ((64, 64), (128, 128), (96, 160), (32, 48)):
+        rows.append(ns["apply_flux_schedule_shift"](sig.clone(), torch.zeros(1, 16, h, w)).numpy())
+    out["shift_in"], out["shift_hw"], out["shift_out"] = sig.numpy(), np.array([(64, 64), (128, 128), (96, 160), (32, 48)]), np.stack(rows)
+    ts = sched.timesteps[torch.tensor([0, 5, 999, 500])]
+    out["get_sigmas_t"] = ts.numpy()
+    out["get_sigmas_out"] = ns["get_sigmas"](ts, n_dim=4, dtype=torch.float32).numpy()
+    out["sched_timesteps"], out["sched_sigmas"] = sched.timesteps.numpy(), sched.sigmas.numpy()
+    np.savez_compressed(os.path.join(OUT, "train.npz"), **out)
+
+
 def g_anyres():
     sys.path.insert(0, REF)
     from univa.utils import anyres_util as ref  # importable: needs only PIL + math
@@ -220,6 +266,7 @@ if __name__ == "__main__":
     g_anyres()
     g_cli()
     g_prompt()
+    g_train()
     g_torch_ops()
     g_oracle_selfpin()
     for f in sorted(os.listdir(OUT)):

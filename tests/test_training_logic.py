@@ -1,0 +1,116 @@
+"""Training-step host logic (gpt_image_edit_amd/training.py) and its oracle (oracle/train.py) -- CPU only.
+
+Pinned to the reference's own functions through tests/golden/train.npz (oracle/make_golden.py::g_train lifts them out
+of train_denoiser.py); the optimiser arithmetic of the oracle is pinned to torch's own AdamW / clip_grad_norm_; the
+autograd gradient of the oracle loss is checked against a finite difference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpt_image_edit_amd import flux_spec, training
+from oracle import train as otrain
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "train.npz"))
+
+
+@pytest.mark.parametrize("impl", [training, otrain])
+def test_trainable_parameter_selection_matches_reference(golden, impl):
+    keys = sorted(flux_spec.flux_param_shapes(flux_spec.FLUX_KONTEXT_CONFIG))
+    assert len(keys) == int(golden["n_keys"])
+    for tag, kw in (("img", dict(only_img_branch=True)), ("all", dict(only_img_branch=False)),
+                    ("img_layers_0_1_12_19_30", dict(layers_to_train=[0, 1, 12, 19, 30], only_img_branch=True))):
+        comps = impl.get_trainable_params(**kw)
+        assert len(comps) == int(golden[f"n_components_{tag}"])
+        mask = np.array([impl.check_param_is_in_components("denoise_tower.denoiser." + k, comps) for k in keys])
+        assert np.array_equal(mask, golden[f"trainable_{tag}"]), tag
+    # the stage-2 configuration: attention projections, q/k norms and the modulation linears of every block, image side
+    names = training.trainable_names(keys)
+    assert len(names) == int(golden["trainable_img"].sum()) == 608
+    assert "transformer_blocks.0.attn.to_q.weight" in names and "transformer_blocks.0.attn.add_q_proj.weight" not in names
+    assert "single_transformer_blocks.37.norm.linear.bias" in names and "single_transformer_blocks.0.proj_mlp.weight" not in names
+    n_params = sum(int(np.prod(flux_spec.flux_param_shapes(flux_spec.FLUX_KONTEXT_CONFIG)[k])) for k in names)
+    assert 3.9e9 < n_params < 4.2e9   # ~4.04 B trainable with the projector
+
+
+@pytest.mark.parametrize("impl", [training, otrain])
+def test_sigma_shift_and_lookup_match_reference(golden, impl):
+    sig = torch.from_numpy(golden["shift_in"])
+    for (h, w), ref in zip(golden["shift_hw"], golden["shift_out"]):
+        got = impl.apply_flux_schedule_shift(sig.clone(), int(h), int(w))
+        np.testing.assert_allclose(got.numpy(), ref, rtol=1e-6, atol=1e-7)
+    st, ss = torch.from_numpy(golden["sched_timesteps"]), torch.from_numpy(golden["sched_sigmas"])
+    got = impl.get_sigmas(torch.from_numpy(golden["get_sigmas_t"]), st, ss, n_dim=4, dtype=torch.float32)
+    assert got.shape == (4, 1, 1, 1)
+    np.testing.assert_array_equal(got.numpy(), golden["get_sigmas_out"])
+
+
+def test_sampling_and_weighting():
+    g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    s_a, t_a = training.sample_sigmas(8, 128, 128, generator=g1)
+    s_b, t_b = otrain.sample_sigmas_continuous(8, 128, 128, generator=g2)
+    assert torch.equal(s_a, s_b) and torch.equal(t_a, t_b) and torch.equal(t_a, s_a * 1000.0)
+    assert float(s_a.min()) > 0 and float(s_a.max()) < 1
+    # the shift pushes sigmas towards 1 more strongly at higher resolution (mu = 1.15 at 4096 tokens, 0.5 at 256)
+    assert float(training.apply_flux_schedule_shift(torch.tensor([0.5]), 128, 128)) == pytest.approx(
+        np.exp(1.15) / (np.exp(1.15) + 1), rel=1e-6)
+    sig = torch.tensor([0.1, 0.5, 0.9])
+    for scheme in ("logit_normal", "mode", "none", "sigma_sqrt", "cosmap"):
+        assert torch.equal(training.loss_weighting(scheme, sig), otrain.compute_loss_weighting_for_sd3(scheme, sig))
+    assert torch.equal(training.loss_weighting("logit_normal", sig), torch.ones(3))
+    assert training.loss_weighting("logit_normal", sig, sigmas_as_weight=True) is sig
+    u = otrain.compute_density_for_timestep_sampling("mode", 1000, generator=torch.Generator().manual_seed(1))
+    assert 0.0 <= float(u.min()) and float(u.max()) <= 1.0
+
+
+def test_oracle_optimizer_matches_torch():
+    torch.manual_seed(3)
+    params = {f"p{i}": torch.randn(7, 5 + i) for i in range(3)}
+    ref = {k: torch.nn.Parameter(v.clone()) for k, v in params.items()}
+    opt = torch.optim.AdamW(ref.values(), lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+    state = {}
+    for step in range(3):
+        grads = {k: torch.randn_like(v) * (5.0 if step == 0 else 0.05) for k, v in params.items()}
+        for k in ref:
+            ref[k].grad = grads[k].clone()
+        norm_ref = torch.nn.utils.clip_grad_norm_(ref.values(), 1.0)
+        opt.step()
+        params, state, norm = otrain.adamw_step(params, grads, state, lr=1e-3, betas=(0.9, 0.99), eps=1e-8,
+                                                weight_decay=1e-2, max_grad_norm=1.0)
+        assert float(norm) == pytest.approx(float(norm_ref), rel=1e-6)
+        for k in params:
+            torch.testing.assert_close(params[k], ref[k].detach(), rtol=2e-6, atol=2e-7)
+
+
+def test_oracle_train_step_gradient_is_the_loss_gradient():
+    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=1, num_single_layers=1, num_attention_heads=2,
+               joint_attention_dim=64, pooled_projection_dim=32)
+    sd = {k: v.double() for k, v in flux_spec.synthetic_state(flux_spec.flux_param_shapes(cfg), seed=3).items()}
+    g = torch.Generator().manual_seed(2)
+    B, h, w = 2, 4, 6
+    batch = dict(model_input=torch.randn(B, 16, h, w, generator=g).double(), cond_latents=torch.randn(B, 16, h, w, generator=g).double(),
+                 noise=torch.randn(B, 16, h, w, generator=g).double(), sigmas=torch.tensor([0.3, 0.8]),
+                 prompt_embeds=torch.randn(B, 5, 64, generator=g).double(), pooled=torch.randn(B, 32, generator=g).double())
+    names = training.trainable_names(sorted(sd))
+    assert names and all(("attn." in n or "norm" in n) for n in names)
+    out = otrain.train_step(sd, names, batch, {}, flux_config=cfg, lr=1e-3)
+    assert torch.isfinite(out["loss"]) and float(out["grad_norm"]) > 0
+    # finite difference along one weight entry and along a whole-tensor direction
+    key = "transformer_blocks.0.attn.to_q.weight"
+    # (the oracle keeps the reference's fp32 islands -- RMSNorm statistics, RoPE, the loss -- so the difference quotient
+    # is only good to ~1e-7 / eps; step along the gradient itself for the largest signal)
+    d = out["grads"][key] / out["grads"][key].norm() * sd[key].norm()
+    eps = 3e-3
+    lp = otrain.denoiser_loss({**sd, key: sd[key] + eps * d}, flux_config=cfg, **batch)
+    lm = otrain.denoiser_loss({**sd, key: sd[key] - eps * d}, flux_config=cfg, **batch)
+    fd = float((lp - lm) / (2 * eps))
+    an = float((out["grads"][key] * d).sum())
+    print(f"directional derivative: autograd {an:.6e}, finite difference {fd:.6e}")
+    assert an > 0 and an == pytest.approx(fd, rel=5e-2)
+    # frozen tensors are untouched, trainable ones moved against their gradient
+    assert set(out["params"]) == set(names)
+    assert float(((out["params"][key] - sd[key]) * out["grads"][key]).sum()) < 0
