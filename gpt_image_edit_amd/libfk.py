@@ -57,6 +57,11 @@ SIGNATURES = {
     "fk_timestep_proj": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp]),
     "fk_add3_bf16": (c_i32, [c_vp] * 4 + [c_i64, c_vp]),
     "fk_true_cfg_bf16": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_i64, c_vp]),
+    "fk_reduce_ws_doubles": (c_i64, []),
+    "fk_flow_noisy_tokens_bf16": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64] + [c_i32] * 4 + [c_vp]),
+    "fk_flow_loss_bf16": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp] + [c_i32] * 4 + [c_vp]),
+    "fk_sumsq": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "fk_adamw_step": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp] + [c_f32] * 6 + [c_i32, c_i64, c_vp]),
     "fk_euler_step_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "fk_transpose_bf16": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "fk_softmax_rows": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp]),

@@ -332,3 +332,79 @@ def image_to_u8(img):
     libfk.check(libfk.load().fk_image_to_u8_nhwc(_ptr(img), int(img.dtype == torch.float32), _ptr(out), B, C, H, W,
                                                  _stream()), "fk_image_to_u8_nhwc")
     return out
+
+
+# ---- optimisation step of the denoiser (include/fk.h; reference train_denoiser.py:935-1181) ------------------------
+def _reduce_ws(device):
+    return torch.empty(libfk.load().fk_reduce_ws_doubles(), dtype=torch.float64, device=device)
+
+
+def _f32c(t, what):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise TypeError(f"{what} must be a contiguous fp32 tensor")
+
+
+def flow_noisy_tokens(x, noise, sigma, out=None):
+    """Packed bf16 tokens of (1 - sigma_b) * x + sigma_b * noise; x, noise fp32 [B,C,h,w], sigma fp32 [B].
+
+    ``out``: a [B, (h/2)(w/2), 4C] bf16 view with contiguous samples (e.g. the target half of the token buffer)."""
+    _need_cuda(x, noise, sigma, out)
+    _f32c(x, "x"); _f32c(noise, "noise"); _f32c(sigma, "sigma")
+    B, C, h, w = x.shape
+    if out is None:
+        out = torch.empty(B, (h // 2) * (w // 2), 4 * C, device=x.device, dtype=BF16)
+    if out.shape != (B, (h // 2) * (w // 2), 4 * C) or out.dtype != BF16 or out.stride(2) != 1 or out.stride(1) != 4 * C:
+        raise ValueError("out must be a [B, S, 4C] bf16 view with contiguous samples")
+    libfk.check(libfk.load().fk_flow_noisy_tokens_bf16(_ptr(x), _ptr(noise), _ptr(sigma), _ptr(out), out.stride(0), B, C,
+                                                       h, w, _stream()), "fk_flow_noisy_tokens_bf16")
+    return out
+
+
+def flow_loss(pred, x, noise, weight=None, want_grad=True):
+    """(loss fp64 [1], grad bf16 like pred or None) of mean(w_b * (unpack(pred) - (noise - x))^2); pred: packed bf16
+    [B, S, 4C] view with contiguous samples."""
+    _need_cuda(pred, x, noise, weight)
+    _f32c(x, "x"); _f32c(noise, "noise")
+    B, C, h, w = x.shape
+    if pred.shape != (B, (h // 2) * (w // 2), 4 * C) or pred.dtype != BF16 or pred.stride(2) != 1 or pred.stride(1) != 4 * C:
+        raise ValueError("pred must be a [B, S, 4C] bf16 view with contiguous samples")
+    if weight is not None:
+        _f32c(weight, "weight")
+    grad = torch.empty(pred.shape, device=pred.device, dtype=BF16) if want_grad else None
+    loss = torch.empty(1, dtype=torch.float64, device=pred.device)
+    libfk.check(libfk.load().fk_flow_loss_bf16(_ptr(pred), pred.stride(0), _ptr(x), _ptr(noise), _ptr(weight), _ptr(grad),
+                                               grad.stride(0) if want_grad else 0, _ptr(loss), _ptr(_reduce_ws(pred.device)),
+                                               B, C, h, w, _stream()), "fk_flow_loss_bf16")
+    return loss, grad
+
+
+def sumsq(tensors, out=None):
+    """fp64 [1]: sum of squares over a list of contiguous fp32 / bf16 tensors (the squared global gradient norm)."""
+    tensors = [tensors] if isinstance(tensors, torch.Tensor) else list(tensors)
+    _need_cuda(*tensors)
+    dev = tensors[0].device
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float64, device=dev)
+    ws = _reduce_ws(dev)
+    lib = libfk.load()
+    for i, t in enumerate(tensors):
+        if t.dtype not in (torch.float32, BF16) or not t.is_contiguous():
+            raise TypeError("sumsq takes contiguous fp32 / bf16 tensors")
+        libfk.check(lib.fk_sumsq(_ptr(t), int(t.dtype == BF16), t.numel(), int(i > 0), _ptr(out), _ptr(ws), _stream()),
+                    "fk_sumsq")
+    return out
+
+
+def adamw_step(master, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+               grad_sumsq=None, max_grad_norm=1.0, param_bf16=None):
+    """In-place AdamW update of the fp32 ``master`` (and the bf16 copy); ``grad_sumsq`` (fp64 [1]) enables clipping."""
+    _need_cuda(master, grad, exp_avg, exp_avg_sq, grad_sumsq, param_bf16)
+    for t, what in ((master, "master"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _f32c(t, what)
+    if grad.dtype not in (torch.float32, BF16) or not grad.is_contiguous() or grad.numel() != master.numel():
+        raise TypeError("grad must be a contiguous fp32 / bf16 tensor of the parameter's size")
+    libfk.check(libfk.load().fk_adamw_step(_ptr(master), _ptr(param_bf16), _ptr(grad), int(grad.dtype == BF16),
+                                           _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(grad_sumsq), float(max_grad_norm),
+                                           float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+                                           int(step), master.numel(), _stream()), "fk_adamw_step")
+    return master

@@ -154,6 +154,32 @@ int fk_add3_bf16(const void* a, const void* b, const void* c, void* out, int64_t
  * (univa/utils/flux_pipeline.py:1095): out = bf16(neg + bf16(scale * bf16(pos - neg))) over n elements
  * (the python-float scale stays fp32, as on the GPU the reference runs on); out may alias pos or neg. */
 int fk_true_cfg_bf16(const void* pos, const void* neg, void* out, float scale, int64_t n, fk_stream_t stream);
+/* ---- optimisation step of the denoiser (reference train_denoiser.py:935-1181); the MMDiT backward is not built yet */
+/* Doubles of workspace the two reductions below need. */
+int64_t fk_reduce_ws_doubles(void);
+/* noisy = (1 - sigma[b]) * x + sigma[b] * noise in fp32 (train_denoiser.py:994), rounded to bf16 and written as the
+ * 2x2-packed tokens FluxKontextPipeline.prepare_latents / _pack_latents produce (:1009-1027):
+ * x, noise fp32 [B, C, h, w]; tokens bf16, sample b at tokens + b*tokens_batch_stride, [ (h/2)(w/2), 4C ] row-major --
+ * the stride lets it land in the target half of the [target | condition] token buffer. */
+int fk_flow_noisy_tokens_bf16(const float* x, const float* noise, const float* sigma, void* tokens,
+                              int64_t tokens_batch_stride, int32_t B, int32_t C, int32_t h, int32_t w, fk_stream_t stream);
+/* Flow-matching loss and its gradient in one pass (train_denoiser.py:1096-1166, unpadded batch):
+ *   d = float(pred) - (noise - x)  on the packed bf16 prediction (the `_unpack_latents` index map is applied here),
+ *   loss[0] = sum(weight[b] * d^2) / (B*C*h*w)   (weight NULL = ones: the shipped logit_normal scheme),
+ *   grad    = bf16(2 * weight[b] * d / (B*C*h*w)) in pred's packed layout (NULL: loss only).
+ * ws: fk_reduce_ws_doubles() doubles; fixed-order two-stage sum, bit-identical from run to run. */
+int fk_flow_loss_bf16(const void* pred, int64_t pred_batch_stride, const float* x, const float* noise,
+                      const float* weight, void* grad, int64_t grad_batch_stride, double* loss, double* ws,
+                      int32_t B, int32_t C, int32_t h, int32_t w, fk_stream_t stream);
+/* out[0] = (accumulate ? out[0] : 0) + sum(g^2) over n fp32 (or bf16) elements: the global gradient norm of
+ * accelerator.clip_grad_norm_ (train_denoiser.py:1171-1177) accumulated tensor by tensor, in double. */
+int fk_sumsq(const void* g, int32_t g_is_bf16, int64_t n, int32_t accumulate, double* out, double* ws, fk_stream_t stream);
+/* torch.optim.AdamW's update (single-tensor form) on fp32 master weights, with the clipping coefficient
+ * min(1, max_grad_norm / (sqrt(grad_sumsq[0]) + 1e-6)) folded into the gradient read (grad_sumsq NULL: no clipping)
+ * and the bf16 copy the forward pass reads written in the same pass (param_bf16 NULL: none).  step counts from 1. */
+int fk_adamw_step(float* master, void* param_bf16, const void* grad, int32_t grad_is_bf16, float* exp_avg,
+                  float* exp_avg_sq, const double* grad_sumsq, float max_grad_norm, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int32_t step, int64_t n, fk_stream_t stream);
 /* FlowMatchEulerDiscreteScheduler.step fused with the pipeline's `noise_pred[:, :S_tgt]` slice:
  *   x[b, s, :] = bf16(float(x) + float(bf16(bf16(dsigma) * v[b, s, :])))   for s < S_tgt
  * x rows at x + b*x_batch_stride + s*C, v rows at v + b*v_batch_stride + s*C.

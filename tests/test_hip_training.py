@@ -1,0 +1,91 @@
+"""GPU parity of the optimisation step's HBM-bound kernels (csrc/train_kernels.hip) against oracle/train.py and torch's
+own AdamW / clip_grad_norm_.  The MMDiT backward has no kernels yet."""
+import pytest
+import torch
+
+from conftest import report
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd import ops as o
+    return o
+
+
+def _batch(B=3, C=16, h=12, w=20, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(B, C, h, w, generator=g), torch.randn(B, C, h, w, generator=g),
+            torch.sigmoid(torch.randn(B, generator=g)))
+
+
+def test_noisy_tokens_match_oracle(ops):
+    from oracle import helpers
+    x, noise, sigma = _batch()
+    B, C, h, w = x.shape
+    ref = helpers.pack_latents(((1.0 - sigma.view(B, 1, 1, 1)) * x + sigma.view(B, 1, 1, 1) * noise).to(BF))
+    got = ops.flow_noisy_tokens(x.cuda(), noise.cuda(), sigma.cuda())
+    assert torch.equal(got.cpu(), ref)
+    # written straight into the target half of a [target | condition] token buffer
+    S = (h // 2) * (w // 2)
+    buf = torch.zeros(B, 2 * S, 4 * C, dtype=BF, device="cuda")
+    ops.flow_noisy_tokens(x.cuda(), noise.cuda(), sigma.cuda(), out=buf[:, :S])
+    assert torch.equal(buf[:, :S].cpu(), ref) and float(buf[:, S:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_flow_loss_and_gradient_match_autograd(ops, weighted):
+    from oracle import helpers, train as otrain
+    x, noise, sigma = _batch(seed=1)
+    B, C, h, w = x.shape
+    pred = torch.randn(B, (h // 2) * (w // 2), 4 * C, generator=torch.Generator().manual_seed(2)).to(BF)
+    wt = (sigma ** -2.0) if weighted else None
+    p = pred.clone().requires_grad_(True)
+    unpacked = helpers.unpack_latents(p, h * 8, w * 8)
+    weighting = wt.view(B, 1, 1, 1) if weighted else torch.ones(B, 1, 1, 1)
+    ref = otrain.flow_matching_loss(unpacked, x, noise, weighting)
+    ref.backward()
+    loss, grad = ops.flow_loss(pred.cuda(), x.cuda(), noise.cuda(), wt.cuda() if weighted else None)
+    assert float(loss) == pytest.approx(float(ref.detach()), rel=2e-6)
+    d = report(f"flow_loss grad (weighted={weighted})", grad, p.grad)
+    # fp32 gradient rounded to bf16 on both sides; the products may differ in the last fp32 bit
+    assert float(d.max()) <= 2 ** -8 * float(p.grad.float().abs().max())
+    assert float((grad.cpu() == p.grad).float().mean()) > 0.99
+    again, _ = ops.flow_loss(pred.cuda(), x.cuda(), noise.cuda(), wt.cuda() if weighted else None, want_grad=False)
+    assert float(again) == float(loss)   # fixed-order reduction
+
+
+def test_adamw_with_clipping_matches_torch(ops):
+    torch.manual_seed(4)
+    shapes = [(257, 33), (1000,), (64, 64, 3)]
+    ref = [torch.nn.Parameter(torch.randn(s) * 0.02) for s in shapes]
+    master = [p.detach().clone().cuda() for p in ref]
+    m = [torch.zeros_like(t) for t in master]
+    v = [torch.zeros_like(t) for t in master]
+    bf = [torch.empty_like(t, dtype=BF) for t in master]
+    opt = torch.optim.AdamW(ref, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+    for step in range(1, 4):
+        grads = [torch.randn(s) * (3.0 if step == 1 else 0.01) for s in shapes]
+        for p, g in zip(ref, grads):
+            p.grad = g.clone()
+        norm_ref = torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        opt.step()
+        gd = [g.cuda() for g in grads]
+        ss = ops.sumsq(gd)
+        assert float(ss.sqrt()) == pytest.approx(float(norm_ref), rel=1e-6)
+        for i in range(len(shapes)):
+            ops.adamw_step(master[i], gd[i], m[i], v[i], step, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2,
+                           grad_sumsq=ss, max_grad_norm=1.0, param_bf16=bf[i])
+        for i, p in enumerate(ref):
+            torch.testing.assert_close(master[i].cpu(), p.detach(), rtol=3e-6, atol=3e-8)
+            assert torch.equal(bf[i].cpu(), master[i].cpu().to(BF))
+    # bf16 gradients (what a bf16 backward hands over) and no clipping
+    g16 = [torch.randn(s).to(BF) for s in shapes]
+    before = [t.clone() for t in master]
+    for i in range(len(shapes)):
+        ops.adamw_step(master[i], g16[i].cuda(), m[i], v[i], 4, lr=1e-3, betas=(0.9, 0.99), weight_decay=0.0)
+    assert all(not torch.equal(a, b) for a, b in zip(before, master))
