@@ -174,7 +174,30 @@ def g_train():
     out["get_sigmas_t"] = ts.numpy()
     out["get_sigmas_out"] = ns["get_sigmas"](ts, n_dim=4, dtype=torch.float32).numpy()
     out["sched_timesteps"], out["sched_sigmas"] = sched.timesteps.numpy(), sched.sigmas.numpy()
+    # self-pin of the step oracle (guards oracle/train.py against accidental edits; not evidence about the reference)
+    from oracle import train as otrain
+    from gpt_image_edit_amd import training
+    cfg, sd, batch = _tiny_train_case()
+    names = training.trainable_names(sorted(sd))
+    res = otrain.train_step(sd, names, batch, {}, flux_config=cfg, lr=1e-3)
+    out["step_loss"] = res["loss"].numpy()
+    out["step_grad_norm"] = res["grad_norm"].numpy()
+    out["step_grad_to_q"] = res["grads"]["transformer_blocks.0.attn.to_q.weight"][:4, :8].numpy()
+    out["step_new_norm_q"] = res["params"]["single_transformer_blocks.0.attn.norm_q.weight"].numpy()
     np.savez_compressed(os.path.join(OUT, "train.npz"), **out)
+
+
+def _tiny_train_case():
+    from gpt_image_edit_amd import flux_spec
+    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=1, num_single_layers=1, num_attention_heads=2,
+               joint_attention_dim=64, pooled_projection_dim=32)
+    sd = flux_spec.synthetic_state(flux_spec.flux_param_shapes(cfg), seed=3)
+    g = torch.Generator().manual_seed(2)
+    B, h, w = 2, 4, 6
+    batch = dict(model_input=torch.randn(B, 16, h, w, generator=g), cond_latents=torch.randn(B, 16, h, w, generator=g),
+                 noise=torch.randn(B, 16, h, w, generator=g), sigmas=torch.tensor([0.3, 0.8]),
+                 prompt_embeds=torch.randn(B, 5, 64, generator=g), pooled=torch.randn(B, 32, generator=g))
+    return cfg, sd, batch
 
 
 def g_anyres():

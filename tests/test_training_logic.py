@@ -114,3 +114,22 @@ def test_oracle_train_step_gradient_is_the_loss_gradient():
     # frozen tensors are untouched, trainable ones moved against their gradient
     assert set(out["params"]) == set(names)
     assert float(((out["params"][key] - sd[key]) * out["grads"][key]).sum()) < 0
+
+
+def test_oracle_train_step_selfpin(golden):
+    # same tiny case as oracle/make_golden.py::_tiny_train_case, fp32
+    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=1, num_single_layers=1, num_attention_heads=2,
+               joint_attention_dim=64, pooled_projection_dim=32)
+    sd = flux_spec.synthetic_state(flux_spec.flux_param_shapes(cfg), seed=3)
+    g = torch.Generator().manual_seed(2)
+    B, h, w = 2, 4, 6
+    batch = dict(model_input=torch.randn(B, 16, h, w, generator=g), cond_latents=torch.randn(B, 16, h, w, generator=g),
+                 noise=torch.randn(B, 16, h, w, generator=g), sigmas=torch.tensor([0.3, 0.8]),
+                 prompt_embeds=torch.randn(B, 5, 64, generator=g), pooled=torch.randn(B, 32, generator=g))
+    res = otrain.train_step(sd, training.trainable_names(sorted(sd)), batch, {}, flux_config=cfg, lr=1e-3)
+    np.testing.assert_allclose(res["loss"].numpy(), golden["step_loss"], rtol=1e-5)
+    np.testing.assert_allclose(res["grad_norm"].numpy(), golden["step_grad_norm"], rtol=1e-4)
+    np.testing.assert_allclose(res["grads"]["transformer_blocks.0.attn.to_q.weight"][:4, :8].numpy(), golden["step_grad_to_q"],
+                               rtol=1e-3, atol=1e-8)
+    np.testing.assert_allclose(res["params"]["single_transformer_blocks.0.attn.norm_q.weight"].numpy(),
+                               golden["step_new_norm_q"], rtol=1e-6)
