@@ -50,7 +50,7 @@ def test_t5_only_and_clip_only_variants(golden):
         assert prompt_embedding.encode_prompt([None, encoders[1]], [None, None], PROMPTS[0], 16, device="cpu",
                                               text_input_ids_list=[None, ids]) == (None, None)
         with pytest.raises(ValueError, match="text_input_ids must be provided"):
-            prompt_embedding._encode_prompt_with_t5(encoders[1], None, prompt=PROMPTS[0])
+            prompt_embedding._run_encoder(prompt_embedding.T5_SEQUENCE, encoders[1], None, [PROMPTS[0]], 16, "cpu", 1, None)
 
 
 def test_pipeline_encode_prompt_string_path():
