@@ -1,0 +1,121 @@
+"""world_size-2 CPU test (gloo) of the ZeRO-2 style sharded AdamW (gpt_image_edit_amd/zero.py): reduce-scatter of fp32
+gradients, global-norm clipping, update of this rank's slice, all-gather of the bf16 parameters -- against
+torch.optim.AdamW + clip_grad_norm_ on the rank-averaged gradients in one process.  The update arithmetic is a torch
+stand-in defined here (on the GPU it is csrc/train_kernels.hip, covered by tests/test_hip_training.py)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+BF = torch.bfloat16
+SHAPES = {"blocks.0.attn.to_q.weight": (33, 17), "blocks.0.attn.to_q.bias": (33,), "blocks.1.norm.linear.weight": (50, 7),
+          "blocks.1.attn.norm_q.weight": (128,)}
+HP = dict(lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+
+
+class TorchKernels:
+    """Same contract as ops.sumsq / ops.adamw_step, in plain torch (test-only stand-in)."""
+
+    @staticmethod
+    def sumsq(t):
+        return (t.double() ** 2).sum().reshape(1)
+
+    @staticmethod
+    def adamw_step(master, grad, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay, grad_sumsq=None,
+                   max_grad_norm=1.0, param_bf16=None):
+        g = grad.float()
+        if grad_sumsq is not None:
+            g = g * torch.clamp(max_grad_norm / (grad_sumsq.sqrt().float() + 1e-6), max=1.0)
+        master.mul_(1 - lr * weight_decay)
+        exp_avg.lerp_(g, 1 - betas[0])
+        exp_avg_sq.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+        denom = (exp_avg_sq.sqrt() / (1 - betas[1] ** step) ** 0.5).add_(eps)
+        master.addcdiv_(exp_avg, denom, value=-lr / (1 - betas[0] ** step))
+        if param_bf16 is not None:
+            param_bf16.copy_(master)
+
+
+def _params(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return {n: (torch.randn(s, generator=g) * 0.05).to(BF) for n, s in SHAPES.items()}
+
+
+def _grads(rank, step):
+    g = torch.Generator().manual_seed(100 + 10 * step + rank)
+    scale = 2.0 if step == 0 else 0.01      # step 0 is clipped, the later ones are not
+    return {n: torch.randn(s, generator=g) * scale for n, s in SHAPES.items()}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gpt_image_edit_amd.zero import ShardedAdamW
+    opt = ShardedAdamW(_params(), max_grad_norm=1.0, kernels=TorchKernels, **HP)
+    norms = []
+    for step in range(3):
+        for n, g in _grads(rank, step).items():
+            opt.grads[n].copy_(g)
+        norms.append(float(opt.step()))
+    q.put((rank, {n: p.clone() for n, p in opt.params.items()}, norms, opt.state_bytes(), opt.layout.slice_numel))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_adamw_gloo_world2_matches_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference: fp32 masters of the bf16 start values, rank-averaged gradients
+    ref = {n: torch.nn.Parameter(p.float()) for n, p in _params().items()}
+    opt = torch.optim.AdamW(ref.values(), **HP)
+    ref_norms = []
+    for step in range(3):
+        gs = [_grads(r, step) for r in range(world)]
+        for n, p in ref.items():
+            p.grad = sum(g[n] for g in gs) / world
+        ref_norms.append(float(torch.nn.utils.clip_grad_norm_(ref.values(), 1.0)))
+        opt.step()
+    (_, p0, n0, bytes0, slice0), (_, p1, n1, _, _) = res
+    total = sum(torch.tensor(s).prod().item() for s in SHAPES.values())
+    assert slice0 % 64 == 0 and slice0 * world >= total and bytes0 == (slice0 * world * 6, slice0 * 16)
+    for a, b, c in zip(n0, n1, ref_norms):
+        assert a == b and abs(a - c) <= 1e-5 * c
+    assert ref_norms[0] > 1.0 > ref_norms[1]
+    for n in SHAPES:
+        assert torch.equal(p0[n], p1[n])                                   # every rank ends with the same weights
+        torch.testing.assert_close(p0[n].float(), ref[n].detach().to(BF).float(), rtol=0, atol=2 ** -8 * 0.3)
+        assert float((p0[n] == ref[n].detach().to(BF)).float().mean()) > 0.97
+
+
+def test_flat_layout_single_process():
+    from gpt_image_edit_amd.zero import FlatLayout, ShardedAdamW
+    L = FlatLayout(SHAPES, 8)
+    assert L.slice_numel % 64 == 0 and L.total == 8 * L.slice_numel >= L.used
+    flat = torch.arange(L.total, dtype=torch.float32)
+    v = L.views(flat)
+    assert sorted(v) == L.names and all(v[n].shape == tuple(SHAPES[n]) for n in SHAPES)
+    spans = sorted((o, o + k) for o, k, _ in L.offsets.values())
+    assert spans[0][0] == 0 and all(a[1] == b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] == L.used
+    # world 1: no collectives; views alias the flat buffers
+    opt = ShardedAdamW(_params(), kernels=TorchKernels, **HP)
+    before = {n: p.clone() for n, p in opt.params.items()}
+    for n in SHAPES:
+        opt.grads[n].fill_(0.5)
+    opt.step()
+    assert all(not torch.equal(before[n], opt.params[n]) for n in SHAPES) and float(opt.flat_grad.abs().sum()) == 0
