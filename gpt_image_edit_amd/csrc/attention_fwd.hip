@@ -143,13 +143,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
   // per wave and tile, on the critical VALU path: the counters show this kernel's MFMA and VALU phases added, not
   // overlapped).  Here every row keeps a FIXED reference m_ref = its row maximum over the FIRST KV tile, so
   // p = exp2(s - m_ref) may exceed 1 when later tiles hold larger scores -- harmless for the fp32 sums and for the
-  // bf16 P fragments (same relative precision) while the excess stays below 2^TAU.  If some row ever outgrows its
-  // reference by more than TAU (adversarial inputs; the tests build one) the workgroup finishes the pass and
-  // repeats it with the exact row maxima from a K-only pre-pass: the result is then the plain two-pass softmax.
-  constexpr float TAU = 40.0f;   // log2 units: p <= 2^40, row sums <= 2^55 for 32768 keys
-  // The reference sits REF_BIAS above the first block's maximum: later scores may then grow by TAU + REF_BIAS = 64 log2
-  // units (44 nats) before a restart is needed, and the first block's own probabilities (>= 2^-24 at its maximum)
-  // are still far from fp32 / bf16 underflow.
+  // bf16 P fragments (bf16 has fp32's exponent range and the same relative precision at every magnitude) as long as
+  // nothing overflows.  If some row ever outgrows its reference by more than the fp32 exponent range (adversarial
+  // inputs; the tests build one) its sums turn inf / NaN; that is detected once, after the pass, and the workgroup
+  // repeats the pass with the exact row maxima from a K-only pre-pass: the result is then the plain two-pass softmax.
+  // The reference sits REF_BIAS above the first block's maximum: later scores may then grow by ~127 + 24 log2 units
+  // (~100 nats) before a restart is needed, and the first block's own probabilities (>= 2^-24 at its maximum) are
+  // still far from fp32 / bf16 underflow.
   constexpr float REF_BIAS = 24.0f;
   float m_ref = 0.f, l_run = 0.f;
   bool overflow = false;         // wave-uniform
@@ -232,12 +232,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16_t s = scores(sb, kb, kt, mask_tag);
-      const float mx = block_max(s);
       if constexpr (FIRST) {
-        if (kb == 0) m_ref = mx + REF_BIAS;   // reference = row maximum over the first 32 keys + bias
-        else overflow = overflow || (__builtin_amdgcn_ballot_w64(mx > m_ref + TAU) != 0);
-      } else {
-        overflow = overflow || (__builtin_amdgcn_ballot_w64(mx > m_ref + TAU) != 0);
+        if (kb == 0) m_ref = block_max(s) + REF_BIAS;   // reference = row maximum over the first 32 keys + bias
       }
       const float nm = -m_ref;
       // ---- softmax numerators (log2 domain; raw v_exp_f32, denormal results may flush) ----------------------
@@ -320,6 +316,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
     }
     // the waves share the K/V ring and its barriers: they repeat the pass together or not at all
     if (attempt == 0) {
+      // Did some row outgrow the exponent range?  No per-tile maximum is kept for this (that was ~1 VALU instruction
+      // per score, a fifth of the softmax work): a score more than ~127 log2 units above the reference makes its
+      // numerator +inf, which poisons the row's sum and its O (inf, or NaN from inf * 0) -- visible here, once.
+      float mag = fabsf(l_run);
+#pragma unroll
+      for (int df = 0; df < 4; ++df)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mag += fabsf(o[df][r]);
+      overflow = __builtin_amdgcn_ballot_w64(!(mag <= 3.0e38f)) != 0;
       __syncthreads();
       if (tid == 0) *wg_flag = 0;
       __syncthreads();
