@@ -10,14 +10,25 @@ canonical synthetic shapes of SURVEY.md section 8(d): S_txt = 512, true 512^2 ta
 (`max_area = 512^2`, `_auto_resize = False`), S = 2560, guidance 3.5, full 19 + 38 block FLUX-Kontext
 transformer and the FLUX VAE with seeded random-init weights (no checkpoints offline).
 The prompt encoders (Qwen2.5-VL / T5 / CLIP, reused as-is on PyTorch-ROCm) are upstream of the path:
-their outputs (prompt_embeds, pooled) are inputs here.
+their outputs (prompt_embeds, pooled) are inputs here; their cost is reported separately (`extra.prompt_encode`).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     : the dominant kernel family (bf16 MFMA GEMM, all epilogues): algorithmic FLOPs of its
                  launches in one edit / their summed duration, measured live with HIP events on the
-                 launch stream in an instrumented edit after the timed region;
-  cpu_baseline : the CPU oracle (fp32 torch restatement, `oracle/`) timed on this box's host cores on
-                 a bounded sample (N = 1, rank 0 only).
+                 launch stream in an instrumented edit after the timed region; `traffic` = HBM bytes per
+                 launch of the family's dominant kernel from the committed PMC passes (profiles/r02_traffic.json);
+  cpu_baseline : the CPU oracle (fp32 torch restatement, `oracle/`) timed on this box's host cores
+                 (N = 1, rank 0 only): ONE full-depth denoise step at the workload's size + VAE encode + decode,
+                 i.e. BASELINE.json configs[0] with 1 of its 4 steps executed; the 4- and 28-step figures are
+                 stated as extrapolations of that;
+  extra        : the 1024 x 1024 half of BASELINE.json's metric (`single_1024x1024_28step`, same run, after the
+                 timed region: 1 warm-up + 3 timed edits per GPU, its own roofline) and the prompt-encode time
+                 T_prompt / T_e2e of SURVEY.md section 8(d);
+  dist         : world size and backend as torch.distributed reports them.
+
+Other workloads (`--workload`): cfg 3 (`cfg3_batch32_1024x1024_28step`), cfg 4 (`cfg4_batch256_dp8`: 32 edits per
+GPU, weak; `--scaling strong` keeps `--global-batch` fixed and shards it `items[rank::world]` like the reference's
+eval generators), and `cfg4_slice4_1024x1024_28step` (a 4-per-GPU slice of cfg 4 that fits short runs).
 """
 import argparse
 import json
@@ -34,12 +45,16 @@ sys.path.insert(0, ROOT)
 BF = torch.bfloat16
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak, MI355X_MICROARCH.md
 WORKLOADS = {
-    # name: (batch, height, width, cond_h, cond_w, S_txt)
+    # name: (batch per GPU, height, width, cond_h, cond_w, S_txt)
     "cfg2_single_512x512_28step": (1, 512, 512, 512, 512, 512),
     "cfg2cli_512x512_cond1mp_28step": (1, 512, 512, 1024, 1024, 512),
     "cfg3_batch32_1024x1024_28step": (32, 1024, 1024, 1024, 1024, 512),
     "single_1024x1024_28step": (1, 1024, 1024, 1024, 1024, 512),
+    "cfg4_batch256_dp8": (32, 1024, 1024, 1024, 1024, 512),
+    "cfg4_slice4_1024x1024_28step": (4, 1024, 1024, 1024, 1024, 512),
 }
+EXTRA_WORKLOAD = "single_1024x1024_28step"
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
 def build_pipeline(device, n_double=19, n_single=38):
@@ -53,8 +68,10 @@ def build_pipeline(device, n_double=19, n_single=38):
     return FluxKontextPipeline(tr, vae)
 
 
-def make_inputs(workload, device, seed):
+def make_inputs(workload, device, seed, batch=None):
     B, H, W, Hc, Wc, S_txt = WORKLOADS[workload]
+    if batch is not None:
+        B = batch
     g = torch.Generator(device=device).manual_seed(seed)
     cond = (torch.randint(0, 256, (B, 3, Hc, Wc), generator=g, device=device).float() / 255.0 - 0.5) / 0.5
     emb = torch.randn(B, S_txt, 4096, generator=g, device=device).to(BF)
@@ -121,42 +138,155 @@ def instrumented_edit(pipe, inp):
     return out
 
 
-def cpu_baseline(workload, budget_blocks=(1, 1)):
-    """Oracle (fp32 torch on the host) on a bounded sample: `budget_blocks` double + single MMDiT blocks
-    at the workload's sequence length, extrapolated to 19 + 38 blocks x 28 steps (the MMDiT is 99.8 % of
-    the edit's FLOPs; VAE and embedders are left out of the estimate, which therefore favours the CPU)."""
+def roofline_of(fam, workload):
+    """`roofline` object of the bench line from the instrumented edit's family sums (+ the committed PMC traffic)."""
+    gm = fam["gemm"]
+    traffic, traffic_note = None, None
+    if os.path.exists(TRAFFIC_FILE):
+        try:
+            tr = json.load(open(TRAFFIC_FILE))
+            ent = tr.get("gemm", {}).get(workload) or tr.get("gemm", {}).get("default")
+            if ent:
+                traffic, traffic_note = ent["hbm_bytes_per_launch"], ent.get("note")
+        except Exception as e:  # a malformed side file must not cost the bench line
+            traffic_note = f"unreadable {TRAFFIC_FILE}: {e}"
+    rl = {
+        "kernel": "gemm8_kernel<*> + gemm2_kernel<*> + gemm5_kernel<*> + gemm_bf16_kernel<*> (bf16 MFMA GEMM family: all MMDiT / VAE linears)",
+        "bound": "mfma", "achieved": gm["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+        "frac": gm["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
+        "launches_per_edit": gm["launches"], "ms_per_edit": gm["ms"], "algorithmic_tflop_per_edit": gm["flops"] / 1e12,
+        "other_kernels": {k: {"ms_per_edit": v["ms"], "tflops": v["tflops"], "launches": v["launches"]}
+                          for k, v in fam.items() if k != "gemm"},
+    }
+    if traffic_note:
+        rl["traffic_note"] = traffic_note
+    return rl
+
+
+def cpu_baseline(workload, mode="full"):
+    """The CPU oracle (fp32 torch on the host cores) on a bounded sample of the workload.
+
+    mode "full": BASELINE.json configs[0] (the reference's CPU diffusers path through the cli-equivalent plumbing:
+    512^2, 4 steps, fp32) with ONE of its denoise steps executed at full depth -- embedders, 19 double + 38 single
+    blocks at the workload's sequence length, output head -- plus the VAE encode of the condition image and the VAE
+    decode; the 19 / 38 blocks of a kind run on one shared seeded weight set (same arithmetic, 2 GB instead of 47.6 GB).  The
+    4-step (cfg 1) and 28-step (cfg 2) figures are extrapolations `t_enc + n * t_step + t_dec`, labelled as such.
+    mode "blocks": 1 double + 1 single block only (a few seconds), extrapolated x(19, 38) x 28.
+    """
     from gpt_image_edit_amd import flux_spec
     from oracle import mmdit
-    B, H, W, Hc, Wc, S_txt = WORKLOADS[workload]
+    from oracle import vae as ovae
+    from oracle.helpers import prepare_latent_image_ids
+    _, H, W, Hc, Wc, S_txt = WORKLOADS[workload]
     B = 1  # per-image cost; the CPU has no batching advantage at these sizes
     S_img = (H // 16) * (W // 16) + (Hc // 16) * (Wc // 16)
-    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=1, num_single_layers=1)
-    shapes = {k: v for k, v in flux_spec.flux_param_shapes(cfg).items()
-              if k.startswith("transformer_blocks.0.") or k.startswith("single_transformer_blocks.0.")}
-    sd = flux_spec.synthetic_state(shapes, seed=5)
+    full = flux_spec.flux_param_shapes(flux_spec.FLUX_KONTEXT_CONFIG)
     g = torch.Generator().manual_seed(0)
-    h = torch.randn(B, S_img, 3072, generator=g)
-    c = torch.randn(B, S_txt, 3072, generator=g)
-    temb = torch.randn(B, 3072, generator=g)
-    from oracle.helpers import prepare_latent_image_ids
     ids = torch.cat([torch.zeros(S_txt, 3), prepare_latent_image_ids(1, S_img)])
     rope = mmdit.rope_tables(ids)
+    common = dict(unit="images/s", cores=torch.get_num_threads(), kind="port", host_cpus=os.cpu_count())
+
+    def block_state(prefix, seed=5):
+        return flux_spec.synthetic_state({k: v for k, v in full.items() if k.startswith(prefix)}, seed=seed)
+
     with torch.no_grad():
+        if mode == "blocks":
+            h = torch.randn(B, S_img, 3072, generator=g)
+            c = torch.randn(B, S_txt, 3072, generator=g)
+            temb = torch.randn(B, 3072, generator=g)
+            sd = block_state("transformer_blocks.0.")
+            sd.update(block_state("single_transformer_blocks.0."))
+            t0 = time.perf_counter()
+            mmdit.double_block(sd, "transformer_blocks.0.", h, c, temb, rope)
+            t1 = time.perf_counter()
+            mmdit.single_block(sd, "single_transformer_blocks.0.", torch.cat([c, h], dim=1), temb, rope)
+            t2 = time.perf_counter()
+            t_d, t_s = t1 - t0, t2 - t1
+            t_edit = 28 * (19 * t_d + 38 * t_s)
+            return dict(common, value=1.0 / t_edit,
+                        sample=f"fp32 oracle, 1 double + 1 single MMDiT block fwd at S={S_txt + S_img} (B=1): {t_d:.2f}s / "
+                               f"{t_s:.2f}s per block, EXTRAPOLATED x(19,38) blocks x28 steps = {t_edit:.0f}s per image "
+                               f"(VAE + embedders excluded)")
+        # ---- one full-depth denoise step ------------------------------------------------------------------------
+        # (the blocks of a kind share ONE seeded weight set, generated outside the timed span: the seeded generator
+        #  is single-threaded and would cost more than the arithmetic; the data dependence through all 57 blocks is kept)
+        tokens = torch.randn(B, S_img, 64, generator=g)
+        enc = torch.randn(B, S_txt, 4096, generator=g)
+        pooled = torch.randn(B, 768, generator=g)
+        sd = block_state("x_embedder.")
+        for pre in ("context_embedder.", "time_text_embed.", "norm_out.", "proj_out.", "transformer_blocks.0.",
+                    "single_transformer_blocks.0."):
+            sd.update(block_state(pre))
         t0 = time.perf_counter()
-        for _ in range(budget_blocks[0]):
-            c2, h2 = mmdit.double_block(sd, "transformer_blocks.0.", h, c, temb, rope)
-        t1 = time.perf_counter()
+        h = mmdit.linear(sd, "x_embedder", tokens)
+        c = mmdit.linear(sd, "context_embedder", enc)
+        temb = mmdit.time_text_embed(sd, torch.full((B,), 500.0), torch.full((B,), 3500.0), pooled)
+        for i in range(19):
+            c, h = mmdit.double_block(sd, "transformer_blocks.0.", h, c, temb, rope)
         s = torch.cat([c, h], dim=1)
-        for _ in range(budget_blocks[1]):
-            mmdit.single_block(sd, "single_transformer_blocks.0.", s, temb, rope)
-        t2 = time.perf_counter()
-    t_d, t_s = (t1 - t0) / budget_blocks[0], (t2 - t1) / budget_blocks[1]
-    t_edit = 28 * (19 * t_d + 38 * t_s)
-    return dict(value=1.0 / t_edit, unit="images/s", cores=torch.get_num_threads(), kind="port",
-                host_cpus=os.cpu_count(),
-                sample=f"fp32 oracle, {budget_blocks[0]} double + {budget_blocks[1]} single MMDiT block fwd at "
-                       f"S={S_txt + S_img} (B=1): {t_d:.2f}s / {t_s:.2f}s per block, extrapolated x(19,38) blocks "
-                       f"x28 steps = {t_edit:.0f}s per image (VAE + embedders excluded)")
+        for i in range(38):
+            s = mmdit.single_block(sd, "single_transformer_blocks.0.", s, temb, rope)
+        e = mmdit.linear(sd, "norm_out.linear", torch.nn.functional.silu(temb))
+        scale, shift = e.chunk(2, dim=1)
+        hh = mmdit.layer_norm(s[:, S_txt:]) * (1 + scale)[:, None, :] + shift[:, None, :]
+        v = mmdit.linear(sd, "proj_out", hh)
+        t_step = time.perf_counter() - t0
+        # ---- VAE either side (weights generated outside the timed spans: "model load excluded") ------------------
+        sd_v = flux_spec.synthetic_state(flux_spec.vae_param_shapes(), seed=1)
+        img = torch.rand(B, 3, Hc, Wc, generator=g) * 2 - 1
+        t0 = time.perf_counter()
+        ovae.encode_for_pipeline(sd_v, img)
+        t_enc = time.perf_counter() - t0
+        z = torch.randn(B, 16, H // 8, W // 8, generator=g)
+        t0 = time.perf_counter()
+        ovae.decode_for_pipeline(sd_v, z)
+        t_dec = time.perf_counter() - t0
+    assert torch.isfinite(v).all()
+    t4, t28 = t_enc + 4 * t_step + t_dec, t_enc + 28 * t_step + t_dec
+    flops_step = mmdit.flops_forward(S_txt + S_img)
+    return dict(common, value=1.0 / t28, cfg1_4step_images_per_s=1.0 / t4,
+                t_step_s=t_step, t_vae_encode_s=t_enc, t_vae_decode_s=t_dec, gflops_step=flops_step / t_step / 1e9,
+                sample=f"fp32 oracle through the cli-equivalent plumbing at S={S_txt + S_img} (B=1): ONE full-depth denoise "
+                       f"step (embedders + 19 double + 38 single blocks + head) {t_step:.1f}s + VAE encode {t_enc:.1f}s + VAE decode {t_dec:.1f}s executed; "
+                       f"`value` = 1 / (enc + 28 x step + dec) = 1 / {t28:.0f}s is an EXTRAPOLATION of that one step "
+                       f"(cfg 1, 4 steps: 1 / {t4:.0f}s)")
+
+
+def prompt_encode_time(device, batch=1):
+    """T_prompt of SURVEY.md section 8(d): the Qwen2.5-VL-7B forward(s) + projector the reference cli runs per edit
+    (`univa/serve/cli.py:199-234`: two VLM forwards, the second with the condition image), random-init weights,
+    reused as-is from `transformers` on PyTorch-ROCm -- NOT part of `value`."""
+    from gpt_image_edit_amd.qwen_adaptor import bench_prompt_encode
+    return bench_prompt_encode(device, batch=batch)
+
+
+def timed_edits(pipe, inp, steps, warmup, world, device, backend):
+    from gpt_image_edit_amd import dp
+
+    def one_step():
+        out = run_edit(pipe, inp)
+        if world > 1:
+            dp.all_gather_latents(out.latents)
+        return out
+
+    for _ in range(warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out.images.float()).all(), "non-finite output image"
+    return elapsed
 
 
 def main():
@@ -165,9 +295,16 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg2_single_512x512_28step", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the workload's batch per GPU; strong: --global-batch fixed, sharded items[rank::world]")
+    ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: total edits per step (default 8 x batch)")
+    ap.add_argument("--cpu-baseline", default="full", choices=["full", "blocks", "none"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 1024^2 and prompt-encode extras")
     args = ap.parse_args()
+    if args.no_cpu_baseline:
+        args.cpu_baseline = "none"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -189,57 +326,65 @@ def main():
 
     from gpt_image_edit_amd import dp
     pipe = build_pipeline(device)
-    inp = make_inputs(args.workload, device, seed=42 + rank)  # every rank edits its own shard (weak scaling)
+    B_w = WORKLOADS[args.workload][0]
+    if args.scaling == "strong":
+        G = args.global_batch or 8 * B_w
+        mine = dp.shard_indices(G, rank, world)      # the reference's inference_list[rank::world_size]
+        if not mine:
+            raise SystemExit(f"--global-batch {G} leaves rank {rank} of {world} without work")
+        batch, global_batch = len(mine), G
+    else:
+        batch, global_batch = B_w, B_w * world
+    inp = make_inputs(args.workload, device, seed=42 + rank, batch=batch)  # every rank edits its own shard
 
-    def one_step():
-        out = run_edit(pipe, inp)
-        if world > 1:
-            dp.all_gather_latents(out.latents)
-        return out
-
-    for _ in range(args.warmup):
-        one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    assert torch.isfinite(out.images.float()).all(), "non-finite output image"
-
-    B = inp["B"]
-    images = B * world * args.steps
+    elapsed = timed_edits(pipe, inp, args.steps, args.warmup, world, device, backend)
+    images = global_batch * args.steps
     S = inp["S_txt"] + inp["S_tgt"] + inp["S_cond"]
     result = {
         "metric": "edited images/sec, 28-step FLUX-Kontext (VAE encode + 28 x MMDiT + VAE decode)",
         "value": images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded random-init weights, random inputs)",
-        "config": {"workload": args.workload, "batch_per_gpu": B, "global_batch": B * world,
+        "config": {"workload": args.workload, "batch_per_gpu": batch, "global_batch": global_batch,
                    "height": inp["H"], "width": inp["W"], "S_txt": inp["S_txt"], "S_tgt": inp["S_tgt"],
                    "S_cond": inp["S_cond"], "seq_len": S, "num_inference_steps": 28, "guidance_scale": 3.5,
                    "blocks": "19 double + 38 single", "parallelism": f"dp{world}"},
+        "dist": {"world_size": dist.get_world_size() if world > 1 else 1,
+                 "backend": (dist.get_backend() + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else "none (single process)",
+                 "collective": "one all_gather_into_tensor of the packed final latents per step" if world > 1 else None},
     }
     if rank == 0 and not args.no_roofline:
-        fam = instrumented_edit(pipe, inp)
-        gm = fam["gemm"]
-        result["roofline"] = {
-            "kernel": "gemm2_kernel<*> + gemm5_kernel<*> + gemm_bf16_kernel<*> (bf16 MFMA GEMM family: all MMDiT / VAE linears)", "bound": "mfma", "achieved": gm["tflops"],
-            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gm["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
-            "launches_per_edit": gm["launches"], "ms_per_edit": gm["ms"], "algorithmic_tflop_per_edit": gm["flops"] / 1e12,
-            "other_kernels": {k: {"ms_per_edit": v["ms"], "tflops": v["tflops"], "launches": v["launches"]}
-                              for k, v in fam.items() if k != "gemm"},
-        }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.workload)
+        result["roofline"] = roofline_of(instrumented_edit(pipe, inp), args.workload)
+
+    # ---- the 1024^2 half of BASELINE.json's metric, in the same run (every rank: weak scaling at 1024^2) ------------
+    extra = {}
+    if not args.no_extra and args.workload != EXTRA_WORKLOAD and WORKLOADS[args.workload][0] == 1:
+        inp2 = make_inputs(EXTRA_WORKLOAD, device, seed=142 + rank)
+        k2 = 3
+        el2 = timed_edits(pipe, inp2, k2, 1, world, device, backend)
+        ex = {"value": world * k2 / el2, "unit": "images/s", "n_gpus": world, "steps": k2, "warmup": 1,
+              "ms_per_step": el2 / k2 * 1e3, "scaling": "weak",
+              "config": {"workload": EXTRA_WORKLOAD, "batch_per_gpu": 1, "height": 1024, "width": 1024,
+                         "seq_len": inp2["S_txt"] + inp2["S_tgt"] + inp2["S_cond"], "num_inference_steps": 28}}
+        if rank == 0 and not args.no_roofline:
+            ex["roofline"] = roofline_of(instrumented_edit(pipe, inp2), EXTRA_WORKLOAD)
+        extra[EXTRA_WORKLOAD] = ex
+        del inp2
+    if rank == 0 and world == 1 and not args.no_extra:
+        try:
+            del pipe
+            torch.cuda.empty_cache()
+            pe = prompt_encode_time(device)
+            t_edit = elapsed / args.steps
+            pe["T_s"] = t_edit
+            pe["T_e2e_s"] = pe["T_prompt_s"] + t_edit
+            extra["prompt_encode"] = pe
+        except Exception as e:  # the extras must never cost the contract line
+            extra["prompt_encode"] = {"error": f"{type(e).__name__}: {e}"}
+    if extra:
+        result["extra"] = extra
+    if rank == 0 and world == 1 and args.cpu_baseline != "none":
+        result["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_baseline)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -5,10 +5,11 @@ Same flags and defaults (``cli.py:271-283``), same helper names and semantics (`
 is what sits behind ``pipe``: ``HipFluxTransformer2DModel`` + ``HipAutoencoderKL`` filled from the same checkpoints
 (``gpt_image_edit_amd.checkpoint``).
 
-Prompt understanding (Qwen2.5-VL + task head, T5/CLIP: SURVEY.md rows a13/a14) is reused as-is from the reference
-package when it is importable next to this one (``univa.models...``); offline, ``--prompt_embeds FILE`` feeds the
-generation half from saved embeddings (a ``torch.save``d dict with ``prompt_embeds`` [1,L,4096] and
-``pooled_prompt_embeds`` [1,768]), which is also how the parity tests drive it.
+Prompt understanding: the Qwen2.5-VL backbone and T5 / CLIP come from the installed
+``transformers`` (reused as-is), wrapped by ``gpt_image_edit_amd.qwen_adaptor`` (task head, ``denoise_embeds`` forward,
+HIP ``denoise_projector``) -- nothing is imported from the reference package.  ``--prompt_embeds FILE`` feeds the
+generation half from saved embeddings instead (a ``torch.save``d dict with ``prompt_embeds`` [1,L,4096] and
+``pooled_prompt_embeds`` [1,768]), which is also how the parity tests drive it offline.
 """
 import argparse
 import os
@@ -59,21 +60,16 @@ def load_pipe(denoiser, flux_path, device):
 
 
 def update_size(i1, i2, anyres="any_11ratio", anchor_pixels=1024 * 1024):
-    """(new_h, new_w) for the edit from the (mean) size of up to two input images (cli.py:82-97)."""
+    """Edit size for a turn (reference cli.py:82-97): with no input image a square of ``anchor_pixels``; otherwise the
+    ``anyres`` bucket of the input's size -- of the MEAN width / height when two images are given."""
     from PIL import Image
-    shapes = []
-    for p in (i1, i2):
-        if p:
-            w, h = Image.open(p).size
-            shapes.append((w, h))
-    if not shapes:
-        return int(anchor_pixels ** 0.5), int(anchor_pixels ** 0.5)
-    if len(shapes) == 1:
-        w, h = shapes[0]
-    else:
-        w = sum(s[0] for s in shapes) / len(shapes)
-        h = sum(s[1] for s in shapes) / len(shapes)
-    return dynamic_resize(int(h), int(w), anyres, anchor_pixels=anchor_pixels)
+    sizes = [Image.open(path).size for path in (i1, i2) if path]        # PIL: (width, height)
+    if not sizes:
+        side = int(anchor_pixels ** 0.5)
+        return side, side
+    mean_w = sizes[0][0] if len(sizes) == 1 else sum(w for w, _ in sizes) / len(sizes)
+    mean_h = sizes[0][1] if len(sizes) == 1 else sum(h for _, h in sizes) / len(sizes)
+    return dynamic_resize(int(mean_h), int(mean_w), anyres, anchor_pixels=anchor_pixels)
 
 
 def prepare_condition_images(image_paths, device):
@@ -185,15 +181,73 @@ def main(args):
         imgs[0].save(args.output)
         print(f"Assistant: generate image at {args.output}")
         return
-    try:  # the interactive loop needs the reference's VLM wrapper and prompt encoders (reused as-is)
-        from univa.serve import cli as ref_cli  # noqa: F401
-    except Exception as e:
-        raise SystemExit("the interactive chat needs the reference package (UnivaQwen2p5VLForConditionalGeneration, "
-                         f"encode_prompt) importable next to this one: {type(e).__name__}: {e}\n"
-                         "offline: pass --prompt_embeds FILE [--images a.png,b.png]")
-    # With the reference importable its own loop is used unchanged, with `load_pipe` swapped for this module's:
-    ref_cli.load_pipe = lambda denoiser, flux_path, dev: load_pipe(args.model_path, flux_path, dev)
-    ref_cli.main(args)
+    chat(args, pipe, tokenizers, text_encoders, device)
+
+
+def load_main_model_and_processor(model_path, device, min_pixels=448 * 448, max_pixels=448 * 448):
+    """(model, task_head, processor) like reference cli.py:30-55, built from this package's adaptor: the stock
+    Qwen2.5-VL weights of the UniWorld directory, its ``denoise_tower.denoise_projector.*`` on the HIP projector and
+    ``task_head_final.pt``."""
+    from transformers import AutoProcessor
+
+    from ..projector import HipDenoiseProjector
+    from ..qwen_adaptor import TaskHead, UnivaQwen2p5VL, load_vlm
+    proj = HipDenoiseProjector(device=device)
+    proj.load_state_dict(checkpoint.read_projector(model_path))
+    model = UnivaQwen2p5VL(load_vlm(model_path, device), proj)
+    task_head = TaskHead().to(device)
+    task_head.load_state_dict(checkpoint.read_task_head(model_path))
+    processor = AutoProcessor.from_pretrained(model_path, min_pixels=min_pixels, max_pixels=max_pixels)
+    return model, task_head, processor
+
+
+def chat(args, pipe, tokenizers, text_encoders, device):
+    """The interactive loop of reference cli.py:118-267 (text and / or image URLs per turn; empty turn exits)."""
+    from PIL import Image
+
+    from ..prompt_embedding import encode_prompt
+    from ..qwen_adaptor import encode_edit_prompt
+    model, task_head, processor = load_main_model_and_processor(args.model_path, device)
+    conversation, history_image_paths, n_generated = [], [], 0
+    print("Interactive UniWorld-V1 Chat (Exit if input is empty)")
+    while True:
+        txt = input("Text prompt (or press Enter to skip): ").strip()
+        img_input = input("Image URLs (comma-separated, or press Enter to skip): ").strip()
+        if not img_input and not txt:
+            print("Exit.")
+            return
+        if args.ocr_enhancer:
+            raise SystemExit("--ocr_enhancer needs the reference's OCR service (out of scope, SURVEY.md section 2)")
+        content = [{"type": "text", "text": txt}] if txt else []
+        urls = [u.strip() for u in img_input.split(",") if u.strip()]
+        new_h, new_w = args.height, args.width
+        for url in urls:
+            content.append({"type": "image", "image": url, "min_pixels": 448 * 448, "max_pixels": 448 * 448})
+            history_image_paths.append(url)
+        if urls:
+            new_h, new_w = update_size(urls[0], urls[1] if len(urls) > 1 else None, "any_11ratio",
+                                       anchor_pixels=args.height * args.width)
+        conversation.append({"role": "user", "content": content})
+        chat_text = processor.apply_chat_template(conversation, tokenize=False, add_generation_prompt=True)
+        chat_text = "<|im_end|>\n".join(chat_text.split("<|im_end|>\n")[1:])      # drop the system turn (cli.py:186)
+        images = [Image.open(c["image"]).convert("RGB") for m in conversation for c in m["content"] if c["type"] == "image"]
+        inputs = processor(text=[chat_text], images=images or None, padding=True, return_tensors="pt").to(device)
+        t5_embeds, pooled = encode_prompt(text_encoders, tokenizers, txt if not args.no_joint_with_t5 else "", 256, device, 1)
+        turn = encode_edit_prompt(model, task_head, inputs, t5_embeds, joint_with_t5=not args.no_joint_with_t5)
+        if turn["generate"]:
+            image = generate_image(pipe, turn["prompt_embeds"], pooled, history_image_paths, new_h, new_w, args)
+            img_url = generate_image_temp.format(n_generated)
+            n_generated += 1
+            image.save(img_url)
+            conversation.append({"role": "assistant", "content": [{"type": "image", "image": img_url}]})
+            history_image_paths.append(img_url)
+            print(f"Assistant: generate image at {img_url}\n")
+        else:
+            generated = model.vlm.generate(**inputs, max_new_tokens=128)
+            reply = processor.batch_decode([o[len(i):] for i, o in zip(inputs.input_ids, generated)],
+                                           skip_special_tokens=True, clean_up_tokenization_spaces=False)[0]
+            print(f"Assistant: {reply}\n")
+            conversation.append({"role": "assistant", "content": [{"type": "text", "text": reply}]})
 
 
 if __name__ == "__main__":
