@@ -67,7 +67,15 @@ FK_DEV void wait_vmcnt() {
   else static_assert(N == 0, "add the vmcnt literal");
 }
 
-template <int NW, int STAGES>
+#ifndef FK_ATTN_PRIO
+#define FK_ATTN_PRIO 1   // static s_setprio(1) for the younger half of the workgroup (waves NW/2 .. NW-1)
+#endif
+
+// F32OUT (parity / debug build of the same kernel, fk_attention_fwd_f32_debug): the output is written as fp32 and
+// the probabilities enter the PV product as TWO bf16 terms (p = hi + lo, 16 mantissa bits instead of 8), so that
+// the result can be held against an fp32 reference at rtol 1e-3 / atol 1e-4 -- with one bf16 term the rounding of
+// P alone (2^-9 per term) sits above that tolerance whatever the kernel does.
+template <int NW, int STAGES, bool F32OUT>
 __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnParams p) {
   constexpr int QBLK = NW * 32;
   constexpr int LOADS = 32 / NW;      // DMA instructions per wave per tile (16 K pieces + 16 V pieces / NW)
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
       vf[0] = v_frag(sb, 2 * kb, 0);
       vf[1] = v_frag(sb, 2 * kb, 1);
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the leading reads (two transpose reads per fragment)
-      bf16x8_t pf;
+      bf16x8_t pf, pf_lo;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int st = 2 * kb + (i >> 2), df = i & 3;
@@ -260,11 +268,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
           pw[2] = pack_bf2(s[r0 + 4], s[r0 + 5]);
           pw[3] = pack_bf2(s[r0 + 6], s[r0 + 7]);
           pf = __builtin_bit_cast(bf16x8_t, pw);
+          if constexpr (F32OUT) {
+            u32x4_t pl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              pl[e] = pack_bf2(s[r0 + 2 * e] - bf_lo(pw[e]), s[r0 + 2 * e + 1] - bf_hi(pw[e]));
+            pf_lo = __builtin_bit_cast(bf16x8_t, pl);
+          }
         }
         if (i + 2 < 8) vf[(i + 2) % 3] = v_frag(sb, 2 * kb + ((i + 2) >> 2), (i + 2) & 3);
         o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % 3], pf, o[df], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the two transpose reads of this slot first ...
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // ... then its MFMA
+        if constexpr (F32OUT) o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % 3], pf_lo, o[df], 0, 0, 0);
+        else {
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the two transpose reads of this slot first ...
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // ... then its MFMA
+        }
       }
     }
     l_run += psum;
@@ -273,6 +291,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
 
   using TT = std::true_type;
   using FF = std::false_type;
+#if FK_ATTN_PRIO
+  // Two waves share every SIMD (waves w and w + NW/2); the later-dispatched one loses the VALU arbitration (priority,
+  // then age) at the head of every segment.  ONE static priority raise for that half, no per-segment flips.  The
+  // condition must be provably wave-uniform: s_setprio ignores EXEC.
+  if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
   const bool ragged = p.S % KVBLK != 0;
   int* const wg_flag = (int*)(smem + STAGES * STAGE_BYTES);   // one word past the ring (allocated by the launcher)
   for (int attempt = 0; attempt < 2; ++attempt) {
@@ -334,19 +358,45 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
     }
   }
 
-  // ---- finalize: O = O^T / l ; lane (q = ql) holds d = 32 df + 8 (r>>2) + 4 hh + (r&3) ---------------
+  // ---- finalize: O = O^T / l ; lane (q = ql) holds d = 32 df + 8 g + 4 hh + (0..3), g = r >> 2 -------------
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
-  if (q_row < p.S) {
-    bf16_t* op = p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_ld + h * HD + 4 * hh;
+  if constexpr (F32OUT) {
+    if (q_row < p.S) {
+      float* op = (float*)p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_ld + h * HD + 4 * hh;
+#pragma unroll
+      for (int df = 0; df < 4; ++df)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(f32x4_t*)(op + 32 * df + 8 * g) = f32x4_t{o[df][4 * g + 0] * inv, o[df][4 * g + 1] * inv,
+                                                       o[df][4 * g + 2] * inv, o[df][4 * g + 3] * inv};
+    }
+  } else {
+    // The two half-waves hold neighbouring 8-byte pieces of one output row.  One v_permlane32_swap per dword pairs
+    // them up: afterwards lanes 0..31 own the 16 bytes of columns 8g .. 8g+7 and lanes 32..63 those of 8(g+1) ..
+    // 8(g+1)+7 -- 8 dwordx4 stores per lane instead of 16 dwordx2 (the store tail is issue-bound, not bandwidth-bound).
+    bf16_t* const orow = p.o + (int64_t)b * p.o_bs + (int64_t)min(q_row, p.S - 1) * p.o_ld + h * HD;
+    const bool wide = ((p.o_ld | p.o_bs) & 7) == 0 && ((uintptr_t)p.o & 15) == 0;   // wave-uniform
 #pragma unroll
     for (int df = 0; df < 4; ++df)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2_t pk;
-        pk[0] = pack_bf2(o[df][4 * g + 0] * inv, o[df][4 * g + 1] * inv);
-        pk[1] = pack_bf2(o[df][4 * g + 2] * inv, o[df][4 * g + 3] * inv);
-        *(u32x2_t*)(op + 32 * df + 8 * g) = pk;
+      for (int g = 0; g < 4; g += 2) {
+        u32x2_t a, c;
+        a[0] = pack_bf2(o[df][4 * g + 0] * inv, o[df][4 * g + 1] * inv);
+        a[1] = pack_bf2(o[df][4 * g + 2] * inv, o[df][4 * g + 3] * inv);
+        c[0] = pack_bf2(o[df][4 * g + 4] * inv, o[df][4 * g + 5] * inv);
+        c[1] = pack_bf2(o[df][4 * g + 6] * inv, o[df][4 * g + 7] * inv);
+        if (wide) {
+#if defined(__HIP_DEVICE_COMPILE__)
+          const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
+          const u32x4_t w = {r0[0], r1[0], r0[1], r1[1]};
+          if (q_row < p.S) *(u32x4_t*)(orow + 32 * df + 8 * g + 8 * hh) = w;
+#endif
+        } else if (q_row < p.S) {
+          *(u32x2_t*)(orow + 32 * df + 8 * g + 4 * hh) = a;
+          *(u32x2_t*)(orow + 32 * df + 8 * (g + 1) + 4 * hh) = c;
+        }
       }
   }
 }
@@ -364,19 +414,37 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
 // (2) rotating waves 4..7 by one phase so that softmax of one wave meets MFMA of its SIMD partner
 // (4-stage ring): 725 TF vs 844.  PMC: matrix pipe 48 % busy, VALU 52 %, no LDS bank conflicts.
 
-template <int NW, int STAGES>
+template <int NW, int STAGES, bool F32OUT>
 int launch(const AttnParams& p, hipStream_t stream) {
   constexpr int SMEM = STAGES * STAGE_BYTES + 16;   // ring + the restart flag word
-  auto kern = attention_fwd_kernel<NW, STAGES>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    attr_done = true;
-  }
+  auto kern = attention_fwd_kernel<NW, STAGES, F32OUT>;
+  FK_ENSURE_MAX_LDS(kern, SMEM, "fk_attention_fwd_bf16");
   const int nqb = (p.S + NW * 32 - 1) / (NW * 32);
   hipLaunchKernelGGL(kern, dim3(nqb * p.H * p.B), dim3(NW * 64), SMEM, stream, p);
   FK_CHECK_LAUNCH("fk_attention_fwd_bf16");
   return FK_OK;
+}
+
+int attention_entry(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H, int32_t S, int64_t v_ld,
+                    int64_t v_batch_stride, int64_t o_ld, int64_t o_batch_stride, float scale, bool f32out,
+                    hipStream_t stream) {
+  FK_CHECK_ARG(q && k && v && o, "fk_attention_fwd_bf16: null pointer");
+  FK_CHECK_ARG(B > 0 && H > 0 && S > 0, "fk_attention_fwd_bf16: bad B/H/S %d %d %d", B, H, S);
+  FK_CHECK_ARG(o_ld % 4 == 0 && o_batch_stride % 4 == 0 && ((uintptr_t)o % (f32out ? 16 : 8) == 0),
+               "fk_attention_fwd_bf16: output must be 8-byte aligned (o_ld %% 4 == 0)");
+  FK_CHECK_ARG(v_ld % 8 == 0 && v_batch_stride % 8 == 0, "fk_attention_fwd_bf16: V strides must be multiples of 8");
+  FK_CHECK_ARG(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0),
+               "fk_attention_fwd_bf16: q/k/v must be 16-byte aligned");
+  // one (batch, head)'s K and V are addressed through 32-bit buffer descriptors / offsets
+  FK_CHECK_ARG(v_ld > 0 && (int64_t)S * HD * 2 < (1ll << 31) && ((int64_t)(S - 1) * v_ld + HD) * 2 < (1ll << 31) &&
+                   (int64_t)(S + KVBLK) * v_ld * 2 < (1ll << 31),
+               "fk_attention_fwd_bf16: S = %d with v_ld = %lld exceeds the 2 GiB a (batch, head)'s K / V may span", S,
+               (long long)v_ld);
+  AttnParams p;
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o;
+  p.B = B; p.H = H; p.S = S; p.v_ld = v_ld; p.v_bs = v_batch_stride; p.o_ld = o_ld; p.o_bs = o_batch_stride;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  return f32out ? launch<8, 3, true>(p, stream) : launch<8, 3, false>(p, stream);
 }
 
 }  // namespace
@@ -384,16 +452,13 @@ int launch(const AttnParams& p, hipStream_t stream) {
 extern "C" int fk_attention_fwd_bf16(const void* q, const void* k, const void* v, void* o, int32_t B,
                                      int32_t H, int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld,
                                      int64_t o_batch_stride, float scale, fk_stream_t stream_) {
-  FK_CHECK_ARG(q && k && v && o, "fk_attention_fwd_bf16: null pointer");
-  FK_CHECK_ARG(B > 0 && H > 0 && S > 0, "fk_attention_fwd_bf16: bad B/H/S %d %d %d", B, H, S);
-  FK_CHECK_ARG(o_ld % 4 == 0 && o_batch_stride % 4 == 0 && ((uintptr_t)o % 8 == 0),
-               "fk_attention_fwd_bf16: output must be 8-byte aligned (o_ld %% 4 == 0)");
-  FK_CHECK_ARG(v_ld % 8 == 0 && v_batch_stride % 8 == 0, "fk_attention_fwd_bf16: V strides must be multiples of 8");
-  FK_CHECK_ARG(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0),
-               "fk_attention_fwd_bf16: q/k/v must be 16-byte aligned");
-  AttnParams p;
-  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o;
-  p.B = B; p.H = H; p.S = S; p.v_ld = v_ld; p.v_bs = v_batch_stride; p.o_ld = o_ld; p.o_bs = o_batch_stride;
-  p.scale_log2 = scale * 1.4426950408889634f;
-  return launch<8, 3>(p, (hipStream_t)stream_);
+  return attention_entry(q, k, v, o, B, H, S, v_ld, v_batch_stride, o_ld, o_batch_stride, scale, false,
+                         (hipStream_t)stream_);
+}
+
+extern "C" int fk_attention_fwd_f32_debug(const void* q, const void* k, const void* v, float* o, int32_t B,
+                                          int32_t H, int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld,
+                                          int64_t o_batch_stride, float scale, fk_stream_t stream_) {
+  return attention_entry(q, k, v, o, B, H, S, v_ld, v_batch_stride, o_ld, o_batch_stride, scale, true,
+                         (hipStream_t)stream_);
 }

@@ -71,6 +71,31 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t s
 
 // host side ---------------------------------------------------------------------------------------
 void fk_set_error(const char* fmt, ...);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize applies to the CURRENT device only: remember per (kernel, device)
+// whether it has been raised.  `done` is the calling launcher's static table (one per kernel instantiation);
+// the race on it is benign (the call is idempotent).  Returns hipSuccess or the runtime's error.
+constexpr int FK_MAX_DEVICES = 64;
+struct fk_lds_attr_table { bool done[FK_MAX_DEVICES]; };
+inline hipError_t fk_ensure_max_lds(fk_lds_attr_table& t, const void* kern, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev >= 0 && dev < FK_MAX_DEVICES && t.done[dev]) return hipSuccess;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && dev >= 0 && dev < FK_MAX_DEVICES) t.done[dev] = true;
+  return e;
+}
+#define FK_ENSURE_MAX_LDS(kern, bytes, name)                                                       \
+  do {                                                                                             \
+    static fk_lds_attr_table tbl_ = {};                                                            \
+    hipError_t ea_ = fk_ensure_max_lds(tbl_, (const void*)(kern), (bytes));                        \
+    if (ea_ != hipSuccess) {                                                                       \
+      fk_set_error("%s: cannot raise the dynamic LDS limit to %d bytes: %s", name, (int)(bytes),   \
+                   hipGetErrorString(ea_));                                                        \
+      return FK_ELAUNCH;                                                                           \
+    }                                                                                              \
+  } while (0)
 #define FK_CHECK_ARG(cond, ...)      \
   do {                               \
     if (!(cond)) {                   \

@@ -665,11 +665,7 @@ int launch(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) 
   }
   ga.tiles_before[FK_MAX_GROUP] = total;
   auto kern = gemm2_kernel<EPI, BN>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<BN>::SMEM_BYTES);
-    attr_done = true;
-  }
+  FK_ENSURE_MAX_LDS(kern, Cfg<BN>::SMEM_BYTES, "fk_gemm_bf16 (256-row tile)");
   hipLaunchKernelGGL(kern, dim3(total), dim3(NT), Cfg<BN>::SMEM_BYTES, stream, ga);
   FK_CHECK_LAUNCH("fk_gemm_bf16 (256-row tile)");
   return FK_OK;
@@ -684,11 +680,7 @@ int launch5(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream)
   }
   ga.tiles_before[FK_MAX_GROUP] = total;
   auto kern = gemm5_kernel<EPI, BN>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg5<BN>::SMEM_BYTES + (FK_TRACE ? 4096 : 0));
-    attr_done = true;
-  }
+  FK_ENSURE_MAX_LDS(kern, Cfg5<BN>::SMEM_BYTES + (FK_TRACE ? 4096 : 0), "fk_gemm_bf16 (256-row tile, 4 waves)");
   hipLaunchKernelGGL(kern, dim3(total), dim3(256), Cfg5<BN>::SMEM_BYTES + (FK_TRACE ? 4096 : 0), stream, ga);
   FK_CHECK_LAUNCH("fk_gemm_bf16 (256-row tile, 4 waves, register staged)");
   return FK_OK;

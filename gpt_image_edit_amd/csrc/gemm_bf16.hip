@@ -268,11 +268,7 @@ template <int EPI, bool OUT_F32, bool CONV = false>
 int launch(const fk_gemm_args& p, hipStream_t stream, const ConvGeom& g = ConvGeom()) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   auto kern = gemm_bf16_kernel<EPI, OUT_F32, CONV>;
-  static bool attr_done = false;  // benign race: idempotent
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    attr_done = true;
-  }
+  FK_ENSURE_MAX_LDS(kern, SMEM_BYTES, CONV ? "fk_conv2d_nhwc_bf16" : "fk_gemm_bf16");
   hipLaunchKernelGGL(kern, dim3(nbm * nbn), dim3(NTHREADS), SMEM_BYTES, stream, p, g);
   FK_CHECK_LAUNCH(CONV ? "fk_conv2d_nhwc_bf16" : "fk_gemm_bf16");
   return FK_OK;

@@ -92,8 +92,34 @@ def as_uint8_nhwc(image):
     return None
 
 
+class NhwcPixels:
+    """Marker for the fused pixel route: ``tensor`` is the VAE encoder's input already in its internal layout
+    (NHWC bf16, channels zero-padded), produced by :func:`pixels_to_latent_input`.  An explicit type instead of a
+    shape test: a bf16 NCHW tensor whose last dimension happens to be 32 (pre-encoded latents of a 256-px-wide
+    image) must not be mistaken for it."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+        self.shape = tensor.shape
+
+    def to(self, *args, **kwargs):
+        return NhwcPixels(self.tensor.to(*args, **kwargs))
+
+
+def nearest_source_index(n_out, n_in):
+    """Source index of ``F.interpolate(mode="nearest")`` for every output position: min(floor(i * in / out), in-1)."""
+    idx = torch.floor(torch.arange(n_out, dtype=torch.float32) * (float(n_in) / float(n_out))).to(torch.int64)
+    return idx.clamp_(max=n_in - 1)
+
+
 def pixels_to_latent_input(u8, height, width, device, cpad=32):
     """uint8 [N,H,W,3] -> NHWC bf16 [N,height,width,cpad] exactly as the reference's float route would produce it
-    (normalise in fp32, nearest resize, renormalise iff nothing is negative, cast to bf16)."""
-    renorm = bool(u8.min() >= 128)  # (u/255 - 0.5)/0.5 >= 0 everywhere <=> u >= 128 (127.5 is not a uint8)
-    return ops.pixels_to_nhwc(u8.to(device).contiguous(), height, width, cpad, renorm)
+    (normalise in fp32, nearest resize, renormalise iff nothing is negative, cast to bf16).
+
+    The reference decides the renormalisation on the RESIZED tensor (``preprocess`` runs after ``resize``,
+    flux_pipeline.py:960-972), so the minimum is taken over the pixels the nearest resize actually samples."""
+    rows = nearest_source_index(height, u8.shape[1]).to(u8.device)
+    cols = nearest_source_index(width, u8.shape[2]).to(u8.device)
+    sampled_min = u8.index_select(1, rows).index_select(2, cols).min()
+    renorm = bool(sampled_min >= 128)  # (u/255 - 0.5)/0.5 >= 0 everywhere <=> u >= 128 (127.5 is not a uint8)
+    return NhwcPixels(ops.pixels_to_nhwc(u8.to(device).contiguous(), height, width, cpad, renorm))

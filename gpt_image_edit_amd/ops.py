@@ -176,6 +176,20 @@ def attention(q, k, v, out, scale=None):
     return out
 
 
+def attention_f32_debug(q, k, v, scale=None):
+    """Parity build of :func:`attention` (fk_attention_fwd_f32_debug): fp32 [B, S, H*128] output, P as hi + lo bf16."""
+    _need_cuda(q, k, v)
+    B, H, S, hd = q.shape
+    if hd != 128 or v.dim() != 3 or v.shape[-1] != H * 128 or v.stride(2) != 1:
+        raise ValueError("q, k: [B,H,S,128]; v: [B,S,H*128] view with a contiguous last dimension")
+    out = torch.empty((B, S, H * 128), device=q.device, dtype=torch.float32)
+    libfk.check(libfk.load().fk_attention_fwd_f32_debug(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, S, v.stride(1),
+                                                       v.stride(0), out.stride(1), out.stride(0),
+                                                       hd ** -0.5 if scale is None else scale, _stream()),
+                "fk_attention_fwd_f32_debug")
+    return out
+
+
 def silu(x, out=None):
     _need_cuda(x)
     if out is None:
@@ -272,14 +286,30 @@ def conv2d_nhwc(x, w_packed, bias, cout, ksize=3, stride=1, pad=1, upsample2x=Fa
     return out
 
 
+_GN_WS = {}
+
+
+def _gn_workspace(lib, B, HW, C, device):
+    """Partial-sum workspace + statistics of one GroupNorm shape, allocated once per (device, shape): calls on one
+    stream are ordered, so consecutive GroupNorms may share it."""
+    key = (str(device), B, HW, C)
+    hit = _GN_WS.get(key)
+    if hit is None:
+        if len(_GN_WS) > 64:
+            _GN_WS.clear()
+        hit = (torch.empty(lib.fk_groupnorm_ws_floats(B, HW, C), device=device, dtype=torch.float32),
+               torch.empty((B, 32, 2), device=device, dtype=torch.float32))
+        _GN_WS[key] = hit
+    return hit
+
+
 def group_norm_nhwc(x, gamma, beta, silu, eps=1e-6, out=None):
     """GroupNorm(32) (+SiLU) over [B, ..., C] NHWC bf16."""
     _need_cuda(x, gamma, beta)
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
     lib = libfk.load()
-    ws = torch.empty(lib.fk_groupnorm_ws_floats(B, HW, C), device=x.device, dtype=torch.float32)
-    stats = torch.empty((B, 32, 2), device=x.device, dtype=torch.float32)
+    ws, stats = _gn_workspace(lib, B, HW, C, x.device)
     libfk.check(lib.fk_groupnorm_stats_nhwc_bf16(_ptr(x), _ptr(stats), _ptr(ws), B, HW, C, 32, eps, _stream()),
                 "fk_groupnorm_stats_nhwc_bf16")
     if out is None:

@@ -163,8 +163,8 @@ class FluxKontextPipeline:
         image_latents = image_ids = None
         if image is not None:
             image = image.to(device=device)
-            if image.dim() == 4 and image.shape[3] == 32 and image.dtype == BF16:  # fused pixel route: NHWC bf16
-                image_latents = self._encode_vae_image(image, nhwc=True)
+            if isinstance(image, image_processor.NhwcPixels):  # fused pixel route (explicit marker, not a shape test)
+                image_latents = self._encode_vae_image(image.tensor, nhwc=True)
             elif image.shape[1] != self.latent_channels:
                 image_latents = self._encode_vae_image(image)
             else:
@@ -181,9 +181,13 @@ class FluxKontextPipeline:
         latent_ids = self._prepare_latent_image_ids(batch_size, height // 2, width // 2, device, dtype)
         if latents is None:
             shape = (batch_size, num_channels_latents, height, width)
-            gdev = generator.device if isinstance(generator, torch.Generator) else device
-            noise = torch.randn(shape, generator=generator if not isinstance(generator, list) else None,
-                                device=gdev, dtype=dtype).to(device)
+            if isinstance(generator, list):
+                # diffusers' randn_tensor: sample i comes from its own generator (on that generator's device)
+                noise = torch.cat([torch.randn((1, *shape[1:]), generator=g, device=g.device, dtype=dtype).to(device)
+                                   for g in generator], dim=0)
+            else:
+                gdev = generator.device if isinstance(generator, torch.Generator) else device
+                noise = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
             latents = self._pack_latents(noise, batch_size, num_channels_latents, height, width)
         else:
             latents = latents.to(device=device, dtype=dtype)

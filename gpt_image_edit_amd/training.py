@@ -2,9 +2,11 @@
 
 What is here is the per-step bookkeeping of the reference's ``train_denoiser.py`` that does not touch activations:
 which parameters train (:70-122), how a step's noise levels are drawn and shifted (:935-993, :779-788) and how the
-loss is weighted.  The tensor work of the step (noisy-input mix, MMDiT forward + backward, loss reduction, AdamW) has no
-HIP implementation yet -- ``oracle/train.py`` holds its CPU restatement for the kernels to be checked against -- and
-nothing here substitutes torch arithmetic for it.
+loss is weighted.  The tensor work of the step runs in libfk: noisy-input mix fused with the token packing, the
+flow-matching loss fused with its gradient, the global gradient norm and AdamW (``csrc/train_kernels.hip``,
+``ops.flow_noisy_tokens / flow_loss / sumsq / adamw_step``), the MMDiT forward (``transformer.py``) and its backward
+(``backward.py``); ``oracle/train.py`` is the CPU restatement they are checked against.  Nothing here substitutes
+torch arithmetic for any of it.
 """
 import math
 

@@ -152,7 +152,7 @@ class HipFluxTransformer2DModel(nn.Module):
             s=e(B, S, D), n=e(B, S, D), qkv=e(B, S, 3 * D), q=e(B, H, S, 128), k=e(B, H, S, 128),
             o=e(B, S, D), ff=e(B, S, 4 * D), cat=e(B, S, 5 * D),
             mod=e(B, self._packed.mod_total), temb=e(B, D), act=e(B, D), tproj=e(B, 256), e1=e(B, D),
-            t_emb=e(B, D), g_emb=e(B, D), p_emb=e(B, D), out=e(B, S_img, self.config.out_channels),
+            t_emb=e(B, D), g_emb=e(B, D), p_emb=e(B, D),
         )
         self._ws = {key: ws}  # keep only the latest shape
         return ws
@@ -323,8 +323,10 @@ class HipFluxTransformer2DModel(nn.Module):
 
         # -- output head: AdaLayerNormContinuous (scale first, then shift) + proj_out -----------------------
         ops.ln_modulate(h, chunk(pk.mod_out, 1), chunk(pk.mod_out, 0), out=n_img)
-        ops.gemm(n_img, P("proj_out.weight"), P("proj_out.bias"), out=ws.out)
-        sample = ws.out
+        # the result is a FRESH tensor every call (64 channels per token: tiny; the caching allocator serves it without
+        # a device sync): callers such as the reference pipeline's true-CFG branch keep one call's output while
+        # making the next (flux_pipeline.py:1067-1095), which a persistent workspace buffer would silently alias
+        sample = ops.gemm(n_img, P("proj_out.weight"), P("proj_out.bias"))
         if not return_dict:
             return (sample,)
         return SimpleNamespace(sample=sample)

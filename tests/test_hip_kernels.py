@@ -281,8 +281,32 @@ def test_attention(ops, B, H, S):
     ref = ref.transpose(1, 2).reshape(B, S, H * 128)
     d = report(f"attention B{B} H{H} S{S}", out[..., :H * 128], ref)
     assert out[..., H * 128:].abs().max().item() == 0
-    # P is rounded to bf16 before the PV product and O to bf16 at the end: ~2^-8 relative per term
-    assert d.max().item() < 3e-2 and d.mean().item() < 2e-3
+    # P is rounded to bf16 before the PV product and O to bf16 at the end (2^-9 relative each): bounds RELATIVE to
+    # the output scale (measured at S = 2560: max 0.25 %, mean 0.02 % of absmax)
+    scale = ref.abs().max().item()
+    assert d.max().item() <= 1e-2 * scale and d.mean().item() <= 1e-3 * scale
+    # 8-byte aligned (not 16-byte) output rows take the narrow-store epilogue: same bits
+    out2 = torch.zeros(B, S, H * 128 + 4, dtype=BF, device="cuda")
+    ops.attention(q.cuda(), k.cuda(), qkv_dev[:, :, 2 * H * 128:], out2)
+    assert torch.equal(out2[..., :H * 128], out[..., :H * 128]) and out2[..., H * 128:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("B,H,S", [(1, 2, 64), (2, 3, 75), (1, 2, 300), (1, 4, 2560), (2, 2, 257)])
+def test_attention_fp32_debug_output_at_stated_tolerance(ops, B, H, S):
+    """fk_attention_fwd_f32_debug = the same kernel with fp32 output and P entering PV as hi + lo bf16 terms: tiling,
+    LDS layouts, exponent reference, masking and the key <-> MFMA k-slot binding are shared with the bf16 build, so
+    this holds the kernel's arithmetic against fp32 SDPA at BASELINE.json's rtol 1e-3 / atol 1e-4."""
+    q, k = randn(B, H, S, 128, seed=20), randn(B, H, S, 128, seed=21)
+    qkv = randn(B, S, 3 * H * 128, seed=22)
+    v = qkv[:, :, 2 * H * 128:].reshape(B, S, H, 128).transpose(1, 2)
+    if S == 300:
+        k[:, :, 200] = q[:, :, 17] * 2.0
+        k[:, :, 290] = q[:, :, 150] * 3.0
+    got = ops.attention_f32_debug(q.cuda(), k.cuda(), qkv.cuda()[:, :, 2 * H * 128:])
+    torch.cuda.synchronize()
+    ref = F.scaled_dot_product_attention(q.float(), k.float(), v.float()).transpose(1, 2).reshape(B, S, H * 128)
+    report(f"attention_f32_debug B{B} H{H} S{S}", got, ref)
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-3, atol=1e-4)
 
 
 def test_attention_value_layout_is_transpose_detecting(ops):

@@ -70,6 +70,25 @@ def test_mmdit_forward_matches_oracle(n_double, n_single, B, S_txt, h, w):
     assert d_bf.max().item() <= 4e-2 * scale
 
 
+def test_forward_outputs_do_not_alias():
+    """Two sequential calls (the reference pipeline's true-CFG branch keeps noise_pred while computing
+    neg_noise_pred, flux_pipeline.py:1067-1095) must return distinct tensors."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd import flux_spec
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=1, num_single_layers=0)
+    m = HipFluxTransformer2DModel(cfg, device="cuda", init="synthetic", seed=8)
+    hs, enc, pooled, t, gd, img_ids, txt_ids = (x.cuda() for x in _inputs(1, 40, 6, 8, cfg, seed=4))
+    kw = dict(hidden_states=hs, pooled_projections=pooled, timestep=t[:1], guidance=gd[:1], txt_ids=txt_ids,
+              img_ids=img_ids, return_dict=False)
+    pos = m(encoder_hidden_states=enc, **kw)[0]
+    keep = pos.clone()
+    neg = m(encoder_hidden_states=-enc, **kw)[0]
+    assert pos.data_ptr() != neg.data_ptr()
+    assert torch.equal(pos, keep) and not torch.equal(pos, neg)
+
+
 def test_state_dict_roundtrip_and_seam():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")

@@ -35,10 +35,55 @@ def test_pixels_in_renormalises_bright_images():
     from oracle import vae as ovae
     g = torch.Generator().manual_seed(5)
     u8 = torch.randint(128, 256, (1, 40, 56, 3), generator=g, dtype=torch.uint8)
-    got = image_processor.pixels_to_latent_input(u8, 48, 48, "cuda").cpu()
+    wrapped = image_processor.pixels_to_latent_input(u8, 48, 48, "cuda")
+    assert isinstance(wrapped, image_processor.NhwcPixels)      # explicit marker of the fused route
+    got = wrapped.tensor.cpu()
     ref = ovae.preprocess_uint8(u8, 48, 48)
     assert ref.min() < 0, "the quirk must actually trigger in this case"
     assert torch.equal(got[..., :3].permute(0, 3, 1, 2), ref)
+
+
+def test_pixels_in_renormalisation_is_decided_after_the_resize():
+    """The reference checks `image.min()` on the RESIZED tensor: a dark pixel that the nearest down-sample drops
+    must not switch the second normalisation off."""
+    _need_gpu()
+    from gpt_image_edit_amd import image_processor
+    from oracle import vae as ovae
+    g = torch.Generator().manual_seed(6)
+    u8 = torch.randint(128, 256, (1, 64, 64, 3), generator=g, dtype=torch.uint8)
+    rows = image_processor.nearest_source_index(32, 64)
+    assert 1 not in rows.tolist()
+    u8[0, 1, 1] = 0                                      # never sampled by the 64 -> 32 nearest resize
+    got = image_processor.pixels_to_latent_input(u8, 32, 32, "cuda").tensor.cpu()
+    ref = ovae.preprocess_uint8(u8, 32, 32)
+    assert ref.min() < 0                                 # the reference renormalised
+    assert torch.equal(got[..., :3].permute(0, 3, 1, 2), ref)
+    u8[0, 2, 2] = 0                                      # sampled: now nothing is renormalised
+    got = image_processor.pixels_to_latent_input(u8, 32, 32, "cuda").tensor.cpu()
+    assert torch.equal(got[..., :3].permute(0, 3, 1, 2), ovae.preprocess_uint8(u8, 32, 32))
+
+
+def test_pre_encoded_latents_32_wide_are_not_mistaken_for_pixels():
+    """[N,16,h,32] bf16 condition latents (a 256-px-wide image) pass through prepare_latents untouched, as in the
+    reference (flux_pipeline.py:675-678), instead of being pushed through the VAE encoder as 'NHWC pixels'."""
+    _need_gpu()
+    from gpt_image_edit_amd import flux_spec
+    from gpt_image_edit_amd.pipeline import FluxKontextPipeline
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    from gpt_image_edit_amd.vae import HipAutoencoderKL
+    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=0, num_single_layers=1)
+    pipe = FluxKontextPipeline(HipFluxTransformer2DModel(cfg, device="cuda", init="synthetic", seed=1),
+                               HipAutoencoderKL(device="cuda", init="synthetic", seed=2))
+    g = torch.Generator().manual_seed(4)
+    lat = torch.randn(2, 16, 8, 32, generator=g).to(BF).cuda()
+    _, image_latents, _, image_ids = pipe.prepare_latents(lat, 2, 16, 64, 256, BF, "cuda",
+                                                          generator=torch.Generator().manual_seed(0))
+    assert torch.equal(image_latents, pipe._pack_latents(lat, 2, 16, 8, 32)) and image_ids.shape == (4 * 16, 3)
+    # one generator per sample (diffusers randn_tensor): sample i is reproducible from generator i alone
+    gens = [torch.Generator().manual_seed(100 + i) for i in range(2)]
+    a = pipe.prepare_latents(None, 2, 16, 64, 64, BF, "cuda", generator=gens)[0]
+    one = pipe.prepare_latents(None, 1, 16, 64, 64, BF, "cuda", generator=[torch.Generator().manual_seed(101)])[0]
+    assert torch.equal(a[1:], one)
 
 
 @pytest.mark.parametrize("dtype", [BF, torch.float32])
