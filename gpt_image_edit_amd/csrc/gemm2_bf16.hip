@@ -30,6 +30,8 @@
 // applied where the tile is written (DMA source address / ds_write address) and again on the ds_read_b128 side.
 // Up to FK_MAX_GROUP problems with identical (N, K, epilogue) share one launch ("grouped GEMM"): the
 // text- and image-stream linears of a double block become one grid.
+#include <type_traits>
+
 #include "fk_common.h"
 
 namespace {
@@ -95,6 +97,9 @@ struct Cfg {
   static constexpr int SMEM_BYTES = (STAGES * STAGE_BYTES > CT_BYTES) ? STAGES * STAGE_BYTES : CT_BYTES;
   // bank-conflict swizzle of the 16-byte chunk index, as a function of the tile row
   static FK_DEV int swz(int row) { return CH == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+  // first tile row / column of the 32 x 32 block (mf, nf) of wave (wm, wn)
+  static FK_DEV int tile_row(int wm, int mf) { return wm * WTM + mf * 32; }
+  static FK_DEV int tile_col(int wn, int nf) { return wn * WTN + nf * 32; }
 };
 
 template <int N>
@@ -104,6 +109,7 @@ FK_DEV void wait_vmcnt() {
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else static_assert(N == 0, "add the vmcnt literal");
 }
@@ -192,7 +198,7 @@ FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& 
       for (int nf = 0; nf < C::NF; ++nf)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n = n0 + wn * C::WTN + nf * 32 + 8 * q + 4 * fhalf;
+          const int n = n0 + C::tile_col(wn, nf) + 8 * q + 4 * fhalf;
           bw[nf][q] = *(const u32x2_t*)((const bf16_t*)p.bias + min(n, p.N - 4));   // columns >= N are never stored
         }
     }
@@ -203,7 +209,7 @@ FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& 
   for (int nf = 0; nf < C::NF; ++nf) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int nl = wn * C::WTN + nf * 32 + 8 * q + 4 * fhalf;
+      const int nl = C::tile_col(wn, nf) + 8 * q + 4 * fhalf;
       const float b[4] = {bf_lo(bw[nf][q][0]), bf_hi(bw[nf][q][0]), bf_lo(bw[nf][q][1]), bf_hi(bw[nf][q][1])};
 #pragma unroll
       for (int mf = 0; mf < C::MF; ++mf) {
@@ -224,7 +230,7 @@ FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& 
         u32x2_t pk;
         pk[0] = pack_bf2(v[0], v[1]);
         pk[1] = pack_bf2(v[2], v[3]);
-        const int ml = wm * C::WTM + mf * 32 + frow;
+        const int ml = C::tile_row(wm, mf) + frow;
         *(u32x2_t*)(ct + ml * C::CT_LD + nl) = pk;
       }
     }
@@ -505,6 +511,8 @@ struct Cfg5 {
   static constexpr int SMEM_BYTES = (STAGES * STAGE_BYTES > CT_BYTES) ? STAGES * STAGE_BYTES : CT_BYTES;
   static_assert(LOADS % KS == 0, "pieces must divide over the k-steps");
   static FK_DEV int swz(int row) { return (row >> 1) & 7; }
+  static FK_DEV int tile_row(int wm, int mf) { return wm * WTM + mf * 32; }
+  static FK_DEV int tile_col(int wn, int nf) { return wn * WTN + nf * 32; }
 };
 
 // k-loop of one work item of the 4-wave kernel: acc = A[m0.., kb*BK ..] x W[n0.., kb*BK ..]^T over `nit` K-tiles.
@@ -656,6 +664,189 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   store_tile<EPI, BN, C>(acc, p, smem, m0, n0, wm, wn);
 }
 
+
+// ---- 8 waves in two groups that alternate between "multiply" and "load" ("ping-pong") ----------------------------
+// 256 x 256 x 64 tile, waves 2 (M) x 4 (N); a wave's output is FOUR 64 x 32 quadrants: rows {128 i + 64 wm + [0,64)} x
+// columns {128 j + 32 wn + [0,32)}, i, j in {0,1}.  The A and W tiles are kept in LDS as two 128-row half-tiles each
+// (A0 | A1 | W0 | W1, 16 KiB apiece, two K-tiles = 128 KiB), and a K-tile is worked off in four phases, one quadrant
+// each (8 MFMAs = 256 matrix-pipe cycles):
+//     phase   reads into registers        DMA request (one half-tile = 2 pieces per wave)    multiplies
+//     P1      A0(t)          (8 b128)     A1(t+1)                                            quadrant (0,0)
+//     P2      W1(t)          (4)          W0(t+2)                                            (0,1)
+//     P3      A1(t)          (8)          A0(t+2)                                            (1,0)
+//     P4      W0(t+1)        (4)          W1(t+2)                                            (1,1)
+//   phase := { reads, DMA requests, s_waitcnt vmcnt(10) } s_barrier { lgkmcnt(0), MFMAs } s_barrier
+// Waves 0-3 (wm = 0) and 4-7 (wm = 1) -- one of each per SIMD -- run this stream ONE barrier apart, so while one
+// group multiplies the other issues its LDS reads and DMA requests: an LDS-DMA request costs its wave >= 60 issue
+// cycles (measured), which stalls the matrix pipe when the same wave also owns the MFMA stream (the
+// one-wave-per-SIMD kernels) and costs nothing here.  Every half-tile is requested exactly 6 phases before it is read
+// and the wait that retires it (vmcnt(10): five younger half-tiles may stay in flight) sits one phase before the
+// read, with a barrier in between; a slot is re-requested no earlier than two phases after its last read.  All eight
+// LDS slots are therefore always in use: 5 phases (~1.3 k cycles) of latency cover per request out of 128 KiB.
+template <int BN>
+struct Cfg8 {
+  static_assert(BN == 256, "the ping-pong kernel is instantiated for the 256 x 256 tile only");
+  static constexpr int NTHREADS = 512;
+  static constexpr int BK = 64, ROW_BYTES = 128;
+  static constexpr int WAVES_M = 2, WAVES_N = 4;
+  static constexpr int MF = 4, NF = 2;
+  static constexpr int HALF_BYTES = 128 * ROW_BYTES;      // one half-tile: 128 rows x 64 k
+  static constexpr int BUF_BYTES = 4 * HALF_BYTES;        // A0 | A1 | W0 | W1 of one K-tile
+  static constexpr int RING_BYTES = 2 * BUF_BYTES;
+  static constexpr int CT_LD = BN + 8;
+  static constexpr int CT_BYTES = BM * CT_LD * 2;
+  static constexpr int SMEM_BYTES = RING_BYTES > CT_BYTES ? RING_BYTES : CT_BYTES;
+  static FK_DEV int swz(int row) { return (row >> 1) & 7; }
+  static FK_DEV int tile_row(int wm, int mf) { return (mf >> 1) * 128 + wm * 64 + (mf & 1) * 32; }
+  static FK_DEV int tile_col(int wn, int nf) { return nf * 128 + wn * 32; }
+};
+
+template <int EPI, int BN>
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
+  using C = Cfg8<BN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;   // group = wm; waves w and w + 4 share a SIMD
+  int pi, m0, n0;
+  select_tile<BN>(ga, pi, m0, n0);
+  const fk_gemm_args& p = ga.p[pi];
+  const int nk = p.K / C::BK;
+
+  // ---- LDS-DMA sources (as gemm2_kernel): piece = 8 rows x 128 B, lane -> (row, slot), source chunk = slot ^ swz(row).
+  // Wave w requests pieces 2w and 2w + 1 of every half-tile.
+  const int lrow = lane >> 3, slot = lane & 7;
+  const __amdgpu_buffer_rsrc_t rs_a =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.A + fk_row_offset(p.a, m0)), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.W + (int64_t)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
+  int a_voff[2][2], w_voff[2][2];   // [half][piece]
+  {
+    const TileRows arow(p.a, m0);
+    const int ldw2 = (int)p.ldw * 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int rl = h * 128 + (wave * 2 + j) * 8 + lrow;   // row inside the 256-row tile
+        const int sw = (slot ^ C::swz(rl)) << 4;
+        a_voff[h][j] = arow.off(min(rl, p.M - 1 - m0)) * 2 + sw;
+        w_voff[h][j] = min(rl, p.N - 1 - n0) * ldw2 + sw;
+      }
+  }
+  // which: 0 = A0, 1 = A1, 2 = W0, 3 = W1; kt is clamped (surplus requests are never read)
+  auto dma_half = [&](int which, int buf, int kt) {
+    const int koff = min(kt, nk - 1) * (C::BK * 2);
+    char* dst = smem + buf * C::BUF_BYTES + which * C::HALF_BYTES + wave * 2048;
+    if (which < 2) {
+      buffer_lds16(rs_a, dst, a_voff[which][0], koff);
+      buffer_lds16(rs_a, dst + 1024, a_voff[which][1], koff);
+    } else {
+      buffer_lds16(rs_w, dst, w_voff[which - 2][0], koff);
+      buffer_lds16(rs_w, dst + 1024, w_voff[which - 2][1], koff);
+    }
+  };
+
+  // ---- MFMA operand addressing -----------------------------------------------------------------------------------
+  const int frow = lane & 31, fhalf = lane >> 5, fsw = C::swz(frow);
+  int koffs[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) koffs[kk] = ((kk * 2 + fhalf) ^ fsw) << 4;
+  const int a_rd = (wm * 64 + frow) * C::ROW_BYTES;   // + sub * 4096 inside half-tile A_i
+  const int w_rd = (wn * 32 + frow) * C::ROW_BYTES;   // inside half-tile W_j
+
+  f32x16_t acc[C::NF][C::MF];
+#pragma unroll
+  for (int i = 0; i < C::NF; ++i)
+#pragma unroll
+    for (int j = 0; j < C::MF; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  bf16x8_t af[2][4], wf[2][4];   // A half in use [sub][kk]; W halves [j][kk]
+  auto read_a = [&](int buf, int h) {
+    const char* b = smem + buf * C::BUF_BYTES + h * C::HALF_BYTES + a_rd;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) af[sub][kk] = *(const bf16x8_t*)(b + sub * 4096 + koffs[kk]);
+  };
+  auto read_w = [&](int buf, int j) {
+    const char* b = smem + buf * C::BUF_BYTES + (2 + j) * C::HALF_BYTES + w_rd;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) wf[j][kk] = *(const bf16x8_t*)(b + koffs[kk]);
+  };
+  // quadrant (i, j): 2 m-blocks x 1 n-block x 4 k-steps, accumulators alternating
+  auto mma = [&](int i, int j) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+        acc[j][2 * i + sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][kk], af[sub][kk], acc[j][2 * i + sub], 0, 0, 0);
+  };
+  auto phase_sync_mma = [&](int i, int j) {
+    wait_vmcnt<10>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    mma(i, j);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: the seven half-tiles read in phases 0 .. 6, in reading order ------------------------------------
+  dma_half(2, 0, 0);   // W0(0)   read in "phase 0" (below)
+  dma_half(0, 0, 0);   // A0(0)   P1 of tile 0
+  dma_half(3, 0, 0);   // W1(0)   P2
+  dma_half(1, 0, 0);   // A1(0)   P3
+  dma_half(2, 1, 1);   // W0(1)   P4
+  dma_half(0, 1, 1);   // A0(1)   P1 of tile 1
+  dma_half(3, 1, 1);   // W1(1)   P2 of tile 1
+  wait_vmcnt<10>();    // W0(0), A0(0) (own pieces) landed
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  read_w(0, 0);
+  if (wm == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one barrier behind group 0
+  __builtin_amdgcn_sched_barrier(0);
+
+  auto tile_body = [&](auto bc, int kt) {
+    constexpr int b = decltype(bc)::value;
+    read_a(b, 0);            dma_half(1, b ^ 1, kt + 1);  phase_sync_mma(0, 0);
+    read_w(b, 1);            dma_half(2, b, kt + 2);      phase_sync_mma(0, 1);
+    read_a(b, 1);            dma_half(0, b, kt + 2);      phase_sync_mma(1, 0);
+    read_w(b ^ 1, 0);        dma_half(3, b, kt + 2);      phase_sync_mma(1, 1);
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    tile_body(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < nk) tile_body(std::integral_constant<int, 1>{}, kt + 1);
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus (clamped) requests must not land in the C tile
+
+  store_tile<EPI, BN, C>(acc, p, smem, m0, n0, wm, wn);
+}
+
+template <int EPI, int BN>
+int launch8(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) {
+  int total = 0;
+  for (int i = 0; i < FK_MAX_GROUP; ++i) {
+    ga.tiles_before[i] = total;
+    if (i < n) total += ((probs[i].M + BM - 1) / BM) * ((probs[i].N + BN - 1) / BN);
+  }
+  ga.tiles_before[FK_MAX_GROUP] = total;
+  auto kern = gemm8_kernel<EPI, BN>;
+  FK_ENSURE_MAX_LDS(kern, Cfg8<BN>::SMEM_BYTES, "fk_gemm_bf16 (256 x 256 tile, 8 waves ping-pong)");
+  hipLaunchKernelGGL(kern, dim3(total), dim3(512), Cfg8<BN>::SMEM_BYTES, stream, ga);
+  FK_CHECK_LAUNCH("fk_gemm_bf16 (256 x 256 tile, 8 waves ping-pong)");
+  return FK_OK;
+}
+
 template <int EPI, int BN>
 int launch(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) {
   int total = 0;
@@ -686,8 +877,10 @@ int launch5(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream)
   return FK_OK;
 }
 
+// variant: 128 = 256 x 128 (8 waves, lockstep), 256 = 256 x 256 (4 waves, register staged), 257 = 256 x 256 ping-pong
 template <int EPI>
 int launch_bn(GroupArgs& ga, const fk_gemm_args* probs, int n, int bn, hipStream_t stream) {
+  if (bn == 257) return launch8<EPI, 256>(ga, probs, n, stream);
   return bn == 256 ? launch5<EPI, 256>(ga, probs, n, stream) : launch<EPI, 128>(ga, probs, n, stream);
 }
 
@@ -743,8 +936,8 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t s
 
   const int G = cu_count();
   int bn = bn_hint;
-  if (bn == 256 && !ok256) bn = 128;
-  if (bn != 128 && bn != 256) {
+  if ((bn == 256 || bn == 257) && !ok256) bn = 128;
+  if (bn != 128 && bn != 256 && bn != 257) {
     auto eff = [G](long tiles) { return (double)tiles / (double)(((tiles + G - 1) / G) * G); };
     bn = (ok256 && FK_RATE_256 * eff(t256) > eff(t128)) ? 256 : 128;
   }

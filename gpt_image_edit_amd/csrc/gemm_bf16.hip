@@ -324,14 +324,21 @@ static int gemm_impl_override() {
   return v;
 }
 
-// FK_GEMM_BN=128|256 forces the N tile of the 256-row kernel (default: chosen per problem size).
+// FK_GEMM_BN=128|256|257 (or fk_gemm_set_variant) forces the large-tile kernel: 128 = 256 x 128 8-wave, 256 = 256 x 256
+// 4-wave register staged, 257 = 256 x 256 8-wave ping-pong; default 0: chosen per problem size.
+static int g_bn_override = -1;
 static int gemm_bn_override() {
-  static int v = -1;
-  if (v < 0) {
+  if (g_bn_override < 0) {
     const char* e = getenv("FK_GEMM_BN");
-    v = e ? atoi(e) : 0;
+    g_bn_override = e ? atoi(e) : 0;
   }
-  return v;
+  return g_bn_override;
+}
+extern "C" int fk_gemm_set_variant(int32_t variant) {
+  FK_CHECK_ARG(variant == 0 || variant == 128 || variant == 256 || variant == 257,
+               "fk_gemm_set_variant: %d is not one of 0 (automatic), 128, 256, 257", variant);
+  g_bn_override = variant;
+  return FK_OK;
 }
 
 extern "C" int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream_) {

@@ -1,0 +1,53 @@
+"""Within-process interleaved A/B of the large-tile GEMM kernels (fk_gemm_set_variant) and the vendor library on the
+path's shapes: N rounds, every variant once per round, ~0.12 s of back-to-back launches per measurement; prints the
+median and the best TF/s per (shape, variant).  `python tools/ab_gemm8.py [rounds] [epi]`."""
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gpt_image_edit_amd import libfk, ops  # noqa: E402
+
+BF = torch.bfloat16
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+epi = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+lib = libfk.load()
+shapes = [(2560, 9216, 3072), (2560, 12288, 3072), (2560, 3072, 12288), (2560, 3072, 15360), (2560, 3072, 3072),
+          (8704, 9216, 3072), (8704, 12288, 3072), (8704, 3072, 12288), (8704, 3072, 15360), (8704, 3072, 3072),
+          (32768, 12288, 3072), (32768, 3072, 12288), (32768, 9216, 3072)]
+variants = [128, 256, 257, "vendor"]
+for (M, N, K) in shapes:
+    a = (torch.rand(M, K, device="cuda") * 2 - 1).to(BF)
+    w = ((torch.rand(N, K, device="cuda") * 2 - 1) * 0.05).to(BF)
+    b = (torch.rand(N, device="cuda") * 2 - 1).to(BF)
+    out = torch.empty(M, N, device="cuda", dtype=BF)
+    fl = 2.0 * M * N * K
+    n_per = max(3, int(0.12 / (fl / 1.1e15)))
+    res = {v: [] for v in variants}
+    ref = None
+    for r in range(rounds + 1):
+        for v in variants:
+            if v == "vendor":
+                fn = lambda: torch.nn.functional.linear(a, w, b)  # noqa: E731
+            else:
+                lib.fk_gemm_set_variant(v)
+                fn = lambda: ops.gemm(a, w, b, out=out, epilogue=epi)  # noqa: E731
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n_per):
+                fn()
+            e1.record()
+            e1.synchronize()
+            if r:
+                res[v].append(fl * n_per / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+            elif v != "vendor":   # first round: the variants must agree bit for bit
+                if ref is None:
+                    ref = out.clone()
+                else:
+                    assert torch.equal(ref, out), f"variant {v} differs from variant 128 on {M}x{N}x{K}"
+    lib.fk_gemm_set_variant(0)
+    print(f"{M}x{N}x{K} epi{epi}: " + "  ".join(f"{v}: med {statistics.median(x):.0f} best {max(x):.0f}" for v, x in res.items()),
+          flush=True)
