@@ -701,9 +701,13 @@ struct Cfg8 {
   static FK_DEV int tile_col(int wn, int nf) { return nf * 128 + wn * 32; }
 };
 
-template <int EPI, int BN>
+// VAR (development A/B, fk_gemm_set_variant(257 + VAR)): bit 0 = ONE barrier per phase -- group 0 synchronises after its
+// load part, group 1 after its MFMAs, no stagger barrier: the same instruction stream, group 1 one quadrant ahead;
+// bit 1 = no s_setprio around the MFMA cluster.
+template <int EPI, int BN, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
   using C = Cfg8<BN>;
+  constexpr bool ONE_BAR = (VAR & 1) != 0, PRIO = (VAR & 2) == 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -788,14 +792,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
   auto phase_sync_mma = [&](int i, int j) {
     wait_vmcnt<10>();
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
+    if (!ONE_BAR || wm == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
     mma(i, j);
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
+    if (!ONE_BAR || wm == 1) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -812,7 +816,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   read_w(0, 0);
-  if (wm == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one barrier behind group 0
+  if (!ONE_BAR && wm == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one barrier behind group 0
   __builtin_amdgcn_sched_barrier(0);
 
   auto tile_body = [&](auto bc, int kt) {
@@ -826,13 +830,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
     tile_body(std::integral_constant<int, 0>{}, kt);
     if (kt + 1 < nk) tile_body(std::integral_constant<int, 1>{}, kt + 1);
   }
-  if (wm == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
+  if (!ONE_BAR && wm == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus (clamped) requests must not land in the C tile
 
   store_tile<EPI, BN, C>(acc, p, smem, m0, n0, wm, wn);
 }
 
-template <int EPI, int BN>
+template <int EPI, int BN, int VAR = 0>
 int launch8(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) {
   int total = 0;
   for (int i = 0; i < FK_MAX_GROUP; ++i) {
@@ -840,7 +844,7 @@ int launch8(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream)
     if (i < n) total += ((probs[i].M + BM - 1) / BM) * ((probs[i].N + BN - 1) / BN);
   }
   ga.tiles_before[FK_MAX_GROUP] = total;
-  auto kern = gemm8_kernel<EPI, BN>;
+  auto kern = gemm8_kernel<EPI, BN, VAR>;
   FK_ENSURE_MAX_LDS(kern, Cfg8<BN>::SMEM_BYTES, "fk_gemm_bf16 (256 x 256 tile, 8 waves ping-pong)");
   hipLaunchKernelGGL(kern, dim3(total), dim3(512), Cfg8<BN>::SMEM_BYTES, stream, ga);
   FK_CHECK_LAUNCH("fk_gemm_bf16 (256 x 256 tile, 8 waves ping-pong)");
@@ -880,7 +884,12 @@ int launch5(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream)
 // variant: 128 = 256 x 128 (8 waves, lockstep), 256 = 256 x 256 (4 waves, register staged), 257 = 256 x 256 ping-pong
 template <int EPI>
 int launch_bn(GroupArgs& ga, const fk_gemm_args* probs, int n, int bn, hipStream_t stream) {
-  if (bn == 257) return launch8<EPI, 256>(ga, probs, n, stream);
+  if (bn == 257) return launch8<EPI, 256, 0>(ga, probs, n, stream);
+  if constexpr (EPI == FK_EPI_NONE || EPI == FK_EPI_GELU_TANH) {   // development variants: two epilogues are enough
+    if (bn == 258) return launch8<EPI, 256, 1>(ga, probs, n, stream);
+    if (bn == 259) return launch8<EPI, 256, 2>(ga, probs, n, stream);
+    if (bn == 260) return launch8<EPI, 256, 3>(ga, probs, n, stream);
+  } else if (bn > 257) return launch8<EPI, 256, 0>(ga, probs, n, stream);
   return bn == 256 ? launch5<EPI, 256>(ga, probs, n, stream) : launch<EPI, 128>(ga, probs, n, stream);
 }
 
@@ -936,8 +945,8 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t s
 
   const int G = cu_count();
   int bn = bn_hint;
-  if ((bn == 256 || bn == 257) && !ok256) bn = 128;
-  if (bn != 128 && bn != 256 && bn != 257) {
+  if (bn >= 256 && !ok256) bn = 128;
+  if (bn != 128 && (bn < 256 || bn > 260)) {
     auto eff = [G](long tiles) { return (double)tiles / (double)(((tiles + G - 1) / G) * G); };
     bn = (ok256 && FK_RATE_256 * eff(t256) > eff(t128)) ? 256 : 128;
   }
