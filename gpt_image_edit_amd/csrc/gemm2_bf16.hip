@@ -44,7 +44,7 @@ constexpr int NT = 512;
 constexpr int GROUP_M = FK_GROUP_M;
 // steady-state rate of the 256 x 256 kernel relative to the 256 x 128 one (measured)
 #ifndef FK_RATE_256
-#define FK_RATE_256 1.12
+#define FK_RATE_256 1.22
 #endif
 #ifndef FK_BSLOT
 #define FK_BSLOT 3
@@ -948,9 +948,9 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t s
   if (bn >= 256 && !ok256) bn = 128;
   if (bn != 128 && (bn < 256 || bn > 260)) {
     auto eff = [G](long tiles) { return (double)tiles / (double)(((tiles + G - 1) / G) * G); };
-    bn = (ok256 && FK_RATE_256 * eff(t256) > eff(t128)) ? 256 : 128;
+    bn = (ok256 && FK_RATE_256 * eff(t256) > eff(t128)) ? 257 : 128;   // 257: the ping-pong kernel owns the 256 x 256 tile
   }
-  g_last_variant = bn;
+  g_last_variant = bn >= 256 ? 256 : 128;   // reported as the tile width
   switch (probs[0].epilogue) {
     case FK_EPI_NONE: return launch_bn<FK_EPI_NONE>(ga, probs, n, bn, stream);
     case FK_EPI_GELU_TANH: return launch_bn<FK_EPI_GELU_TANH>(ga, probs, n, bn, stream);
