@@ -296,7 +296,7 @@ class HipFluxTransformer2DModel(nn.Module):
                             cos=cos, sin=sin, s_offset=S_txt)
                 qk_t = dict(q_out=ws.q, k_out=ws.k, wq=P(p + "attn.norm_added_q.weight"),
                             wk=P(p + "attn.norm_added_k.weight"), cos=cos, sin=sin, s_offset=0)
-                if self._split_qkv(B * S):
+                if self._split_qkv(B * ws.S):
                     # q | k columns (N = 2D) and v columns (N = D) as two launches: see _split_qkv
                     ops.gemm_grouped([dict(a=n_img, w=blk.wqkv_img[:2 * D], bias=blk.bqkv_img[:2 * D],
                                            out=ws.qkv[:, S_txt:, :2 * D], qkv=qk_i),
@@ -337,7 +337,7 @@ class HipFluxTransformer2DModel(nn.Module):
             if FUSE_QKV:
                 qk = dict(q_out=ws.q, k_out=ws.k, wq=P(p + "attn.norm_q.weight"), wk=P(p + "attn.norm_k.weight"),
                           cos=cos, sin=sin, s_offset=0)
-                if self._split_qkv(B * S):
+                if self._split_qkv(B * ws.S):
                     ops.gemm(n, blk.wqkv[:2 * D], blk.bqkv[:2 * D], out=ws.qkv[:, :, :2 * D], epilogue=ops.FK_EPI_QKV, qkv=qk)
                     ops.gemm(n, blk.wqkv[2 * D:], blk.bqkv[2 * D:], out=ws.qkv[:, :, 2 * D:])
                 else:
