@@ -305,8 +305,10 @@ static int validate_gemm(const fk_gemm_args& p) {
   if (p.epilogue == FK_EPI_QKV) {
     FK_CHECK_ARG(!p.out_fp32 && p.q_out && p.k_out && p.wq && p.wk && p.rope_cos && p.rope_sin,
                  "fk_gemm_bf16: FK_EPI_QKV needs q_out/k_out/wq/wk/rope tables");
-    FK_CHECK_ARG(p.qkv_heads > 0 && p.N == 3 * p.qkv_heads * 128 && p.qkv_s_total > 0 && p.qkv_s_offset >= 0,
-                 "fk_gemm_bf16: FK_EPI_QKV needs N = 3*H*128");
+    // N = 3*H*128: q | k | v columns; N = 2*H*128: the q | k columns only (the v columns as a plain GEMM of their own)
+    FK_CHECK_ARG(p.qkv_heads > 0 && (p.N == 3 * p.qkv_heads * 128 || p.N == 2 * p.qkv_heads * 128) && p.qkv_s_total > 0 &&
+                     p.qkv_s_offset >= 0,
+                 "fk_gemm_bf16: FK_EPI_QKV needs N = 3*H*128 (q | k | v) or 2*H*128 (q | k)");
     FK_CHECK_ARG(((uintptr_t)p.q_out % 16 == 0) && ((uintptr_t)p.k_out % 16 == 0) && ((uintptr_t)p.wq % 16 == 0) &&
                      ((uintptr_t)p.wk % 16 == 0) && ((uintptr_t)p.rope_cos % 16 == 0) && ((uintptr_t)p.rope_sin % 16 == 0),
                  "fk_gemm_bf16: FK_EPI_QKV pointers must be 16-byte aligned");

@@ -43,7 +43,7 @@ enum {
  *   FK_EPI_GATE_RES  : y = bf16(res + bf16(gate[b] * y))   (gate_msa.unsqueeze(1) * attn_out; h + ...)
  *   FK_EPI_RES       : y = bf16(res + y)                   (ResnetBlock2D / VAE attention residual)
  *   FK_EPI_SCALE     : y = bf16(alpha * acc)  (no bias)    (attention scores for the VAE mid block)
- *   FK_EPI_QKV       : fused QKV projection of FluxAttnProcessor2_0 (N = 3*H*128 = q | k | v): the q and k
+ *   FK_EPI_QKV       : fused QKV projection of FluxAttnProcessor2_0 (N = 3*H*128 = q | k | v, or 2*H*128 = q | k): the q and k
  *                      thirds get per-head RMSNorm(eps 1e-6, weight) + interleaved RoPE and are written
  *                      head-major to q_out / k_out [B, H, S_total, 128]; the v third is stored like
  *                      FK_EPI_NONE into C (= the qkv buffer the attention kernel reads V from).
