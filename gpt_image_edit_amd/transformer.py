@@ -30,7 +30,6 @@ from . import flux_spec, ops
 BF16 = torch.bfloat16
 # FK_FUSE_QKV=0 keeps RMSNorm+RoPE as the separate fk_qkv_post_bf16 pass (A/B measurement, identical results)
 FUSE_QKV = os.environ.get("FK_FUSE_QKV", "1") != "0"
-SPLIT_QKV = {"0": False, "1": True}.get(os.environ.get("FK_SPLIT_QKV", ""))
 
 
 def rope_tables(ids, axes_dim=(16, 56, 56), theta=10000.0):
@@ -158,21 +157,6 @@ class HipFluxTransformer2DModel(nn.Module):
         self._ws = {key: ws}  # keep only the latest shape
         return ws
 
-    def _split_qkv(self, rows):
-        """Whether the fused QKV projection (N = 3D) runs as two launches, q | k columns (N = 2D) + v columns (N = D).
-
-        With few row tiles the 3D-wide grid suits neither large tile: at M = 2560 it is 360 tiles of 256 x 256 (1.4
-        rounds of 256 CUs) or 720 of 256 x 128 (the slower kernel).  Split, the 2D part is 240 tiles of 256 x 256 --
-        one round on the ping-pong kernel -- and the D part 240 tiles of 256 x 128.  Same arithmetic per output
-        element (K order unchanged), one more launch.  FK_SPLIT_QKV=0/1 overrides (A/B)."""
-        if SPLIT_QKV is not None:
-            return SPLIT_QKV
-        row_tiles = (rows + 255) // 256
-        cus = 256
-        t_3d, t_2d = row_tiles * (3 * self.inner_dim // 256), row_tiles * (2 * self.inner_dim // 256)
-        # the 3D grid is a full round plus a poorly filled second one, the 2D grid nearly one full round
-        return cus < t_3d < 1.5 * cus and 0.75 * cus < t_2d <= cus
-
     def _rope(self, txt_ids, img_ids):
         # Step-invariant: keyed on the identity of the id tensors (the pipeline passes the same objects for
         # all 28 steps), so the hot loop never reads ids back to the host.  Strong refs keep the ids alive.
@@ -292,24 +276,13 @@ class HipFluxTransformer2DModel(nn.Module):
             # text + image streams share every launch: joint LN+modulate, grouped GEMMs (one grid, two weights)
             ops.ln_modulate2(s, chunk(mt, 0), chunk(mt, 1), chunk(mi, 0), chunk(mi, 1), S_txt, out=n)
             if FUSE_QKV:  # RMSNorm + RoPE + head-major q / k come out of the projection GEMM's epilogue
-                qk_i = dict(q_out=ws.q, k_out=ws.k, wq=P(p + "attn.norm_q.weight"), wk=P(p + "attn.norm_k.weight"),
-                            cos=cos, sin=sin, s_offset=S_txt)
-                qk_t = dict(q_out=ws.q, k_out=ws.k, wq=P(p + "attn.norm_added_q.weight"),
-                            wk=P(p + "attn.norm_added_k.weight"), cos=cos, sin=sin, s_offset=0)
-                if self._split_qkv(B * ws.S):
-                    # q | k columns (N = 2D) and v columns (N = D) as two launches: see _split_qkv
-                    ops.gemm_grouped([dict(a=n_img, w=blk.wqkv_img[:2 * D], bias=blk.bqkv_img[:2 * D],
-                                           out=ws.qkv[:, S_txt:, :2 * D], qkv=qk_i),
-                                      dict(a=n_txt, w=blk.wqkv_txt[:2 * D], bias=blk.bqkv_txt[:2 * D],
-                                           out=ws.qkv[:, :S_txt, :2 * D], qkv=qk_t)], epilogue=ops.FK_EPI_QKV)
-                    ops.gemm_grouped([dict(a=n_img, w=blk.wqkv_img[2 * D:], bias=blk.bqkv_img[2 * D:],
-                                           out=ws.qkv[:, S_txt:, 2 * D:]),
-                                      dict(a=n_txt, w=blk.wqkv_txt[2 * D:], bias=blk.bqkv_txt[2 * D:],
-                                           out=ws.qkv[:, :S_txt, 2 * D:])])
-                else:
-                    ops.gemm_grouped([dict(a=n_img, w=blk.wqkv_img, bias=blk.bqkv_img, out=ws.qkv[:, S_txt:], qkv=qk_i),
-                                      dict(a=n_txt, w=blk.wqkv_txt, bias=blk.bqkv_txt, out=ws.qkv[:, :S_txt], qkv=qk_t)],
-                                     epilogue=ops.FK_EPI_QKV)
+                ops.gemm_grouped([dict(a=n_img, w=blk.wqkv_img, bias=blk.bqkv_img, out=ws.qkv[:, S_txt:],
+                                       qkv=dict(q_out=ws.q, k_out=ws.k, wq=P(p + "attn.norm_q.weight"),
+                                                wk=P(p + "attn.norm_k.weight"), cos=cos, sin=sin, s_offset=S_txt)),
+                                  dict(a=n_txt, w=blk.wqkv_txt, bias=blk.bqkv_txt, out=ws.qkv[:, :S_txt],
+                                       qkv=dict(q_out=ws.q, k_out=ws.k, wq=P(p + "attn.norm_added_q.weight"),
+                                                wk=P(p + "attn.norm_added_k.weight"), cos=cos, sin=sin, s_offset=0))],
+                                 epilogue=ops.FK_EPI_QKV)
             else:
                 ops.gemm_grouped([dict(a=n_img, w=blk.wqkv_img, bias=blk.bqkv_img, out=ws.qkv[:, S_txt:]),
                                   dict(a=n_txt, w=blk.wqkv_txt, bias=blk.bqkv_txt, out=ws.qkv[:, :S_txt])])
@@ -335,13 +308,9 @@ class HipFluxTransformer2DModel(nn.Module):
             m0 = blk.mod  # chunks: shift, scale, gate
             ops.ln_modulate(s, chunk(m0, 0), chunk(m0, 1), out=n)
             if FUSE_QKV:
-                qk = dict(q_out=ws.q, k_out=ws.k, wq=P(p + "attn.norm_q.weight"), wk=P(p + "attn.norm_k.weight"),
-                          cos=cos, sin=sin, s_offset=0)
-                if self._split_qkv(B * ws.S):
-                    ops.gemm(n, blk.wqkv[:2 * D], blk.bqkv[:2 * D], out=ws.qkv[:, :, :2 * D], epilogue=ops.FK_EPI_QKV, qkv=qk)
-                    ops.gemm(n, blk.wqkv[2 * D:], blk.bqkv[2 * D:], out=ws.qkv[:, :, 2 * D:])
-                else:
-                    ops.gemm(n, blk.wqkv, blk.bqkv, out=ws.qkv, epilogue=ops.FK_EPI_QKV, qkv=qk)
+                ops.gemm(n, blk.wqkv, blk.bqkv, out=ws.qkv, epilogue=ops.FK_EPI_QKV,
+                         qkv=dict(q_out=ws.q, k_out=ws.k, wq=P(p + "attn.norm_q.weight"),
+                                  wk=P(p + "attn.norm_k.weight"), cos=cos, sin=sin, s_offset=0))
             else:
                 ops.gemm(n, blk.wqkv, blk.bqkv, out=ws.qkv)
                 ops.qkv_post(ws.qkv, ws.q, ws.k, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"), None, None,
