@@ -1,33 +1,26 @@
 // Large-tile bf16 MFMA GEMMs for the MMDiT linears (same contract as gemm_bf16.hip, used when M >= 192).
 // v_mfma_f32_32x32x16_bf16, operands swapped like gemm_bf16.hip (W rows -> MFMA A operand) so a lane owns 4
 // consecutive output columns of one row.  Two kernels, chosen per problem by (tile-quantisation efficiency) x
-// (measured steady-state rate):
+// (measured steady-state rate); both accumulate over K in the same order, so they agree bit for bit:
 //
-//   gemm2_kernel   256 x 128 x 64, 8 waves (4 x 2, 64 x 64 per wave), buffer-form LDS-DMA staging into a 3-stage ring,
+//   gemm2_kernel   256 x 128 x 64, 8 waves (4 x 2, 64 x 64 per wave) in lockstep, LDS-DMA staging into a 3-stage ring,
 //                  straight-line k-loop with the next k-step's fragment reads pinned in front of this one's MFMAs
-//   gemm5_kernel   256 x 256 x 64, 4 waves (2 x 2, 128 x 128 per wave, one wave per SIMD, accumulators in AGPRs),
-//                  buffer_load -> VGPR -> ds_write_b128 staging into a 2-stage ring, slot-scheduled k-loop
+//   gemm8_kernel   256 x 256 x 64, 8 waves (2 x 4, 128 x 64 per wave) in two groups that alternate between an MFMA
+//                  phase and an LDS-read / LDS-DMA phase ("ping-pong"), 8 half-tile slots = 128 KiB
 //
-// What the measurements of round 1 say (tools/pmc_gemm_compare.sh, tools/trace_gemm.py):
-//  * Under sustained MFMA load the chip clocks ~1.4-1.5 GHz, so the at-clock ceiling is ~1.5 PFLOP/s; the vendor
-//    library's hand-written 256x256 kernel keeps the MFMA pipe 90 % busy there (1.48 PF/s on 32768x3072x12288).
-//  * All 8-wave variants tried (LDS-DMA 2/3/4 stages, mid-tile or end-of-tile barrier, register staging, weights
-//    streamed straight into registers from a fragment-packed copy, phase-staggered waves) land on the same
-//    1.0-1.1 PF/s plateau with the pipe ~64 % busy and the waves 26-28 % parked in s_waitcnt/s_barrier; removing
-//    every vmcnt wait changes nothing, i.e. not memory latency.  (Probes that disable the staging run on stale,
-//    constant LDS data and clock higher: their 1.4-1.56 PF/s "ceilings" are not comparable.)
-//  * s_memtime traces of a 4-wave kernel: a k-step of 16 MFMAs + 8 ds_read_b128 takes ~540 cycles (ideal 512), but
-//    each `global_load_lds_dwordx4` adds 54-68 cycles of ISSUE time to its wave -- longer than the 28-cycle shadow
-//    of an MFMA, so the matrix pipe drains behind every piece (8 pieces per 32 MFMAs -> 68 % busy, exactly what
-//    the counters show).  `buffer_load_dwordx4` (one address VGPR) + `ds_write_b128` are two short instructions
-//    that each fit a shadow: gemm5_kernel reaches 75 % busy / 1.20 PF/s with the slots pinned in source order.
+// What the measurements say (rounds 1 and 2; DESIGN.md section 4, profiles/r0x_gemm_*):
+//  * The chip is POWER-bound under MFMA load: 1.27-1.45 GHz instead of 2.4.  What a kernel can win is (matrix pipe
+//    busy) x (clock its energy per flop leaves).  gemm8_kernel keeps the pipe 89 % busy (the vendor library's
+//    hand-written kernel: 89 %) but clocks 1.27 GHz against 1.42: 0.75 LDS fragment reads per MFMA against 0.5 for
+//    128 x 128 wave tiles.
+//  * An LDS-DMA request costs its wave >= 60 ISSUE cycles, longer than the 28-cycle shadow of an MFMA: with one wave
+//    per SIMD (the round-1 `gemm5` 4-wave kernels: 76 % busy) the pipe drains behind every piece; with two waves per
+//    SIMD in opposite phases it is free.  In lockstep (gemm2_kernel) the 8 waves reach 68 % busy.
 //  * `global_load_lds` is a FLAT-class instruction: while one is pending hipcc turns every `lgkmcnt(N)` wait into
-//    `lgkmcnt(0)`, so the wait in front of an MFMA also waits for the reads just issued for the NEXT k-step.  The
-//    MUBUF form (`buffer_load_dwordx4 ... lds`) keeps the counts exact; with it, unconditional (clamped) requests
-//    and sched_group_barrier-pinned read/MFMA order gemm2_kernel gained 4-15 % (68 % busy).
+//    `lgkmcnt(0)`.  The MUBUF form (`buffer_load_dwordx4 ... lds`) keeps the counts exact.
 //
 // The LDS image of a tile row is 128 B (64 k); the bank-conflict swizzle (16-byte chunk ^ ((row >> 1) & 7)) is
-// applied where the tile is written (DMA source address / ds_write address) and again on the ds_read_b128 side.
+// applied where the tile is written (DMA source address) and again on the ds_read_b128 side.
 // Up to FK_MAX_GROUP problems with identical (N, K, epilogue) share one launch ("grouped GEMM"): the
 // text- and image-stream linears of a double block become one grid.
 #include <type_traits>
@@ -42,15 +35,9 @@ constexpr int NT = 512;
 #define FK_GROUP_M 8
 #endif
 constexpr int GROUP_M = FK_GROUP_M;
-// steady-state rate of the 256 x 256 kernel relative to the 256 x 128 one (measured)
+// steady-state rate of the 256 x 256 kernel relative to the 256 x 128 one (measured: 1.23-1.27 on full grids)
 #ifndef FK_RATE_256
 #define FK_RATE_256 1.22
-#endif
-#ifndef FK_BSLOT
-#define FK_BSLOT 3
-#endif
-#ifndef FK_TRACE
-#define FK_TRACE 0  // development: s_memtime stamps of gemm5_kernel (tools/trace_gemm.py)
 #endif
 
 
@@ -484,187 +471,6 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GroupArgs ga) {
   store_tile<EPI, BN, C>(acc, p, smem, m0, n0, wm, wn);
 }
 
-// ---- 4 waves, register staged --------------------------------------------------------------------------------
-// s_memtime traces of an LDS-DMA 4-wave variant: a k-step of 16 MFMAs + 8 ds_read_b128 runs in ~540 cycles (ideal 512), but
-// every `global_load_lds_dwordx4` adds 54-68 cycles of ISSUE time to the wave -- longer than the 28-cycle shadow
-// of an MFMA, so with one wave per SIMD the matrix pipe drains behind each piece (8 pieces per 32 MFMAs -> 68 %,
-// exactly what the counters show).  Plain `global_load_dwordx4` + `ds_write_b128` are two short instructions that
-// each fit into an MFMA shadow, which is what the vendor kernel does.  Tile t+1 travels global -> registers during
-// tile t-1.., registers -> LDS during tile t (a k-step's worth per k-step), and is multiplied during tile t+1.
-template <int BN>
-struct Cfg5 {
-  static_assert(BN == 256, "the 4-wave kernel is instantiated for the 256 x 256 tile only");
-  static constexpr int NTHREADS = 256;
-  static constexpr int BK = 64, STAGES = 2, KS = 4, CH = 8, ROW_BYTES = 128, RPI = 8;
-  static constexpr int WAVES_M = 2, WAVES_N = 2;
-  static constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
-  static constexpr int MF = WTM / 32, NF = WTN / 32;
-  static constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES;
-  static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-  static constexpr int A_LOADS = A_BYTES / 1024 / 4, W_LOADS = W_BYTES / 1024 / 4;
-  static constexpr int LOADS = A_LOADS + W_LOADS;
-  static constexpr int PPK = LOADS / KS;
-  static constexpr int GAP = (NF * MF) / PPK;
-  static constexpr int FRAG_STRIDE = 32 * ROW_BYTES;
-  static constexpr int CT_LD = BN + 8;
-  static constexpr int CT_BYTES = BM * CT_LD * 2;
-  static constexpr int SMEM_BYTES = (STAGES * STAGE_BYTES > CT_BYTES) ? STAGES * STAGE_BYTES : CT_BYTES;
-  static_assert(LOADS % KS == 0, "pieces must divide over the k-steps");
-  static FK_DEV int swz(int row) { return (row >> 1) & 7; }
-  static FK_DEV int tile_row(int wm, int mf) { return wm * WTM + mf * 32; }
-  static FK_DEV int tile_col(int wn, int nf) { return wn * WTN + nf * 32; }
-};
-
-// k-loop of one work item of the 4-wave kernel: acc = A[m0.., kb*BK ..] x W[n0.., kb*BK ..]^T over `nit` K-tiles.
-template <int BN>
-FK_DEV void gemm5_mainloop(const fk_gemm_args& p, int m0, int n0, int kb, int nit, char* smem,
-                           f32x16_t (&acc)[Cfg5<BN>::NF][Cfg5<BN>::MF], int wave, int lane, int wm, int wn) {
-  using C = Cfg5<BN>;
-  constexpr int BK = C::BK, KS = C::KS;
-
-  // Buffer loads: one SGPR descriptor per operand (base = first row of the tile), a 32-bit per-lane byte offset
-  // per piece (constant over K) and the K offset in an SGPR -- one address VGPR per load and no VALU address math.
-  // piece i of a tile = 8 rows x 128 B; lane -> (row = lane/8, chunk = lane%8), stored at slot chunk ^ swz(row)
-  const int lrow = lane >> 3, chunk = lane & 7;
-  const bf16_t* a_base = (const bf16_t*)p.A + fk_row_offset(p.a, m0);
-  const bf16_t* w_base = (const bf16_t*)p.W + (int64_t)n0 * p.ldw;
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, 0x7fffffff, 0x00020000);
-  int voff[C::LOADS], dst[C::LOADS];
-  const TileRows arow(p.a, m0);
-  const int ldw2 = (int)p.ldw * 2;
-#pragma unroll
-  for (int j = 0; j < C::LOADS; ++j) {
-    const bool isA = j < C::A_LOADS;
-    const int rl = (wave * (isA ? C::A_LOADS : C::W_LOADS) + (isA ? j : j - C::A_LOADS)) * C::RPI + lrow;
-    if (isA) voff[j] = arow.off(min(rl, p.M - 1 - m0)) * 2 + chunk * 16;
-    else voff[j] = min(rl, p.N - 1 - n0) * ldw2 + chunk * 16;
-    dst[j] = (isA ? 0 : C::A_BYTES) + rl * C::ROW_BYTES + ((chunk ^ C::swz(rl)) << 4);
-  }
-  auto gload = [&](int i, int koff_bytes) {
-    return __builtin_amdgcn_raw_buffer_load_b128(i < C::A_LOADS ? rs_a : rs_w, voff[i], koff_bytes, 0);
-  };
-
-  const int frow = lane & 31, fhalf = lane >> 5, fsw = C::swz(frow);
-  const int a_rd = (wm * C::WTM + frow) * C::ROW_BYTES;
-  const int w_rd = C::A_BYTES + (wn * C::WTN + frow) * C::ROW_BYTES;
-
-#pragma unroll
-  for (int i = 0; i < C::NF; ++i)
-#pragma unroll
-    for (int j = 0; j < C::MF; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  bf16x8_t af[2][C::MF], wf[2][C::NF];
-  auto read_frag = [&](int buf, const char* sb, int kk, int f) {
-    const int coff = (((kk * 2 + fhalf) ^ fsw) << 4);
-    if (f < C::MF) af[buf][f] = *(const bf16x8_t*)(sb + a_rd + f * C::FRAG_STRIDE + coff);
-    else wf[buf][f - C::MF] = *(const bf16x8_t*)(sb + w_rd + (f - C::MF) * C::FRAG_STRIDE + coff);
-  };
-  // bytes; clamped: surplus tiles are never multiplied
-  auto koff_of = [&](int t) { return (kb + min(t, nit - 1)) * (BK * 2); };
-
-  // Staging registers.  Pieces [0, PPK) ("quarter 0") run one tile ahead of the others: they are written in the
-  // LAST k-step of an iteration (after its barrier, into the stage that barrier freed).
-  typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned g_t;
-  g_t g[C::LOADS];
-  // fill: tile 0 -> stage 0 entirely; tile 1: quarter 0 -> stage 1, rest in registers; quarter 0 registers <- tile 2
-#pragma unroll
-  for (int i = 0; i < C::LOADS; ++i) g[i] = gload(i, koff_of(0));
-#pragma unroll
-  for (int i = 0; i < C::LOADS; ++i) *(g_t*)(smem + dst[i]) = g[i];
-#pragma unroll
-  for (int i = 0; i < C::LOADS; ++i) g[i] = gload(i, koff_of(1));
-#pragma unroll
-  for (int i = 0; i < C::PPK; ++i) {
-    *(g_t*)(smem + C::STAGE_BYTES + dst[i]) = g[i];
-    g[i] = gload(i, koff_of(2));
-  }
-  __syncthreads();
-#pragma unroll
-  for (int f = 0; f < C::MF + C::NF; ++f) read_frag(0, smem, 0, f);
-
-  // One k-step = NM MFMA slots, pinned in source order (every filler must fit the 28-cycle shadow of its MFMA):
-  //   slots R0+1..R0+NFR  one ds_read_b128 of the next k-step's fragments each
-  //   slots W0, W0+2, ..  ds_write_b128 of staging piece q (registers -> LDS), W0 = NM - 2*PPK
-  //   slots W0+1, W0+3,.. buffer_load of the same registers for the next tile
-  // The last k-step of a tile carries the tile's barrier in front of slot R0 = BSLOT instead of at the k-step
-  // boundary: the LDS traffic of k-step KS-2 drains under the first BSLOT MFMAs instead of in front of a waitcnt.
-  auto kstep = [&](int cb, const char* sb_rd, int kk_rd, int p0, char* sb_wr, int koff, int r0, bool barrier) {
-    const int nb = cb ^ 1;
-    constexpr int NM = C::NF * C::MF, NFR = C::MF + C::NF, W0 = NM - 2 * C::PPK;
-#pragma unroll
-    for (int i = 0; i < NM; ++i) {
-      const int nf = i / C::MF, mf = i % C::MF;
-      if (barrier && i == r0) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      acc[nf][mf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][nf], af[cb][mf], acc[nf][mf], 0, 0, 0);
-      if (i >= r0 + 1 && i - r0 - 1 < NFR) read_frag(nb, sb_rd, kk_rd, i - r0 - 1);
-      if (i >= W0) {
-        const int pc = p0 + (i - W0) / 2;
-        if (((i - W0) & 1) == 0) *(g_t*)(sb_wr + dst[pc]) = g[pc];
-        else g[pc] = gload(pc, koff);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-#if FK_TRACE
-  int* trace = (int*)(smem + C::SMEM_BYTES) + wave * 256;
-  auto stamp = [&](int j, int ev) {
-    if (j >= 16 && j < 32 && lane == 0) trace[(j - 16) * 8 + ev] = (int)__builtin_amdgcn_s_memtime();
-  };
-#else
-  auto stamp = [&](int, int) {};
-#endif
-  for (int j = 0; j < nit; ++j) {
-    char* sb = smem + (j & 1) * C::STAGE_BYTES;
-    char* sb_nx = smem + ((j + 1) & 1) * C::STAGE_BYTES;
-    const int koff2 = koff_of(j + 2), koff3 = koff_of(j + 3);
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      stamp(j, kk);
-      // k-steps 0..2: quarters 1..3 of tile j+1 -> the other stage (free since the previous barrier), registers
-      // <- tile j+2;   k-step 3 (after this iteration's barrier): quarter 0 of tile j+2 -> this stage, <- tile j+3
-      if (kk < KS - 1) kstep(kk & 1, sb, kk + 1, (kk + 1) * C::PPK, sb_nx, koff2, 0, false);
-      else kstep(kk & 1, sb_nx, 0, 0, sb, koff3, FK_BSLOT, true);  // barrier: tile j+1 complete in LDS, reads of tile j done
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
-
-template <int EPI, int BN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm5_kernel(const GroupArgs ga) {
-  using C = Cfg5<BN>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave % C::WAVES_M, wn = wave / C::WAVES_M;
-  int pi, m0, n0;
-  select_tile<BN>(ga, pi, m0, n0);
-  const fk_gemm_args& p = ga.p[pi];
-  f32x16_t acc[C::NF][C::MF];
-  gemm5_mainloop<BN>(p, m0, n0, 0, p.K / C::BK, smem, acc, wave, lane, wm, wn);
-#if FK_TRACE
-  {
-    int* trace = (int*)(smem + C::SMEM_BYTES) + wave * 256;
-    __syncthreads();
-    if (p.rope_cos && (blockIdx.x & 63) == 0) {
-      int* gt = (int*)p.rope_cos + ((blockIdx.x >> 6) * 4 + wave) * 128;
-      for (int i = lane; i < 128; i += 64) gt[i] = trace[i];
-    }
-    __syncthreads();
-  }
-#endif
-  store_tile<EPI, BN, C>(acc, p, smem, m0, n0, wm, wn);
-}
-
-
 // ---- 8 waves in two groups that alternate between "multiply" and "load" ("ping-pong") ----------------------------
 // 256 x 256 x 64 tile, waves 2 (M) x 4 (N); a wave's output is FOUR 64 x 32 quadrants: rows {128 i + 64 wm + [0,64)} x
 // columns {128 j + 32 wn + [0,32)}, i, j in {0,1}.  The A and W tiles are kept in LDS as two 128-row half-tiles each
@@ -701,13 +507,11 @@ struct Cfg8 {
   static FK_DEV int tile_col(int wn, int nf) { return nf * 128 + wn * 32; }
 };
 
-// VAR (development A/B, fk_gemm_set_variant(257 + VAR)): bit 0 = ONE barrier per phase -- group 0 synchronises after its
-// load part, group 1 after its MFMAs, no stagger barrier: the same instruction stream, group 1 one quadrant ahead;
-// bit 1 = no s_setprio around the MFMA cluster.
-template <int EPI, int BN, int VAR>
+// Measured and dropped (tools/ab_gemm8.py, same process, interleaved): ONE barrier per phase (group 0 synchronising after
+// its load part, group 1 after its MFMAs, no stagger) -1.5 %; no s_setprio around the MFMA cluster +-0.
+template <int EPI, int BN>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
   using C = Cfg8<BN>;
-  constexpr bool ONE_BAR = (VAR & 1) != 0, PRIO = (VAR & 2) == 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -792,14 +596,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
   auto phase_sync_mma = [&](int i, int j) {
     wait_vmcnt<10>();
     __builtin_amdgcn_sched_barrier(0);
-    if (!ONE_BAR || wm == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);
     mma(i, j);
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    if (!ONE_BAR || wm == 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -816,7 +620,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   read_w(0, 0);
-  if (!ONE_BAR && wm == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one barrier behind group 0
+  if (wm == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one barrier behind group 0
   __builtin_amdgcn_sched_barrier(0);
 
   auto tile_body = [&](auto bc, int kt) {
@@ -830,13 +634,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
     tile_body(std::integral_constant<int, 0>{}, kt);
     if (kt + 1 < nk) tile_body(std::integral_constant<int, 1>{}, kt + 1);
   }
-  if (!ONE_BAR && wm == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
+  if (wm == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus (clamped) requests must not land in the C tile
 
   store_tile<EPI, BN, C>(acc, p, smem, m0, n0, wm, wn);
 }
 
-template <int EPI, int BN, int VAR = 0>
+template <int EPI, int BN>
 int launch8(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) {
   int total = 0;
   for (int i = 0; i < FK_MAX_GROUP; ++i) {
@@ -844,7 +648,7 @@ int launch8(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream)
     if (i < n) total += ((probs[i].M + BM - 1) / BM) * ((probs[i].N + BN - 1) / BN);
   }
   ga.tiles_before[FK_MAX_GROUP] = total;
-  auto kern = gemm8_kernel<EPI, BN, VAR>;
+  auto kern = gemm8_kernel<EPI, BN>;
   FK_ENSURE_MAX_LDS(kern, Cfg8<BN>::SMEM_BYTES, "fk_gemm_bf16 (256 x 256 tile, 8 waves ping-pong)");
   hipLaunchKernelGGL(kern, dim3(total), dim3(512), Cfg8<BN>::SMEM_BYTES, stream, ga);
   FK_CHECK_LAUNCH("fk_gemm_bf16 (256 x 256 tile, 8 waves ping-pong)");
@@ -866,31 +670,10 @@ int launch(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) 
   return FK_OK;
 }
 
-template <int EPI, int BN>
-int launch5(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) {
-  int total = 0;
-  for (int i = 0; i < FK_MAX_GROUP; ++i) {
-    ga.tiles_before[i] = total;
-    if (i < n) total += ((probs[i].M + BM - 1) / BM) * ((probs[i].N + BN - 1) / BN);
-  }
-  ga.tiles_before[FK_MAX_GROUP] = total;
-  auto kern = gemm5_kernel<EPI, BN>;
-  FK_ENSURE_MAX_LDS(kern, Cfg5<BN>::SMEM_BYTES + (FK_TRACE ? 4096 : 0), "fk_gemm_bf16 (256-row tile, 4 waves)");
-  hipLaunchKernelGGL(kern, dim3(total), dim3(256), Cfg5<BN>::SMEM_BYTES + (FK_TRACE ? 4096 : 0), stream, ga);
-  FK_CHECK_LAUNCH("fk_gemm_bf16 (256-row tile, 4 waves, register staged)");
-  return FK_OK;
-}
-
-// variant: 128 = 256 x 128 (8 waves, lockstep), 256 = 256 x 256 (4 waves, register staged), 257 = 256 x 256 ping-pong
+// variant: 128 = 256 x 128 (8 waves, lockstep), 256 = 256 x 256 (8 waves, ping-pong)
 template <int EPI>
 int launch_bn(GroupArgs& ga, const fk_gemm_args* probs, int n, int bn, hipStream_t stream) {
-  if (bn == 257) return launch8<EPI, 256, 0>(ga, probs, n, stream);
-  if constexpr (EPI == FK_EPI_NONE || EPI == FK_EPI_GELU_TANH) {   // development variants: two epilogues are enough
-    if (bn == 258) return launch8<EPI, 256, 1>(ga, probs, n, stream);
-    if (bn == 259) return launch8<EPI, 256, 2>(ga, probs, n, stream);
-    if (bn == 260) return launch8<EPI, 256, 3>(ga, probs, n, stream);
-  } else if (bn > 257) return launch8<EPI, 256, 0>(ga, probs, n, stream);
-  return bn == 256 ? launch5<EPI, 256>(ga, probs, n, stream) : launch<EPI, 128>(ga, probs, n, stream);
+  return bn == 256 ? launch8<EPI, 256>(ga, probs, n, stream) : launch<EPI, 128>(ga, probs, n, stream);
 }
 
 int cu_count() {
@@ -945,12 +728,12 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t s
 
   const int G = cu_count();
   int bn = bn_hint;
-  if (bn >= 256 && !ok256) bn = 128;
-  if (bn != 128 && (bn < 256 || bn > 260)) {
+  if (bn == 256 && !ok256) bn = 128;
+  if (bn != 128 && bn != 256) {
     auto eff = [G](long tiles) { return (double)tiles / (double)(((tiles + G - 1) / G) * G); };
-    bn = (ok256 && FK_RATE_256 * eff(t256) > eff(t128)) ? 257 : 128;   // 257: the ping-pong kernel owns the 256 x 256 tile
+    bn = (ok256 && FK_RATE_256 * eff(t256) > eff(t128)) ? 256 : 128;
   }
-  g_last_variant = bn >= 256 ? 256 : 128;   // reported as the tile width
+  g_last_variant = bn;
   switch (probs[0].epilogue) {
     case FK_EPI_NONE: return launch_bn<FK_EPI_NONE>(ga, probs, n, bn, stream);
     case FK_EPI_GELU_TANH: return launch_bn<FK_EPI_GELU_TANH>(ga, probs, n, bn, stream);

@@ -17,7 +17,7 @@ lib = libfk.load()
 shapes = [tuple(int(x) for x in t.split("x")) for t in os.environ["AB_SHAPES"].split(",")] if os.environ.get("AB_SHAPES") else [(2560, 9216, 3072), (2560, 12288, 3072), (2560, 3072, 12288), (2560, 3072, 15360), (2560, 3072, 3072),
           (8704, 9216, 3072), (8704, 12288, 3072), (8704, 3072, 12288), (8704, 3072, 15360), (8704, 3072, 3072),
           (32768, 12288, 3072), (32768, 3072, 12288), (32768, 9216, 3072)]
-variants = [int(v) if v != "vendor" else v for v in os.environ.get("AB_VARIANTS", "128,256,257,vendor").split(",")]
+variants = [int(v) if v != "vendor" else v for v in os.environ.get("AB_VARIANTS", "128,256,vendor").split(",")]
 for (M, N, K) in shapes:
     a = (torch.rand(M, K, device="cuda") * 2 - 1).to(BF)
     w = ((torch.rand(N, K, device="cuda") * 2 - 1) * 0.05).to(BF)
