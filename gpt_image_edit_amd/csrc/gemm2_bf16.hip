@@ -655,6 +655,182 @@ int launch8(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream)
   return FK_OK;
 }
 
+
+// ---- the same two-group alternation on the 256 x 128 tile ---------------------------------------------------------
+// For grids whose 256 x 256 tiling leaves the last round of 256 CUs poorly filled (M = 2560: N = 3072, 9216).
+// Waves 4 (M) x 2 (N), 64 x 64 per wave; group = the N half (waves w, w + 4 share a SIMD).  A K-tile is two phases of
+// 8 MFMAs: (A rows of the wave) x (W block j), j = 0, 1.  LDS: three stages of [A_lo | A_hi | W_0 | W_1] = 48 KiB,
+// where W_j holds the j-th 32-row block of both N halves (so that a phase's W operand is one slot):
+//     phase   reads into registers            DMA requests per wave                         multiplies
+//     P1(u)   A(u)               (8 b128)     A_lo(u+2), A_hi(u+2)     (4)   vmcnt(10)      j = 0
+//     P2(u)   W_1(u), W_0(u+1)   (4 + 4)      W_0(u+3), W_1(u+2)       (2)   vmcnt(8)       j = 1
+// Every request is retired three phases after its issue and read one phase later; a slot is re-requested no earlier
+// than two phases after its last read (same rules as gemm8_kernel).
+template <int BN>
+struct Cfg9 {
+  static_assert(BN == 128, "instantiated for the 256 x 128 tile only");
+  static constexpr int NTHREADS = 512;
+  static constexpr int BK = 64, ROW_BYTES = 128;
+  static constexpr int WAVES_M = 4, WAVES_N = 2;
+  static constexpr int WTM = 64, WTN = 64, MF = 2, NF = 2;
+  static constexpr int A_HALF = 128 * ROW_BYTES, W_PART = 64 * ROW_BYTES;
+  static constexpr int STAGE_BYTES = 2 * A_HALF + 2 * W_PART;   // 48 KiB
+  static constexpr int STAGES = 3;
+  static constexpr int CT_LD = BN + 8;
+  static constexpr int CT_BYTES = BM * CT_LD * 2;
+  static constexpr int SMEM_BYTES = STAGES * STAGE_BYTES > CT_BYTES ? STAGES * STAGE_BYTES : CT_BYTES;
+  static FK_DEV int swz(int row) { return (row >> 1) & 7; }
+  static FK_DEV int tile_row(int wm, int mf) { return wm * WTM + mf * 32; }
+  static FK_DEV int tile_col(int wn, int nf) { return wn * WTN + nf * 32; }
+};
+
+template <int EPI, int BN>
+__global__ __launch_bounds__(512, 2) void gemm9_kernel(const GroupArgs ga) {
+  using C = Cfg9<BN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;   // group = wn
+  int pi, m0, n0;
+  select_tile<BN>(ga, pi, m0, n0);
+  const fk_gemm_args& p = ga.p[pi];
+  const int nk = p.K / C::BK;
+
+  const int lrow = lane >> 3, slot = lane & 7;
+  const __amdgpu_buffer_rsrc_t rs_a =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.A + fk_row_offset(p.a, m0)), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.W + (int64_t)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
+  int a_voff[2][2], w_voff[2];   // A: [half][piece]; W: [part j], one piece per wave
+  {
+    const TileRows arow(p.a, m0);
+    const int ldw2 = (int)p.ldw * 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int rl = h * 128 + (wave * 2 + j) * 8 + lrow;
+        a_voff[h][j] = arow.off(min(rl, p.M - 1 - m0)) * 2 + ((slot ^ C::swz(rl)) << 4);
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int sr = wave * 8 + lrow;                      // row inside the 64-row part W_j
+      const int rl = (sr >> 5) * 64 + j * 32 + (sr & 31);  // row inside the 128-row W tile
+      w_voff[j] = min(rl, p.N - 1 - n0) * ldw2 + ((slot ^ C::swz(sr)) << 4);
+    }
+  }
+  auto dma_a = [&](int stage, int kt) {   // both halves of the A tile: 4 requests
+    const int koff = min(kt, nk - 1) * (C::BK * 2);
+    char* dst = smem + stage * C::STAGE_BYTES + wave * 2048;
+    buffer_lds16(rs_a, dst, a_voff[0][0], koff);
+    buffer_lds16(rs_a, dst + 1024, a_voff[0][1], koff);
+    buffer_lds16(rs_a, dst + C::A_HALF, a_voff[1][0], koff);
+    buffer_lds16(rs_a, dst + C::A_HALF + 1024, a_voff[1][1], koff);
+  };
+  auto dma_w = [&](int j, int stage, int kt) {   // part W_j: 1 request
+    const int koff = min(kt, nk - 1) * (C::BK * 2);
+    buffer_lds16(rs_w, smem + stage * C::STAGE_BYTES + 2 * C::A_HALF + j * C::W_PART + wave * 1024, w_voff[j], koff);
+  };
+
+  const int frow = lane & 31, fhalf = lane >> 5, fsw = C::swz(frow);
+  int koffs[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) koffs[kk] = ((kk * 2 + fhalf) ^ fsw) << 4;
+  const int a_rd = (wm * 64 + frow) * C::ROW_BYTES;                   // rows 64 wm .. of the 256-row A image (+ mf * 4096)
+  const int w_rd = 2 * C::A_HALF + (wn * 32 + frow) * C::ROW_BYTES;   // inside part W_j (+ j * W_PART)
+
+  f32x16_t acc[C::NF][C::MF];
+#pragma unroll
+  for (int i = 0; i < C::NF; ++i)
+#pragma unroll
+    for (int j = 0; j < C::MF; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  bf16x8_t af[2][4], wf[2][4];   // A [mf][kk]; W [j][kk]
+  auto read_a = [&](int stage) {
+    const char* b = smem + stage * C::STAGE_BYTES + a_rd;
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) af[mf][kk] = *(const bf16x8_t*)(b + mf * 4096 + koffs[kk]);
+  };
+  auto read_w = [&](int stage, int j) {
+    const char* b = smem + stage * C::STAGE_BYTES + w_rd + j * C::W_PART;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) wf[j][kk] = *(const bf16x8_t*)(b + koffs[kk]);
+  };
+  auto mma = [&](int j) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf)
+        acc[j][mf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][kk], af[mf][kk], acc[j][mf], 0, 0, 0);
+  };
+  auto phase_sync_mma = [&](auto vm, int j) {
+    wait_vmcnt<decltype(vm)::value>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    mma(j);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using V10 = std::integral_constant<int, 10>;
+  using V8 = std::integral_constant<int, 8>;
+
+  // ---- prologue: everything read in phases 0 .. 4, in reading order (13 requests) --------------------------------
+  dma_w(0, 0, 0);   // W_0(0)   "phase 0"
+  dma_a(0, 0);      // A(0)     P1(0)
+  dma_w(1, 0, 0);   // W_1(0)   P2(0)
+  dma_w(0, 1, 1);   // W_0(1)   P2(0)
+  dma_a(1, 1);      // A(1)     P1(1)
+  dma_w(1, 1, 1);   // W_1(1)   P2(1)
+  dma_w(0, 2, 2);   // W_0(2)   P2(1)
+  wait_vmcnt<8>();  // W_0(0), A(0) landed (own pieces)
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  read_w(0, 0);
+  if (wn == 1) __builtin_amdgcn_s_barrier();   // the stagger
+  __builtin_amdgcn_sched_barrier(0);
+
+  auto tile_body = [&](auto sc, int kt) {
+    constexpr int st = decltype(sc)::value, st1 = (st + 1) % 3, st2 = (st + 2) % 3;
+    read_a(st);                        dma_a(st2, kt + 2);                             phase_sync_mma(V10{}, 0);
+    read_w(st, 1); read_w(st1, 0);     dma_w(0, st, kt + 3); dma_w(1, st2, kt + 2);    phase_sync_mma(V8{}, 1);
+  };
+  for (int kt = 0; kt < nk; kt += 3) {
+    tile_body(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < nk) tile_body(std::integral_constant<int, 1>{}, kt + 1);
+    if (kt + 2 < nk) tile_body(std::integral_constant<int, 2>{}, kt + 2);
+  }
+  if (wn == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  store_tile<EPI, BN, C>(acc, p, smem, m0, n0, wm, wn);
+}
+
+template <int EPI, int BN>
+int launch9(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) {
+  int total = 0;
+  for (int i = 0; i < FK_MAX_GROUP; ++i) {
+    ga.tiles_before[i] = total;
+    if (i < n) total += ((probs[i].M + BM - 1) / BM) * ((probs[i].N + BN - 1) / BN);
+  }
+  ga.tiles_before[FK_MAX_GROUP] = total;
+  auto kern = gemm9_kernel<EPI, BN>;
+  FK_ENSURE_MAX_LDS(kern, Cfg9<BN>::SMEM_BYTES, "fk_gemm_bf16 (256 x 128 tile, 8 waves ping-pong)");
+  hipLaunchKernelGGL(kern, dim3(total), dim3(512), Cfg9<BN>::SMEM_BYTES, stream, ga);
+  FK_CHECK_LAUNCH("fk_gemm_bf16 (256 x 128 tile, 8 waves ping-pong)");
+  return FK_OK;
+}
+
 template <int EPI, int BN>
 int launch(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) {
   int total = 0;
@@ -673,6 +849,7 @@ int launch(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) 
 // variant: 128 = 256 x 128 (8 waves, lockstep), 256 = 256 x 256 (8 waves, ping-pong)
 template <int EPI>
 int launch_bn(GroupArgs& ga, const fk_gemm_args* probs, int n, int bn, hipStream_t stream) {
+  if (bn == 129) return launch9<EPI, 128>(ga, probs, n, stream);   // development: ping-pong on the 256 x 128 tile
   return bn == 256 ? launch8<EPI, 256>(ga, probs, n, stream) : launch<EPI, 128>(ga, probs, n, stream);
 }
 
@@ -729,11 +906,11 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t s
   const int G = cu_count();
   int bn = bn_hint;
   if (bn == 256 && !ok256) bn = 128;
-  if (bn != 128 && bn != 256) {
+  if (bn != 128 && bn != 129 && bn != 256) {
     auto eff = [G](long tiles) { return (double)tiles / (double)(((tiles + G - 1) / G) * G); };
     bn = (ok256 && FK_RATE_256 * eff(t256) > eff(t128)) ? 256 : 128;
   }
-  g_last_variant = bn;
+  g_last_variant = bn == 129 ? 128 : bn;
   switch (probs[0].epilogue) {
     case FK_EPI_NONE: return launch_bn<FK_EPI_NONE>(ga, probs, n, bn, stream);
     case FK_EPI_GELU_TANH: return launch_bn<FK_EPI_GELU_TANH>(ga, probs, n, bn, stream);

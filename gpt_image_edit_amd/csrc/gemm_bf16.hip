@@ -337,7 +337,7 @@ static int gemm_bn_override() {
   return g_bn_override;
 }
 extern "C" int fk_gemm_set_variant(int32_t variant) {
-  FK_CHECK_ARG(variant == 0 || variant == 128 || variant == 256,
+  FK_CHECK_ARG(variant == 0 || variant == 128 || variant == 129 || variant == 256,
                "fk_gemm_set_variant: %d is not one of 0 (automatic), 128, 256", variant);
   g_bn_override = variant;
   return FK_OK;
