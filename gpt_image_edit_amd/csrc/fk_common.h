@@ -67,7 +67,7 @@ FK_DEV int64_t fk_row_offset(const fk_rows& r, int64_t m) {
 
 // internal: returned by fk_gemm2_launch when a 256-row tile's rows are not addressable with 32-bit byte offsets
 constexpr int FK_E2BIG_STRIDES = -100;
-int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t stream);  // gemm2_bf16.hip
+int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t stream);  // gemm_pingpong_bf16.hip
 
 // host side ---------------------------------------------------------------------------------------
 void fk_set_error(const char* fmt, ...);

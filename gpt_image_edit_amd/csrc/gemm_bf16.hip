@@ -326,8 +326,8 @@ static int gemm_impl_override() {
   return v;
 }
 
-// FK_GEMM_BN=128|256 (or fk_gemm_set_variant) forces the large-tile kernel: 128 = 256 x 128 (8 waves in lockstep),
-// 256 = 256 x 256 (8 waves in two alternating groups); default 0: chosen per problem size.
+// FK_GEMM_BN=128|256 (or fk_gemm_set_variant) forces the tile width of the large-tile kernel (256 x 128 or 256 x 256);
+// default 0: chosen per problem size.
 static int g_bn_override = -1;
 static int gemm_bn_override() {
   if (g_bn_override < 0) {
@@ -337,7 +337,7 @@ static int gemm_bn_override() {
   return g_bn_override;
 }
 extern "C" int fk_gemm_set_variant(int32_t variant) {
-  FK_CHECK_ARG(variant == 0 || variant == 128 || variant == 129 || variant == 256,
+  FK_CHECK_ARG(variant == 0 || variant == 128 || variant == 256,
                "fk_gemm_set_variant: %d is not one of 0 (automatic), 128, 256", variant);
   g_bn_override = variant;
   return FK_OK;

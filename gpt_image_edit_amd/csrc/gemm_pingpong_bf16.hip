@@ -1,23 +1,27 @@
 // Large-tile bf16 MFMA GEMMs for the MMDiT linears (same contract as gemm_bf16.hip, used when M >= 192).
 // v_mfma_f32_32x32x16_bf16, operands swapped like gemm_bf16.hip (W rows -> MFMA A operand) so a lane owns 4
-// consecutive output columns of one row.  Two kernels, chosen per problem by (tile-quantisation efficiency) x
+// consecutive output columns of one row.  Two tile shapes, chosen per problem by (tile-quantisation efficiency) x
 // (measured steady-state rate); both accumulate over K in the same order, so they agree bit for bit:
 //
-//   gemm2_kernel   256 x 128 x 64, 8 waves (4 x 2, 64 x 64 per wave) in lockstep, LDS-DMA staging into a 3-stage ring,
-//                  straight-line k-loop with the next k-step's fragment reads pinned in front of this one's MFMAs
-//   gemm8_kernel   256 x 256 x 64, 8 waves (2 x 4, 128 x 64 per wave) in two groups that alternate between an MFMA
-//                  phase and an LDS-read / LDS-DMA phase ("ping-pong"), 8 half-tile slots = 128 KiB
+//   gemm8_kernel   256 x 256 x 64, 8 waves (2 x 4, 128 x 64 per wave), 8 half-tile LDS slots = 128 KiB
+//   gemm9_kernel   256 x 128 x 64, 8 waves (4 x 2,  64 x 64 per wave), 3 stages of 48 KiB
 //
-// What the measurements say (rounds 1 and 2; DESIGN.md section 4, profiles/r0x_gemm_*):
+// Both run their 8 waves as TWO GROUPS (one wave of each per SIMD) that alternate between an MFMA phase (8 MFMAs =
+// 256 matrix-pipe cycles) and a load phase (LDS fragment reads for the next phase + LDS-DMA requests for tiles
+// 3-6 phases ahead), two raw s_barriers per phase, the groups one barrier apart ("ping-pong").
+//
+// What the measurements say (rounds 1 and 2; DESIGN.md section 4, profiles/r02_gemm_variants.txt):
 //  * The chip is POWER-bound under MFMA load: 1.27-1.45 GHz instead of 2.4.  What a kernel can win is (matrix pipe
 //    busy) x (clock its energy per flop leaves).  gemm8_kernel keeps the pipe 89 % busy (the vendor library's
 //    hand-written kernel: 89 %) but clocks 1.27 GHz against 1.42: 0.75 LDS fragment reads per MFMA against 0.5 for
-//    128 x 128 wave tiles.
+//    128 x 128 wave tiles.  gemm9_kernel (1.0 reads per MFMA): 74 % busy at 1.30 GHz.
 //  * An LDS-DMA request costs its wave >= 60 ISSUE cycles, longer than the 28-cycle shadow of an MFMA: with one wave
-//    per SIMD (the round-1 `gemm5` 4-wave kernels: 76 % busy) the pipe drains behind every piece; with two waves per
-//    SIMD in opposite phases it is free.  In lockstep (gemm2_kernel) the 8 waves reach 68 % busy.
+//    per SIMD (round 1's 4-wave 256 x 256 kernels: 76 % busy) the pipe drains behind every piece; with all 8 waves in
+//    lockstep (round 1's 256 x 128 kernel) 69 % busy; with two groups in opposite phases the requests are free.
 //  * `global_load_lds` is a FLAT-class instruction: while one is pending hipcc turns every `lgkmcnt(N)` wait into
 //    `lgkmcnt(0)`.  The MUBUF form (`buffer_load_dwordx4 ... lds`) keeps the counts exact.
+//  * One barrier per phase instead of two (-1.5 %) and dropping s_setprio around the MFMA cluster (+-0) were measured
+//    on gemm8_kernel and not kept.
 //
 // The LDS image of a tile row is 128 B (64 k); the bank-conflict swizzle (16-byte chunk ^ ((row >> 1) & 7)) is
 // applied where the tile is written (DMA source address) and again on the ds_read_b128 side.
@@ -30,7 +34,6 @@
 namespace {
 
 constexpr int BM = 256;
-constexpr int NT = 512;
 #ifndef FK_GROUP_M
 #define FK_GROUP_M 8
 #endif
@@ -59,35 +62,6 @@ FK_DEV void buffer_lds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset
   (void)rsrc; (void)lds_dst; (void)voffset; (void)soffset;
 #endif
 }
-
-template <int BN>
-struct Cfg {
-  static constexpr int NTHREADS = NT;
-  static_assert(BN == 128, "the 8-wave kernel is instantiated for the 256 x 128 tile only");
-  static constexpr int BK = 64;
-  static constexpr int STAGES = 3;
-  static constexpr int KS = BK / 16;                   // MFMA k-steps per tile
-  static constexpr int CH = BK / 8;                    // 16-byte chunks per tile row
-  static constexpr int ROW_BYTES = BK * 2;
-  static constexpr int RPI = 64 / CH;                  // tile rows covered by one DMA instruction (1 KiB)
-  static constexpr int WAVES_M = 4, WAVES_N = 2;
-  static constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;  // wave tile
-  static constexpr int MF = WTM / 32, NF = WTN / 32;
-  static constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES;
-  static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-  static constexpr int PF = STAGES - 1;
-  static constexpr int A_LOADS = A_BYTES / 1024 / 8, W_LOADS = W_BYTES / 1024 / 8;  // DMA instr. per wave per tile
-  static constexpr int LOADS = A_LOADS + W_LOADS;
-  static constexpr int FRAG_STRIDE = 32 * ROW_BYTES;   // LDS distance between 32-row fragments
-  static constexpr int CT_LD = BN + 8;
-  static constexpr int CT_BYTES = BM * CT_LD * 2;
-  static constexpr int SMEM_BYTES = (STAGES * STAGE_BYTES > CT_BYTES) ? STAGES * STAGE_BYTES : CT_BYTES;
-  // bank-conflict swizzle of the 16-byte chunk index, as a function of the tile row
-  static FK_DEV int swz(int row) { return CH == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
-  // first tile row / column of the 32 x 32 block (mf, nf) of wave (wm, wn)
-  static FK_DEV int tile_row(int wm, int mf) { return wm * WTM + mf * 32; }
-  static FK_DEV int tile_col(int wn, int nf) { return wn * WTN + nf * 32; }
-};
 
 template <int N>
 FK_DEV void wait_vmcnt() {
@@ -346,131 +320,6 @@ FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& 
 }
 
 
-template <int EPI, int BN>
-__global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GroupArgs ga) {
-  using C = Cfg<BN>;
-  constexpr int BK = C::BK;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave % C::WAVES_M, wn = wave / C::WAVES_M;
-  int pi, m0, n0;
-  select_tile<BN>(ga, pi, m0, n0);
-  const fk_gemm_args& p = ga.p[pi];
-
-  // ---- LDS-DMA sources: lane -> (row = base + lane/CH, slot = lane%CH), source chunk = slot ^ swz(row) --
-  // Buffer form (`buffer_load_dwordx4 ... lds`): one SGPR descriptor per operand based at the tile's first row,
-  // a 32-bit byte offset VGPR per piece (constant over K) and the K offset in an SGPR.  Besides saving the 64-bit
-  // address arithmetic this keeps hipcc's LDS wait counts exact: `global_load_lds` is a FLAT-class instruction,
-  // and while one is pending every `lgkmcnt` wait degrades to lgkmcnt(0), i.e. also waits for the fragment reads
-  // issued for the NEXT k-step.
-  const int lrow = lane / C::CH, slot = lane % C::CH;
-  const __amdgpu_buffer_rsrc_t rs_a =
-      __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.A + fk_row_offset(p.a, m0)), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w =
-      __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.W + (int64_t)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
-  int a_voff[C::A_LOADS], w_voff[C::W_LOADS];
-  const TileRows arow(p.a, m0);
-  const int ldw2 = (int)p.ldw * 2;
-#pragma unroll
-  for (int j = 0; j < C::A_LOADS; ++j) {
-    const int rl = (wave * C::A_LOADS + j) * C::RPI + lrow;  // row inside the A tile
-    a_voff[j] = arow.off(min(rl, p.M - 1 - m0)) * 2 + ((slot ^ C::swz(rl)) << 4);
-  }
-#pragma unroll
-  for (int j = 0; j < C::W_LOADS; ++j) {
-    const int rl = (wave * C::W_LOADS + j) * C::RPI + lrow;
-    w_voff[j] = min(rl, p.N - 1 - n0) * ldw2 + ((slot ^ C::swz(rl)) << 4);
-  }
-  // piece i of the tile's DMA list (A pieces first); `koff` = byte offset of the K-tile
-  auto issue_piece = [&](int i, int koff, char* sb) {
-    if (i < C::A_LOADS) buffer_lds16(rs_a, sb + (wave * C::A_LOADS + i) * 1024, a_voff[i], koff);
-    else buffer_lds16(rs_w, sb + C::A_BYTES + (wave * C::W_LOADS + (i - C::A_LOADS)) * 1024, w_voff[i - C::A_LOADS], koff);
-  };
-
-  // ---- MFMA operand addressing (same swizzle on the read side) -----------------------------------------
-  const int frow = lane & 31, fhalf = lane >> 5, fsw = C::swz(frow);
-  const int a_rd = (wm * C::WTM + frow) * C::ROW_BYTES;               // + mf*FRAG_STRIDE
-  const int w_rd = C::A_BYTES + (wn * C::WTN + frow) * C::ROW_BYTES;  // + nf*FRAG_STRIDE
-
-  f32x16_t acc[C::NF][C::MF];
-#pragma unroll
-  for (int i = 0; i < C::NF; ++i)
-#pragma unroll
-    for (int j = 0; j < C::MF; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  bf16x8_t af[2][C::MF], wf[2][C::NF];
-  auto read_frags = [&](int buf, const char* sb, int kk) {
-    const int coff = (((kk * 2 + fhalf) ^ fsw) << 4);
-#pragma unroll
-    for (int mf = 0; mf < C::MF; ++mf) af[buf][mf] = *(const bf16x8_t*)(sb + a_rd + mf * C::FRAG_STRIDE + coff);
-#pragma unroll
-    for (int nf = 0; nf < C::NF; ++nf) wf[buf][nf] = *(const bf16x8_t*)(sb + w_rd + nf * C::FRAG_STRIDE + coff);
-  };
-
-  // Pipeline: tiles kt+1 .. kt+PF are in flight / landed while tile kt multiplies.  The ONE barrier per tile
-  // sits after the MFMAs of the tile's second-to-last k-step: it publishes tile kt+1 (every wave has waited
-  // for its own pieces of it) and retires the reads of tile kt, so that the last k-step can already fetch
-  // the first fragments of tile kt+1 -- the MFMA stream never waits for an LDS round trip at a tile boundary.
-  // The loop body is straight-line code: every DMA piece and fragment read is issued unconditionally (tile indices
-  // are clamped; the surplus requests are never consumed), so the wait counts are exact constants and hipcc keeps
-  // `lgkmcnt(N)` waits that let the just-issued reads of the NEXT k-step stay in flight under this one's MFMAs.
-  const int nk = p.K / BK;
-#pragma unroll
-  for (int s = 0; s < C::PF; ++s) {
-    const int koff = min(s, nk - 1) * (BK * 2);
-#pragma unroll
-    for (int i = 0; i < C::LOADS; ++i) issue_piece(i, koff, smem + s * C::STAGE_BYTES);
-  }
-  wait_vmcnt<(C::PF - 1) * C::LOADS>();
-  __builtin_amdgcn_s_barrier();
-  read_frags(0, smem, 0);
-
-  int st_cur = 0, st_pf = C::PF;  // stage of tile kt, stage receiving tile kt+PF (= stage of tile kt-1)
-  constexpr int DMA_KK = C::KS - 1;                               // k-steps that carry DMA pieces (before the barrier)
-  constexpr int PER_KK = (C::LOADS + DMA_KK - 1) / DMA_KK;
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* sb = smem + st_cur * C::STAGE_BYTES;
-    const int st_nx = (st_cur == C::STAGES - 1) ? 0 : st_cur + 1;
-    const char* sb_nx = smem + st_nx * C::STAGE_BYTES;
-    char* sb_pf = smem + st_pf * C::STAGE_BYTES;
-    const int koff_pf = min(kt + C::PF, nk - 1) * (BK * 2);
-#pragma unroll
-    for (int kk = 0; kk < C::KS; ++kk) {
-      const int cb = kk & 1, nb = cb ^ 1;
-      // the NEXT k-step's fragments first (they have this k-step's MFMAs to land), then this k-step's DMA pieces
-      if (kk < C::KS - 1) read_frags(nb, sb, kk + 1);
-      else read_frags(nb, sb_nx, 0);
-      if (kk < DMA_KK) {
-#pragma unroll
-        for (int i = kk * PER_KK; i < (kk + 1) * PER_KK && i < C::LOADS; ++i) issue_piece(i, koff_pf, sb_pf);
-      }
-#pragma unroll
-      for (int nf = 0; nf < C::NF; ++nf)
-#pragma unroll
-        for (int mf = 0; mf < C::MF; ++mf)
-          acc[nf][mf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][nf], af[cb][mf], acc[nf][mf], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, C::MF + C::NF, 0);   // the fragment reads of this slot first ...
-      __builtin_amdgcn_sched_group_barrier(0x008, C::MF * C::NF, 0);   // ... then its MFMAs
-      if (kk == C::KS - 2) {
-        // tile kt+1 landed (own pieces) once only the PF-1 newer tiles (all issued by now) remain outstanding
-        wait_vmcnt<(C::PF - 1) * C::LOADS>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of tile kt are complete
-        __builtin_amdgcn_s_barrier();
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    st_cur = st_nx;
-    st_pf = (st_pf == C::STAGES - 1) ? 0 : st_pf + 1;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus (clamped) requests must not land in the C tile
-
-  store_tile<EPI, BN, C>(acc, p, smem, m0, n0, wm, wn);
-}
-
 // ---- 8 waves in two groups that alternate between "multiply" and "load" ("ping-pong") ----------------------------
 // 256 x 256 x 64 tile, waves 2 (M) x 4 (N); a wave's output is FOUR 64 x 32 quadrants: rows {128 i + 64 wm + [0,64)} x
 // columns {128 j + 32 wn + [0,32)}, i, j in {0,1}.  The A and W tiles are kept in LDS as two 128-row half-tiles each
@@ -507,8 +356,6 @@ struct Cfg8 {
   static FK_DEV int tile_col(int wn, int nf) { return nf * 128 + wn * 32; }
 };
 
-// Measured and dropped (tools/ab_gemm8.py, same process, interleaved): ONE barrier per phase (group 0 synchronising after
-// its load part, group 1 after its MFMAs, no stagger) -1.5 %; no s_setprio around the MFMA cluster +-0.
 template <int EPI, int BN>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
   using C = Cfg8<BN>;
@@ -522,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
   const fk_gemm_args& p = ga.p[pi];
   const int nk = p.K / C::BK;
 
-  // ---- LDS-DMA sources (as gemm2_kernel): piece = 8 rows x 128 B, lane -> (row, slot), source chunk = slot ^ swz(row).
+  // ---- LDS-DMA sources: piece = 8 rows x 128 B, lane -> (row, slot), source chunk = slot ^ swz(row).
   // Wave w requests pieces 2w and 2w + 1 of every half-tile.
   const int lrow = lane >> 3, slot = lane & 7;
   const __amdgpu_buffer_rsrc_t rs_a =
@@ -658,6 +505,7 @@ int launch8(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream)
 
 // ---- the same two-group alternation on the 256 x 128 tile ---------------------------------------------------------
 // For grids whose 256 x 256 tiling leaves the last round of 256 CUs poorly filled (M = 2560: N = 3072, 9216).
+// +1..4 % over the lockstep 256 x 128 kernel of round 1 on every shape of the path (69 -> 74 % MFMA-busy).
 // Waves 4 (M) x 2 (N), 64 x 64 per wave; group = the N half (waves w, w + 4 share a SIMD).  A K-tile is two phases of
 // 8 MFMAs: (A rows of the wave) x (W block j), j = 0, 1.  LDS: three stages of [A_lo | A_hi | W_0 | W_1] = 48 KiB,
 // where W_j holds the j-th 32-row block of both N halves (so that a phase's W operand is one slot):
@@ -831,26 +679,10 @@ int launch9(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream)
   return FK_OK;
 }
 
-template <int EPI, int BN>
-int launch(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) {
-  int total = 0;
-  for (int i = 0; i < FK_MAX_GROUP; ++i) {
-    ga.tiles_before[i] = total;
-    if (i < n) total += ((probs[i].M + BM - 1) / BM) * ((probs[i].N + BN - 1) / BN);
-  }
-  ga.tiles_before[FK_MAX_GROUP] = total;
-  auto kern = gemm2_kernel<EPI, BN>;
-  FK_ENSURE_MAX_LDS(kern, Cfg<BN>::SMEM_BYTES, "fk_gemm_bf16 (256-row tile)");
-  hipLaunchKernelGGL(kern, dim3(total), dim3(NT), Cfg<BN>::SMEM_BYTES, stream, ga);
-  FK_CHECK_LAUNCH("fk_gemm_bf16 (256-row tile)");
-  return FK_OK;
-}
-
-// variant: 128 = 256 x 128 (8 waves, lockstep), 256 = 256 x 256 (8 waves, ping-pong)
+// variant = tile width: 128 -> gemm9_kernel (256 x 128), 256 -> gemm8_kernel (256 x 256)
 template <int EPI>
 int launch_bn(GroupArgs& ga, const fk_gemm_args* probs, int n, int bn, hipStream_t stream) {
-  if (bn == 129) return launch9<EPI, 128>(ga, probs, n, stream);   // development: ping-pong on the 256 x 128 tile
-  return bn == 256 ? launch8<EPI, 256>(ga, probs, n, stream) : launch<EPI, 128>(ga, probs, n, stream);
+  return bn == 256 ? launch8<EPI, 256>(ga, probs, n, stream) : launch9<EPI, 128>(ga, probs, n, stream);
 }
 
 int cu_count() {
@@ -906,11 +738,11 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t s
   const int G = cu_count();
   int bn = bn_hint;
   if (bn == 256 && !ok256) bn = 128;
-  if (bn != 128 && bn != 129 && bn != 256) {
+  if (bn != 128 && bn != 256) {
     auto eff = [G](long tiles) { return (double)tiles / (double)(((tiles + G - 1) / G) * G); };
     bn = (ok256 && FK_RATE_256 * eff(t256) > eff(t128)) ? 256 : 128;
   }
-  g_last_variant = bn == 129 ? 128 : bn;
+  g_last_variant = bn;
   switch (probs[0].epilogue) {
     case FK_EPI_NONE: return launch_bn<FK_EPI_NONE>(ga, probs, n, bn, stream);
     case FK_EPI_GELU_TANH: return launch_bn<FK_EPI_GELU_TANH>(ga, probs, n, bn, stream);

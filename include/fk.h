@@ -95,8 +95,8 @@ typedef struct fk_gemm_args {
 } fk_gemm_args;
 
 int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream);
-/* Which large-tile kernel the calling thread's last fk_gemm_bf16[_grouped] used: 128 = 256 x 128 tile (8 waves in
- * lockstep), 256 = 256 x 256 tile (8 waves in two alternating groups), 0 = neither so far (tests, profiling). */
+/* Which large tile the calling thread's last fk_gemm_bf16[_grouped] used: 128 = 256 x 128, 256 = 256 x 256,
+ * 0 = neither so far (tests, profiling). */
 int fk_gemm_last_variant(void);
 /* Tuning / measurement hook: force the large-tile kernel of every later fk_gemm_bf16[_grouped] call of the process:
  * 128 = 256 x 128 tile, 256 = 256 x 256 tile; 0 = back to the per-problem choice.  Same results bit for bit
