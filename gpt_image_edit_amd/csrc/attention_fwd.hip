@@ -409,6 +409,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
 // shadow -- with two waves per SIMD the hardware overlaps one wave's VALU with the other's MFMAs at no issue cost.
 // Not built; kept as a starting point for a hand-allocated version.
 //
+// Round 2: the two-group ("ping-pong") structure that took the GEMM to 89 % MFMA-busy -- groups of 4 waves alternating
+// between a 16-MFMA phase from registers (S^T of block b+1 and O^T += V^T P^T of block b) and a softmax + LDS-read
+// phase, two barriers per phase, K / V rings of 4 x 16 KiB -- is correct (all attention tests) and 7-14 % SLOWER than
+// this kernel at every shape (profiles/r02_attention_variants.txt): the softmax phase is VALU work that the partner's
+// MFMA phase starves of issue slots (with s_setprio on the MFMA phase another -3 %), and every phase boundary pays an
+// LDS round trip; free-running waves overlap better than barrier-enforced alternation here.  Removed (git history).
+//
 // Measured dead ends (kept out of the tree, see git history): (1) issuing QK^T of tile t+1 before the softmax
 // of tile t inside one wave (register pressure -> spills, compiler does not interleave: 760 TF vs 844);
 // (2) rotating waves 4..7 by one phase so that softmax of one wave meets MFMA of its SIMD partner
@@ -425,320 +432,6 @@ int launch(const AttnParams& p, hipStream_t stream) {
   return FK_OK;
 }
 
-
-// =====================================================================================================================
-// Two-group ("ping-pong") form of the same attention: the 8 waves of a workgroup run as two groups (waves 0-3 and 4-7,
-// one of each per SIMD) that alternate between a pure-MFMA phase and a VALU / LDS phase, one barrier apart -- the
-// structure that took the GEMM from 69-76 % to 89 % MFMA-busy (gemm_pingpong_bf16.hip).  Per 32-key block b a wave runs
-//     Y(b): softmax numerators of block b (exp2, row sums, bf16 pack)  +  LDS reads of the operands of X(b) into
-//           registers (K fragments of block b+1, V^T fragments of block b)  +  this phase's LDS-DMA requests
-//     X(b): 16 MFMAs from registers only: S^T(b+1) = K(b+1) Q^T  and  O^T += V^T(b) P^T(b)
-//   phase(b) := Y(b); s_waitcnt vmcnt(8); s_barrier; lgkmcnt(0); X(b); s_barrier
-// so while one group's waves hold the matrix pipe for 512 cycles, their SIMD partners do the softmax of their own block
-// on the VALU and fetch operands: the lockstep kernel above shows MFMA-busy 48 % + VALU-busy 52 % = 100 %, i.e. no
-// overlap at all.  K and V tiles (64 keys = two blocks) live in two LDS rings of 4 x 16 KiB; K(t) is read in phases
-// 2t-1 and 2t, V(t) in 2t and 2t+1; phase 2u requests K(u+3), phase 2u+1 requests V(u+3): every request is retired by
-// the wait four phases later and first read one phase after that, a slot is re-requested two phases after its last read.
-// Same arithmetic as the lockstep kernel (fixed exponent reference, restart on overflow, masking), same results.
-template <bool F32OUT>
-__global__ __launch_bounds__(512, 2) void attention_pp_kernel(const AttnParams p) {
-  constexpr int NW = 8, QBLK = 256, RING = 4;
-  constexpr int V_RING = RING * K_TILE_BYTES;               // byte offset of the V ring
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;
-  const int ql = lane & 31, hh = lane >> 5;
-
-  const int nqb = (p.S + QBLK - 1) / QBLK;
-  int t;
-  {
-    const int nwg = gridDim.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  }
-  const int qb = t % nqb;
-  const int bh = t / nqb;
-  const int b = bh / p.H, h = bh - b * p.H;
-  const bf16_t* Kg = p.k + (int64_t)bh * p.S * HD;
-  const bf16_t* Vg = p.v + (int64_t)b * p.v_bs + h * HD;
-
-  const int q_row = qb * QBLK + wave * 32 + ql;
-  bf16x8_t qf[8];
-  {
-    const bf16_t* qp = p.q + ((int64_t)bh * p.S + min(q_row, p.S - 1)) * HD + 8 * hh;
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const bf16x8_t*)(qp + 16 * kk);
-  }
-
-  // ---- LDS-DMA: piece = 4 key rows x 256 B; a wave requests pieces 2w, 2w+1 of every K tile and of every V tile ----
-  const int prow = lane >> 4, pslot = lane & 15;
-  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, p.S * HD * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_v =
-      __builtin_amdgcn_make_buffer_rsrc((void*)Vg, 0, (int)(((int64_t)(p.S - 1) * p.v_ld + HD) * 2), 0x00020000);
-  int k_voff[2], v_voff[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = (wave * 2 + i) * 4 + prow;
-    k_voff[i] = (r * HD + ((pslot ^ (r & 15)) << 3)) * 2;
-    const int vcol = ((((pslot >> 2) ^ (r & 3)) << 5) + ((pslot & 3) << 3));
-    v_voff[i] = (int)((r * p.v_ld + vcol) * 2);
-  }
-  const int nkt = (p.S + KVBLK - 1) / KVBLK;
-  const int nblk = 2 * nkt;
-  const int k_tile_bytes = KVBLK * HD * 2, v_tile_bytes = (int)(KVBLK * p.v_ld * 2);
-  auto issue_k = [&](int kt) {   // tile index clamped: surplus requests re-fetch the last tile and are never read
-    const int kc = min(kt, nkt - 1);
-    char* sb = smem + (kt & (RING - 1)) * K_TILE_BYTES + wave * 2048;
-    buffer_lds16(rs_k, sb, k_voff[0], kc * k_tile_bytes);
-    buffer_lds16(rs_k, sb + 1024, k_voff[1], kc * k_tile_bytes);
-  };
-  auto issue_v = [&](int kt) {
-    const int kc = min(kt, nkt - 1);
-    char* sb = smem + V_RING + (kt & (RING - 1)) * K_TILE_BYTES + wave * 2048;
-    buffer_lds16(rs_v, sb, v_voff[0], kc * v_tile_bytes);
-    buffer_lds16(rs_v, sb + 1024, v_voff[1], kc * v_tile_bytes);
-  };
-
-  // ---- operand reads (same LDS images and swizzles as the lockstep kernel) -----------------------------------------
-  // K fragment kk of a block: row ql, 16-byte chunk (2 kk + hh) ^ (ql & 15)  =  x_k ^ (kk << 5); V^T fragment (step,
-  // df): x_v ^ (df << 6) + step * 4096 -- ONE address register per operand, the rest is an XOR with a literal (kept
-  // out of the loop-invariant hoisting that would cost 12 registers: the kernel is at the 256-VGPR limit).
-  const int tj = (lane & 15) >> 2, tq = lane & 3, tdh = (lane >> 4) & 1;
-  int x_k = ql * 256 + ((((ql & 15) >> 1) << 5) | (((hh ^ ql) & 1) << 4));
-  int x_v = V_RING + (4 * hh + tj) * 256 + (tj << 6) + tdh * 32 + tq * 8;
-  bf16x8_t kf[8], vf[8];
-  auto read_k = [&](int blk) {   // K fragments of block blk (tile blk >> 1, half blk & 1)
-    asm volatile("" : "+v"(x_k));
-    const char* sb = smem + ((blk >> 1) & (RING - 1)) * K_TILE_BYTES + (blk & 1) * 8192;
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) kf[kk] = *(const bf16x8_t*)(sb + (x_k ^ (kk << 5)));
-  };
-  auto read_v = [&](int blk) {   // V^T fragments of block blk: i = 4 * step + df
-    asm volatile("" : "+v"(x_v));
-    const char* sb = smem + ((blk >> 1) & (RING - 1)) * K_TILE_BYTES + (blk & 1) * 8192;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const char* vp = sb + (i >> 2) * 4096 + (x_v ^ ((i & 3) << 6));
-      const s16x4_t lo = lds_tr16(vp);
-      const s16x4_t hi = lds_tr16(vp + 2048);
-      bf16x8_t f;
-      f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-      f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-      vf[i] = f;
-    }
-  };
-
-  f32x16_t o[4], s;
-  bf16x8_t pf[2], pf_lo[2];
-  constexpr float REF_BIAS = 24.0f;
-  float m_ref = 0.f, l_run = 0.f;
-  const bool ragged = p.S % KVBLK != 0;
-  int* const wg_flag = (int*)(smem + 2 * RING * K_TILE_BYTES);
-
-  auto block_max = [&](const f32x16_t& sv) {
-    float mx = sv[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sv[r]);
-    return fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2;
-  };
-  auto mask_block = [&](f32x16_t& sv, int blk) {   // keys >= S of the ragged last tile
-    const int kbase = 32 * blk + 4 * hh;
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (kbase + (r & 3) + 8 * (r >> 2) >= p.S) sv[r] = -1.0e30f;
-  };
-  // Y: numerators of the block whose scores are in `s`, packed into pf (k-steps 0 / 1 of the block)
-  auto softmax_block = [&]() {
-    const float nm = -m_ref;
-    float psum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, nm));
-      s[r] = pv;
-      psum += pv;
-    }
-    l_run += psum;
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      u32x4_t pw;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) pw[e] = pack_bf2(s[8 * st + 2 * e], s[8 * st + 2 * e + 1]);
-      pf[st] = __builtin_bit_cast(bf16x8_t, pw);
-      if constexpr (F32OUT) {
-        u32x4_t pl;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          pl[e] = pack_bf2(s[8 * st + 2 * e] - bf_lo(pw[e]), s[8 * st + 2 * e + 1] - bf_hi(pw[e]));
-        pf_lo[st] = __builtin_bit_cast(bf16x8_t, pl);
-      }
-    }
-  };
-  // X: registers only, straight-line.  QK of the next block (a chain on one accumulator) interleaved with PV of this
-  // block (4 accumulators).  The first phase multiplies a zero P (nothing to add yet), the last one computes an S^T that
-  // nobody reads: no branches, no selects.
-  auto mfma_phase = [&]() {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], qf[i], i == 0 ? f32x16_t{} : s, 0, 0, 0);
-      o[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i], pf[i >> 2], o[i & 3], 0, 0, 0);
-      if constexpr (F32OUT) o[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i], pf_lo[i >> 2], o[i & 3], 0, 0, 0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-  };
-  auto sync_then = [&]() {
-    wait_vmcnt<8>();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_phase();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    if (attempt == 1) {
-      // exact row maxima (rare path, kept simple): K tiles one at a time through ring slot 0, all waves in lockstep
-      m_ref = -3.0e38f;
-      for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
-        {
-          char* sb = smem + wave * 2048;
-          buffer_lds16(rs_k, sb, k_voff[0], kt * k_tile_bytes);
-          buffer_lds16(rs_k, sb + 1024, k_voff[1], kt * k_tile_bytes);
-        }
-        wait_vmcnt<0>();
-        __syncthreads();
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          const char* sb = smem + kb * 8192;
-          f32x16_t sv;
-#pragma unroll
-          for (int kk = 0; kk < 8; ++kk)
-            sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)(sb + (x_k ^ (kk << 5))), qf[kk],
-                                                         kk == 0 ? f32x16_t{} : sv, 0, 0, 0);
-          if (ragged && kt == nkt - 1) mask_block(sv, 2 * kt + kb);
-          m_ref = fmaxf(m_ref, block_max(sv));
-        }
-      }
-      __syncthreads();
-    }
-    // ---- prologue: K(0), V(0), K(1), V(1), K(2), V(2); K(0) is needed first --------------------------------------
-#pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
-      issue_k(kt);
-      issue_v(kt);
-    }
-    l_run = 0.f;
-#pragma unroll
-    for (int df = 0; df < 4; ++df)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[df][r] = 0.f;
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // K(0) landed (own pieces)
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    read_k(0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) vf[i] = bf16x8_t{};
-    pf[0] = pf[1] = bf16x8_t{};
-    if constexpr (F32OUT) pf_lo[0] = pf_lo[1] = bf16x8_t{};
-    if (grp == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one barrier behind group 0
-    __builtin_amdgcn_sched_barrier(0);
-    sync_then();                                  // phase -1: S^T(0) (and 0 x 0 into O); its wait retires V(0)
-    // ---- phases 0 .. nblk-1 ----------------------------------------------------------------------------------------
-    for (int blk = 0; blk < nblk; ++blk) {
-      if (ragged && blk >= nblk - 2) mask_block(s, blk);
-      if (attempt == 0 && blk == 0) m_ref = block_max(s) + REF_BIAS;
-      softmax_block();
-      read_v(blk);
-      read_k(min(blk + 1, nblk - 1));
-      if (blk & 1) issue_v((blk >> 1) + 3);
-      else issue_k((blk >> 1) + 3);
-      sync_then();
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (attempt == 0) {
-      float mag = fabsf(l_run);
-#pragma unroll
-      for (int df = 0; df < 4; ++df)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mag += fabsf(o[df][r]);
-      const bool overflow = __builtin_amdgcn_ballot_w64(!(mag <= 3.0e38f)) != 0;
-      __syncthreads();
-      if (tid == 0) *wg_flag = 0;
-      __syncthreads();
-      if (overflow && lane == 0) atomicOr(wg_flag, 1);
-      __syncthreads();
-      if (*wg_flag == 0) break;
-    }
-  }
-
-  // ---- finalize (as the lockstep kernel) ---------------------------------------------------------------------------
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
-  if constexpr (F32OUT) {
-    if (q_row < p.S) {
-      float* op = (float*)p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_ld + h * HD + 4 * hh;
-#pragma unroll
-      for (int df = 0; df < 4; ++df)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *(f32x4_t*)(op + 32 * df + 8 * g) = f32x4_t{o[df][4 * g + 0] * inv, o[df][4 * g + 1] * inv,
-                                                       o[df][4 * g + 2] * inv, o[df][4 * g + 3] * inv};
-    }
-  } else {
-    bf16_t* const orow = p.o + (int64_t)b * p.o_bs + (int64_t)min(q_row, p.S - 1) * p.o_ld + h * HD;
-    const bool wide = ((p.o_ld | p.o_bs) & 7) == 0 && ((uintptr_t)p.o & 15) == 0;
-#pragma unroll
-    for (int df = 0; df < 4; ++df)
-#pragma unroll
-      for (int g = 0; g < 4; g += 2) {
-        u32x2_t a, c;
-        a[0] = pack_bf2(o[df][4 * g + 0] * inv, o[df][4 * g + 1] * inv);
-        a[1] = pack_bf2(o[df][4 * g + 2] * inv, o[df][4 * g + 3] * inv);
-        c[0] = pack_bf2(o[df][4 * g + 4] * inv, o[df][4 * g + 5] * inv);
-        c[1] = pack_bf2(o[df][4 * g + 6] * inv, o[df][4 * g + 7] * inv);
-        if (wide) {
-#if defined(__HIP_DEVICE_COMPILE__)
-          const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);
-          const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
-          const u32x4_t w = {r0[0], r1[0], r0[1], r1[1]};
-          if (q_row < p.S) *(u32x4_t*)(orow + 32 * df + 8 * g + 8 * hh) = w;
-#endif
-        } else if (q_row < p.S) {
-          *(u32x2_t*)(orow + 32 * df + 8 * g + 4 * hh) = a;
-          *(u32x2_t*)(orow + 32 * df + 8 * (g + 1) + 4 * hh) = c;
-        }
-      }
-  }
-}
-
-template <bool F32OUT>
-int launch_pp(const AttnParams& p, hipStream_t stream) {
-  constexpr int SMEM = 8 * K_TILE_BYTES + 16;   // two rings of 4 x 16 KiB + the restart flag word
-  auto kern = attention_pp_kernel<F32OUT>;
-  FK_ENSURE_MAX_LDS(kern, SMEM, "fk_attention_fwd_bf16");
-  const int nqb = (p.S + 255) / 256;
-  hipLaunchKernelGGL(kern, dim3(nqb * p.H * p.B), dim3(512), SMEM, stream, p);
-  FK_CHECK_LAUNCH("fk_attention_fwd_bf16");
-  return FK_OK;
-}
-
-int g_attn_variant = -1;   // 0 / 1: lockstep kernel, 2: two-group kernel (FK_ATTN_VARIANT, fk_attention_set_variant)
-int attn_variant() {
-  if (g_attn_variant < 0) {
-    const char* e = getenv("FK_ATTN_VARIANT");
-    g_attn_variant = e ? atoi(e) : 0;
-  }
-  return g_attn_variant;
-}
 
 int attention_entry(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H, int32_t S, int64_t v_ld,
                     int64_t v_batch_stride, int64_t o_ld, int64_t o_batch_stride, float scale, bool f32out,
@@ -759,7 +452,6 @@ int attention_entry(const void* q, const void* k, const void* v, void* o, int32_
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o;
   p.B = B; p.H = H; p.S = S; p.v_ld = v_ld; p.v_bs = v_batch_stride; p.o_ld = o_ld; p.o_bs = o_batch_stride;
   p.scale_log2 = scale * 1.4426950408889634f;
-  if (attn_variant() == 2) return f32out ? launch_pp<true>(p, stream) : launch_pp<false>(p, stream);
   return f32out ? launch<8, 3, true>(p, stream) : launch<8, 3, false>(p, stream);
 }
 
@@ -770,12 +462,6 @@ extern "C" int fk_attention_fwd_bf16(const void* q, const void* k, const void* v
                                      int64_t o_batch_stride, float scale, fk_stream_t stream_) {
   return attention_entry(q, k, v, o, B, H, S, v_ld, v_batch_stride, o_ld, o_batch_stride, scale, false,
                          (hipStream_t)stream_);
-}
-
-extern "C" int fk_attention_set_variant(int32_t variant) {
-  FK_CHECK_ARG(variant >= 0 && variant <= 2, "fk_attention_set_variant: %d is not one of 0, 1, 2", variant);
-  g_attn_variant = variant;
-  return FK_OK;
 }
 
 extern "C" int fk_attention_fwd_f32_debug(const void* q, const void* k, const void* v, float* o, int32_t B,

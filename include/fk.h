@@ -143,9 +143,6 @@ int fk_qkv_post_bf16(const void* qkv, void* q_out, void* k_out, const void* wq_i
 int fk_attention_fwd_bf16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H,
                           int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld,
                           int64_t o_batch_stride, float scale, fk_stream_t stream);
-/* Tuning / measurement hook: 0 or 1 = the lockstep kernel, 2 = the two-group ("ping-pong") kernel, for every later
- * fk_attention_fwd_* call of the process. */
-int fk_attention_set_variant(int32_t variant);
 /* Parity / debug build of the SAME kernel (same tiling, LDS layouts, softmax, key <-> MFMA k-slot binding): the output
  * is fp32 (o_ld / o_batch_stride in fp32 elements, 16-byte aligned) and every probability enters the PV product as
  * two bf16 terms (hi + lo), so the result can be compared with an fp32 reference at the tolerance BASELINE.json
