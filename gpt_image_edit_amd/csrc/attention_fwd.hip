@@ -41,6 +41,7 @@ struct AttnParams {
   int64_t v_ld, v_bs;  // V row (token) stride / batch stride in elements; head h at column h*128
   int64_t o_ld, o_bs;
   float scale_log2;    // scale * log2(e)
+  float* lse;          // optional [B, H, S]: log2-domain log-sum-exp of every row (saved for the backward pass)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
   // ---- finalize: O = O^T / l ; lane (q = ql) holds d = 32 df + 8 g + 4 hh + (0..3), g = r >> 2 -------------
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
+  if (p.lse && hh == 0 && q_row < p.S) p.lse[(int64_t)bh * p.S + q_row] = m_ref + __builtin_amdgcn_logf(l_tot);
   if constexpr (F32OUT) {
     if (q_row < p.S) {
       float* op = (float*)p.o + (int64_t)b * p.o_bs + (int64_t)q_row * p.o_ld + h * HD + 4 * hh;
@@ -435,7 +437,7 @@ int launch(const AttnParams& p, hipStream_t stream) {
 
 int attention_entry(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H, int32_t S, int64_t v_ld,
                     int64_t v_batch_stride, int64_t o_ld, int64_t o_batch_stride, float scale, bool f32out,
-                    hipStream_t stream) {
+                    hipStream_t stream, float* lse = nullptr) {
   FK_CHECK_ARG(q && k && v && o, "fk_attention_fwd_bf16: null pointer");
   FK_CHECK_ARG(B > 0 && H > 0 && S > 0, "fk_attention_fwd_bf16: bad B/H/S %d %d %d", B, H, S);
   FK_CHECK_ARG(o_ld % 4 == 0 && o_batch_stride % 4 == 0 && ((uintptr_t)o % (f32out ? 16 : 8) == 0),
@@ -452,6 +454,7 @@ int attention_entry(const void* q, const void* k, const void* v, void* o, int32_
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o;
   p.B = B; p.H = H; p.S = S; p.v_ld = v_ld; p.v_bs = v_batch_stride; p.o_ld = o_ld; p.o_bs = o_batch_stride;
   p.scale_log2 = scale * 1.4426950408889634f;
+  p.lse = lse;
   return f32out ? launch<8, 3, true>(p, stream) : launch<8, 3, false>(p, stream);
 }
 
@@ -462,6 +465,14 @@ extern "C" int fk_attention_fwd_bf16(const void* q, const void* k, const void* v
                                      int64_t o_batch_stride, float scale, fk_stream_t stream_) {
   return attention_entry(q, k, v, o, B, H, S, v_ld, v_batch_stride, o_ld, o_batch_stride, scale, false,
                          (hipStream_t)stream_);
+}
+
+extern "C" int fk_attention_fwd_lse_bf16(const void* q, const void* k, const void* v, void* o, float* lse, int32_t B,
+                                         int32_t H, int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld,
+                                         int64_t o_batch_stride, float scale, fk_stream_t stream_) {
+  FK_CHECK_ARG(lse != nullptr, "fk_attention_fwd_lse_bf16: null lse");
+  return attention_entry(q, k, v, o, B, H, S, v_ld, v_batch_stride, o_ld, o_batch_stride, scale, false,
+                         (hipStream_t)stream_, lse);
 }
 
 extern "C" int fk_attention_fwd_f32_debug(const void* q, const void* k, const void* v, float* o, int32_t B,

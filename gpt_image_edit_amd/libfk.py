@@ -35,6 +35,10 @@ class GemmArgs(ctypes.Structure):
     ]
 
 
+class AttnView(ctypes.Structure):
+    _fields_ = [("p", c_vp), ("ld", c_i64), ("head_stride", c_i64), ("batch_stride", c_i64)]
+
+
 class ConvArgs(ctypes.Structure):
     _fields_ = [
         ("x", c_vp), ("w", c_vp), ("bias", c_vp), ("y", c_vp), ("res", c_vp),
@@ -55,6 +59,15 @@ SIGNATURES = {
     "fk_qkv_post_bf16": (c_i32, [c_vp] * 9 + [c_i32] * 4 + [c_f32, c_vp]),
     "fk_attention_fwd_bf16": (c_i32, [c_vp] * 4 + [c_i32] * 3 + [c_i64] * 4 + [c_f32, c_vp]),
     "fk_attention_fwd_f32_debug": (c_i32, [c_vp] * 4 + [c_i32] * 3 + [c_i64] * 4 + [c_f32, c_vp]),
+    "fk_attention_fwd_lse_bf16": (c_i32, [c_vp] * 5 + [c_i32] * 3 + [c_i64] * 4 + [c_f32, c_vp]),
+    "fk_attention_bwd_bf16": (c_i32, [ctypes.POINTER(AttnView)] * 4 + [c_vp, c_vp] + [ctypes.POINTER(AttnView)] * 3 + [c_i32] * 3 + [c_f32, c_vp]),
+    "fk_bwd_ws_floats": (c_i64, []),
+    "fk_ln_modulate_bwd_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_i64, c_i64, c_vp, Rows, c_vp, Rows, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_f32, c_vp]),
+    "fk_gate_res_bwd_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_i64, c_i64, c_vp, Rows, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp]),
+    "fk_gelu_bwd_bf16": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "fk_qkv_post_bwd_bf16": (c_i32, [c_vp] * 12 + [c_i32] * 4 + [c_f32, c_vp]),
+    "fk_colsum_bf16": (c_i32, [c_vp, Rows, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "fk_rowdot_bf16": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "fk_silu_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "fk_timestep_proj": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_vp]),
     "fk_add3_bf16": (c_i32, [c_vp] * 4 + [c_i64, c_vp]),

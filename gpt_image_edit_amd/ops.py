@@ -262,6 +262,141 @@ def softmax_rows(x, out=None):
     return out
 
 
+# ---- backward pass of the MMDiT (include/fk.h "backward pass"; reference: autograd, train_denoiser.py:1172) -----------
+_BWD_WS = {}
+
+
+def bwd_workspace(device):
+    """fp32 scratch of the two-stage reductions (one per device; kernels on one stream are ordered)."""
+    key = str(device)
+    ws = _BWD_WS.get(key)
+    if ws is None:
+        ws = torch.empty(libfk.load().fk_bwd_ws_floats(), device=device, dtype=torch.float32)
+        _BWD_WS[key] = ws
+    return ws
+
+
+def attn_view(t, head_major):
+    """fk_attn_view of a bf16 tensor: head-major [B,H,S,128] (contiguous rows) or token-major [B,S,H*128] view."""
+    v = libfk.AttnView()
+    v.p = t.data_ptr()
+    if head_major:
+        if t.dim() != 4 or t.shape[3] != 128 or t.stride(3) != 1:
+            raise ValueError("head-major view must be [B,H,S,128] with a contiguous last dimension")
+        v.ld, v.head_stride, v.batch_stride = t.stride(2), t.stride(1), t.stride(0)
+    else:
+        if t.dim() != 3 or t.stride(2) != 1:
+            raise ValueError("token-major view must be [B,S,H*128] with a contiguous last dimension")
+        v.ld, v.head_stride, v.batch_stride = t.stride(1), 128, t.stride(0)
+    return v
+
+
+def attention_lse(q, k, v, out, lse, scale=None):
+    """:func:`attention` that also writes lse [B,H,S] fp32 (log2 domain) for :func:`attention_bwd`."""
+    _need_cuda(q, k, v, out, lse)
+    B, H, S, hd = q.shape
+    if lse.dtype != torch.float32 or lse.shape != (B, H, S) or not lse.is_contiguous():
+        raise ValueError("lse must be a contiguous fp32 [B,H,S] tensor")
+    libfk.check(libfk.load().fk_attention_fwd_lse_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, H, S, v.stride(1),
+                                                      v.stride(0), out.stride(1), out.stride(0),
+                                                      hd ** -0.5 if scale is None else scale, _stream()),
+                "fk_attention_fwd_lse_bf16")
+    return out
+
+
+def rowdot(a, c, heads, out=None):
+    """out[b,h,s] = sum_d a[b,s,h*128+d] * c[b,s,h*128+d]; a, c: [B,S,heads*128] views."""
+    _need_cuda(a, c)
+    B, S, _ = a.shape
+    if out is None:
+        out = torch.empty((B, heads, S), device=a.device, dtype=torch.float32)
+    libfk.check(libfk.load().fk_rowdot_bf16(_ptr(a), a.stride(1), a.stride(0), _ptr(c), c.stride(1), c.stride(0), _ptr(out),
+                                            B, S, heads, _stream()), "fk_rowdot_bf16")
+    return out
+
+
+def attention_bwd(q, k, v, dout, lse, dsum, dq, dk, dv, scale=None):
+    """dq, dk [B,H,S,128] and dv ([B,S,H*128] view) of softmax(q k^T scale) v given dout ([B,S,H*128] view), lse, dsum."""
+    _need_cuda(q, k, v, dout, lse, dsum, dq, dk, dv)
+    B, H, S, hd = q.shape
+    views = [attn_view(q, True), attn_view(k, True), attn_view(v, False), attn_view(dout, False),
+             attn_view(dq, True), attn_view(dk, True), attn_view(dv, False)]
+    r = [ctypes.byref(x) for x in views]
+    libfk.check(libfk.load().fk_attention_bwd_bf16(r[0], r[1], r[2], r[3], _ptr(lse), _ptr(dsum), r[4], r[5], r[6], B, H, S,
+                                                  hd ** -0.5 if scale is None else scale, _stream()),
+                "fk_attention_bwd_bf16")
+
+
+def ln_modulate_bwd(x, dn, scale, dx_out, dmod_shift, dx_in=None, eps=1e-6):
+    """Adjoint of :func:`ln_modulate` for one stream view x / dn / dx [B,R,D]; scale: [B,D] view of the modulation
+    vector; dmod_shift: fp32 [B, >=2D] view whose columns [0,D) receive dshift and [D,2D) dscale."""
+    _need_cuda(x, dn, scale, dx_out, dmod_shift, dx_in)
+    B, R, D = x.shape
+    M, rx = rows_of(x)
+    _, rg = rows_of(dn)
+    _, ro = rows_of(dx_out)
+    ri = rows_of(dx_in)[1] if dx_in is not None else Rows(0, 0, 0)
+    if dmod_shift.dtype != torch.float32 or dmod_shift.stride(1) != 1 or dmod_shift.shape[1] < 2 * D:
+        raise ValueError("dmod_shift must be an fp32 [B, >= 2D] view")
+    base = dmod_shift.data_ptr()
+    libfk.check(libfk.load().fk_ln_modulate_bwd_bf16(_ptr(x), rx, _ptr(dn), rg, _ptr(scale), scale.stride(0), R, _ptr(dx_in), ri,
+                                                    _ptr(dx_out), ro, ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * D),
+                                                    dmod_shift.stride(0), _ptr(bwd_workspace(x.device)), B, D, eps, _stream()),
+                "fk_ln_modulate_bwd_bf16")
+    return dx_out
+
+
+def gate_res_bwd(dout, y, gate, dy, dgate):
+    """dy = dout * gate[b]; dgate[b] = sum_s dout * y.  dout / y / dy: [B,R,N] views; gate: [B,N] view; dgate fp32 [B,N] view."""
+    _need_cuda(dout, y, gate, dy, dgate)
+    B, R, N = dout.shape
+    _, r0 = rows_of(dout)
+    _, r1 = rows_of(y)
+    _, r2 = rows_of(dy)
+    libfk.check(libfk.load().fk_gate_res_bwd_bf16(_ptr(dout), r0, _ptr(y), r1, _ptr(gate), gate.stride(0), R, _ptr(dy), r2,
+                                                 _ptr(dgate), dgate.stride(0), _ptr(bwd_workspace(dout.device)), B, N, _stream()),
+                "fk_gate_res_bwd_bf16")
+    return dy
+
+
+def gelu_bwd(h, df, out=None):
+    """out = df * gelu_tanh'(h) (contiguous tensors of one shape)."""
+    _need_cuda(h, df)
+    if not (h.is_contiguous() and df.is_contiguous()):
+        raise ValueError("gelu_bwd takes contiguous tensors")
+    if out is None:
+        out = torch.empty_like(df)
+    libfk.check(libfk.load().fk_gelu_bwd_bf16(_ptr(h), _ptr(df), _ptr(out), h.numel(), _stream()), "fk_gelu_bwd_bf16")
+    return out
+
+
+def qkv_post_bwd(dq, dk, qkv, dqkv, wq_img, wk_img, wq_txt, wk_txt, cos, sin, s_txt, eps=1e-6):
+    """Adjoint of :func:`qkv_post`; returns dw fp32 [2 (q,k)][2 (image,text)][128]."""
+    _need_cuda(dq, dk, qkv, dqkv, cos, sin)
+    B, S, D3 = qkv.shape
+    H = D3 // 384
+    if not (qkv.is_contiguous() and dqkv.is_contiguous() and dq.is_contiguous() and dk.is_contiguous()):
+        raise ValueError("qkv_post_bwd takes contiguous tensors")
+    dw = torch.empty((2, 2, 128), device=qkv.device, dtype=torch.float32)
+    libfk.check(libfk.load().fk_qkv_post_bwd_bf16(_ptr(dq), _ptr(dk), _ptr(qkv), _ptr(dqkv), _ptr(wq_img), _ptr(wk_img),
+                                                 _ptr(wq_txt), _ptr(wk_txt), _ptr(cos), _ptr(sin), _ptr(dw),
+                                                 _ptr(bwd_workspace(qkv.device)), B, S, s_txt, H, eps, _stream()),
+                "fk_qkv_post_bwd_bf16")
+    return dw
+
+
+def colsum(x, out=None):
+    """fp32 [N] = sum over the rows of a [M,N] / [B,R,N] view (bias gradients)."""
+    _need_cuda(x)
+    M, rx = rows_of(x)
+    N = x.shape[-1]
+    if out is None:
+        out = torch.empty(N, device=x.device, dtype=torch.float32)
+    libfk.check(libfk.load().fk_colsum_bf16(_ptr(x), rx, M, N, _ptr(out), _ptr(bwd_workspace(x.device)), _stream()),
+                "fk_colsum_bf16")
+    return out
+
+
 # ---- FLUX AutoencoderKL pieces (NHWC bf16 activations) -------------------------------------------------
 def conv2d_nhwc(x, w_packed, bias, cout, ksize=3, stride=1, pad=1, upsample2x=False, res=None, out=None):
     """x: [B,H,W,Cin] bf16; w_packed: [cout, Kpad] (k = (kh*ks+kw)*Cin + ci, zero padded to 64)."""

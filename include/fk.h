@@ -151,6 +151,50 @@ int fk_attention_fwd_f32_debug(const void* q, const void* k, const void* v, floa
                                int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld,
                                int64_t o_batch_stride, float scale, fk_stream_t stream);
 
+/* ---- backward pass of the MMDiT (train_denoiser.py:1172 `accelerator.backward(loss)` through diffusers' blocks) ---- */
+/* Forward attention that also saves lse[b, h, s] = log2(sum_j exp(q.k_j * scale)) (fp32) for the backward pass. */
+int fk_attention_fwd_lse_bf16(const void* q, const void* k, const void* v, void* o, float* lse, int32_t B, int32_t H,
+                              int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld, int64_t o_batch_stride,
+                              float scale, fk_stream_t stream);
+/* A [B, H, S, 128] bf16 tensor in any of the layouts the path uses: element (b, h, s, d) at
+ * p + b*batch_stride + h*head_stride + s*ld + d   (head-major q / k: ld = 128, head_stride = S*128;
+ * token-major slices of a [B, S, n*H*128] buffer: ld = n*H*128, head_stride = 128). */
+typedef struct fk_attn_view {
+  const void* p;
+  int64_t ld, head_stride, batch_stride;
+} fk_attn_view;
+/* dQ, dK, dV of O = softmax(Q K^T scale) V given dO, the forward's lse and dsum[b, h, s] = sum_d dO * O (fk_rowdot_bf16).
+ * Three deterministic passes (no atomics); dq / dk / dv are written, not accumulated. */
+int fk_attention_bwd_bf16(const fk_attn_view* q, const fk_attn_view* k, const fk_attn_view* v, const fk_attn_view* dout,
+                          const float* lse, const float* dsum, const fk_attn_view* dq, const fk_attn_view* dk,
+                          const fk_attn_view* dv, int32_t B, int32_t H, int32_t S, float scale, fk_stream_t stream);
+/* fp32 elements of workspace `ws` the reductions below need (per-workgroup partial sums, fixed-order finalisation). */
+int64_t fk_bwd_ws_floats(void);
+/* Adjoint of fk_ln_modulate_bf16 for one stream (rows [b*rows_per_batch, (b+1)*rows_per_batch) use scale row b):
+ *   dx_out = (dx_in ? dx_in : 0) + dLN/dx,   dshift[b] = sum_s dn,   dscale[b] = sum_s dn * LN(x)     (fp32 outputs;
+ * dscale must be dshift + D: the (shift, scale) chunk pair of the block's modulation vector, batch stride given). */
+int fk_ln_modulate_bwd_bf16(const void* x, fk_rows xr, const void* dn, fk_rows dnr, const void* scale,
+                            int64_t mod_batch_stride, int64_t rows_per_batch, const void* dx_in, fk_rows dxi, void* dx_out,
+                            fk_rows dxo, float* dshift, float* dscale, int64_t dmod_batch_stride, float* ws, int32_t B,
+                            int32_t D, float eps, fk_stream_t stream);
+/* Adjoint of the FK_EPI_GATE_RES epilogue out = res + gate[b] * y:  dy = dout * gate[b] (bf16),
+ * dgate[b, :] = sum_s dout * y (fp32);  dres = dout. */
+int fk_gate_res_bwd_bf16(const void* dout, fk_rows dor, const void* y, fk_rows yr, const void* gate,
+                         int64_t gate_batch_stride, int64_t rows_per_batch, void* dy, fk_rows dyr, float* dgate,
+                         int64_t dgate_batch_stride, float* ws, int32_t B, int32_t N, fk_stream_t stream);
+/* out = df * gelu_tanh'(h) over n elements (h = the Linear's bf16 output before the activation); out may alias df. */
+int fk_gelu_bwd_bf16(const void* h, const void* df, void* out, int64_t n, fk_stream_t stream);
+/* Adjoint of fk_qkv_post_bf16: dq, dk [B, H, S, 128] -> the q and k thirds of dqkv [B, S, 3*H*128] (gradient of the raw
+ * projection `qkv`), and dw [2 (q, k)][2 (image, text)][128] fp32 = gradients of the RMSNorm weights. */
+int fk_qkv_post_bwd_bf16(const void* dq, const void* dk, const void* qkv, void* dqkv, const void* wq_img, const void* wk_img,
+                         const void* wq_txt, const void* wk_txt, const float* cos, const float* sin, float* dw, float* ws,
+                         int32_t B, int32_t S, int32_t S_txt, int32_t H, float eps, fk_stream_t stream);
+/* out[n] = sum_m x[m, n] (fp32): bias gradients. */
+int fk_colsum_bf16(const void* x, fk_rows xr, int64_t M, int32_t N, float* out, float* ws, fk_stream_t stream);
+/* out[b, h, s] = sum_d a[b, s, h*128 + d] * c[b, s, h*128 + d] (fp32): the softmax-backward row term. */
+int fk_rowdot_bf16(const void* a, int64_t a_ld, int64_t a_batch_stride, const void* c, int64_t c_ld,
+                   int64_t c_batch_stride, float* out, int32_t B, int32_t S, int32_t H, fk_stream_t stream);
+
 /* Elementwise / tiny kernels ------------------------------------------------------------------ */
 /* y = bf16(silu(x)) over n elements (n % 8 == 0). */
 int fk_silu_bf16(const void* x, void* y, int64_t n, fk_stream_t stream);
