@@ -1,0 +1,327 @@
+"""MMDiT training forward + backward on the HIP kernels.
+
+Counterpart of what ``accelerator.backward(loss)`` (reference ``train_denoiser.py:1172``) does to the FLUX-Kontext
+denoiser with ``enable_gradient_checkpointing()`` (``:486``): the forward keeps ONE tensor per block -- the residual
+stream entering it -- and the backward walks the blocks in reverse, re-running each block's forward with its pre-gate /
+pre-activation tensors stored (un-fused epilogues, same rounding points, hence the same values as the inference
+forward) and then its adjoint.  Gradients are produced for the parameters the reference un-freezes
+(``train_denoiser.py:70-119``, ``training.trainable_names``): in every double block the image-stream ``attn.to_q / to_k
+/ to_v / to_out.0``, ``attn.norm_q / norm_k`` and ``norm1.linear``; in every single block ``attn.to_q / to_k / to_v``,
+``attn.norm_q / norm_k`` and ``norm.linear`` -- plus the gradient w.r.t. ``encoder_hidden_states`` (for the
+``denoise_projector``).  Frozen weights (MLPs, text-stream projections, embedders) only carry the data gradient.
+
+Everything is a libfk call:
+  data gradients   dX = dY W          fk_gemm_bf16 on W^T (transposed once: frozen weights at first use, trainable ones
+                                      after every optimiser step -- ``refresh()``)
+  weight gradients dW = dY^T X        fk_gemm_bf16 on the two token-major operands transposed by fk_transpose_bf16
+                                      (tokens zero-padded to a multiple of 64 = the GEMM's K granule)
+  adjoints of the fused kernels       fk_attention_bwd_bf16, fk_ln_modulate_bwd_bf16, fk_gate_res_bwd_bf16,
+                                      fk_gelu_bwd_bf16, fk_qkv_post_bwd_bf16, fk_colsum_bf16, fk_rowdot_bf16
+Token reductions are fixed-order two-stage sums and the attention backward uses no atomics: gradients are bit-identical
+from run to run.  Weight gradients are bf16 (what autograd produces for bf16 parameters); bias, norm-weight and
+modulation reductions stay fp32 (``fk_adamw_step`` takes either).
+"""
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+class FluxBackward:
+    """Training forward / backward around a ``HipFluxTransformer2DModel`` (which keeps owning the parameters)."""
+
+    def __init__(self, model, trainable=None):
+        from . import training
+        self.m = model
+        names = list(model.state_dict().keys())
+        self.trainable = set(trainable if trainable is not None else training.trainable_names(names))
+        self._wT = {}          # name -> W^T (bf16 [in, out]) for the data gradients
+        self._buf = {}
+        self._saved = None
+
+    # ---- transposed weights ------------------------------------------------------------------------------------------
+    def _transposed(self, key, w):
+        t = self._wT.get(key)
+        if t is None:
+            t = torch.empty((w.shape[1], w.shape[0]), device=w.device, dtype=BF16)
+            ops.transpose(w.unsqueeze(0), t.unsqueeze(0))
+            self._wT[key] = t
+        return t
+
+    def wT(self, name):
+        return self._transposed(name, self.m.p(name))
+
+    def refresh(self):
+        """After an optimiser step: drop the transposes (and the model's fused copies) of the trainable weights."""
+        for k in list(self._wT):
+            if k in self.trainable or k.startswith("packed:"):
+                del self._wT[k]
+        self.m._packed = None
+
+    # ---- buffers ---------------------------------------------------------------------------------------------------
+    def _b(self, name, shape, dtype=BF16, zero=False):
+        t = self._buf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = (torch.zeros if zero else torch.empty)(shape, device=self.m.device, dtype=dtype)
+            self._buf[name] = t
+        return t
+
+    # ---- weight gradient: dW[N, K] = dY^T X over the rows of two [B, R, *] views ---------------------------------------
+    def _wgrad(self, dy, x, out=None):
+        B, R, N = dy.shape
+        K = x.shape[-1]
+        Mp = _pad64(B * R)
+        dyT = self._b(f"dyT{N}x{Mp}", (N, Mp), zero=True)
+        xT = self._b(f"xT{K}x{Mp}", (K, Mp), zero=True)
+        ops.transpose(dy, torch.as_strided(dyT, (B, N, R), (R, Mp, 1)))
+        ops.transpose(x, torch.as_strided(xT, (B, K, R), (R, Mp, 1)))
+        return ops.gemm(dyT, xT, out=out)
+
+    # ---- forward (training): the inference kernels, one checkpoint per block -------------------------------------------
+    @torch.no_grad()
+    def forward(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids, guidance):
+        m, P = self.m, self.m.p
+        pk = m._packed or m.pack_weights()
+        D = m.inner_dim
+        B, S_img, _ = hidden_states.shape
+        S_txt = encoder_hidden_states.shape[1]
+        ws = m._workspace(B, S_txt, S_img)
+        S = ws.S
+        cos, sin = m._rope(txt_ids, img_ids)
+        hs = hidden_states.to(BF16).contiguous()
+        enc = encoder_hidden_states.to(BF16).contiguous()
+        s = ws.s
+        ops.gemm(hs, P("x_embedder.weight"), P("x_embedder.bias"), out=s[:, S_txt:])
+        ops.gemm(enc, P("context_embedder.weight"), P("context_embedder.bias"), out=s[:, :S_txt])
+        m._conditioning(timestep, guidance, pooled_projections.to(BF16).contiguous(), ws.tproj, ws.e1, ws.t_emb, ws.g_emb,
+                        ws.p_emb, ws.temb, ws.act, ws.mod)
+        nblk = len(pk.double) + len(pk.single)
+        ckpt = self._b("ckpt", (nblk + 1, B, S, D))
+        sv = SimpleNamespace(B=B, S=S, S_txt=S_txt, S_img=S_img, cos=cos, sin=sin, ckpt=ckpt, enc=enc, hs=hs, ws=ws, pk=pk)
+        for i in range(len(pk.double)):
+            ckpt[i].copy_(s)
+            self._double_forward(i, sv, s, save=False)
+        for j in range(len(pk.single)):
+            ckpt[len(pk.double) + j].copy_(s)
+            self._single_forward(j, sv, s, save=False)
+        ckpt[nblk].copy_(s)
+        mod = ws.mod
+        n_img = ws.n[:, S_txt:]
+        ops.ln_modulate(s[:, S_txt:], mod[:, pk.mod_out + D: pk.mod_out + 2 * D], mod[:, pk.mod_out: pk.mod_out + D], out=n_img)
+        self._saved = sv
+        return ops.gemm(n_img, P("proj_out.weight"), P("proj_out.bias"))
+
+    def _chunk(self, sv, off, j):
+        D = self.m.inner_dim
+        return sv.ws.mod[:, off + j * D: off + (j + 1) * D]
+
+    def _double_forward(self, i, sv, s, save):
+        """One FluxTransformerBlock on the joint buffer ``s`` (in place).  save=True: the un-fused form that leaves
+        n1, raw qkv, q, k, o, lse, y1 (pre-gate), x1, n2, h1 (pre-GELU), f, y2 in the buffers the backward reads."""
+        m, P, ws, pk = self.m, self.m.p, sv.ws, sv.pk
+        D, H, S_txt = m.inner_dim, m.num_heads, sv.S_txt
+        blk, p = pk.double[i], f"transformer_blocks.{i}."
+        mi, mt = blk.mod_img, blk.mod_txt
+        ch = lambda off, j: self._chunk(sv, off, j)  # noqa: E731
+        n = ws.n
+        img, txt = slice(S_txt, None), slice(0, S_txt)
+        ops.ln_modulate2(s, ch(mt, 0), ch(mt, 1), ch(mi, 0), ch(mi, 1), S_txt, out=n)
+        ops.gemm_grouped([dict(a=n[:, img], w=blk.wqkv_img, bias=blk.bqkv_img, out=ws.qkv[:, img]),
+                          dict(a=n[:, txt], w=blk.wqkv_txt, bias=blk.bqkv_txt, out=ws.qkv[:, txt])])
+        ops.qkv_post(ws.qkv, ws.q, ws.k, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"),
+                     P(p + "attn.norm_added_q.weight"), P(p + "attn.norm_added_k.weight"), sv.cos, sv.sin, S_txt)
+        if save:
+            ops.attention_lse(ws.q, ws.k, ws.qkv[:, :, 2 * D:], ws.o, self._b("lse", (sv.B, H, sv.S), torch.float32))
+        else:
+            ops.attention(ws.q, ws.k, ws.qkv[:, :, 2 * D:], ws.o)
+        y1 = self._b("y1", (sv.B, sv.S, D))
+        ops.gemm_grouped([dict(a=ws.o[:, img], w=P(p + "attn.to_out.0.weight"), bias=P(p + "attn.to_out.0.bias"), out=y1[:, img]),
+                          dict(a=ws.o[:, txt], w=P(p + "attn.to_add_out.weight"), bias=P(p + "attn.to_add_out.bias"), out=y1[:, txt])])
+        x1 = self._b("x1", (sv.B, sv.S, D)) if save else s
+        ops.gate_res_fwd(s[:, img], y1[:, img], ch(mi, 2), x1[:, img])
+        ops.gate_res_fwd(s[:, txt], y1[:, txt], ch(mt, 2), x1[:, txt])
+        n2 = self._b("n2", (sv.B, sv.S, D))
+        ops.ln_modulate2(x1, ch(mt, 3), ch(mt, 4), ch(mi, 3), ch(mi, 4), S_txt, out=n2)
+        h1 = self._b("h1", (sv.B, sv.S, 4 * D))
+        ops.gemm_grouped([dict(a=n2[:, img], w=P(p + "ff.net.0.proj.weight"), bias=P(p + "ff.net.0.proj.bias"), out=h1[:, img]),
+                          dict(a=n2[:, txt], w=P(p + "ff_context.net.0.proj.weight"), bias=P(p + "ff_context.net.0.proj.bias"),
+                               out=h1[:, txt])])
+        ops.gelu_tanh(h1, ws.ff)
+        y2 = self._b("y2", (sv.B, sv.S, D))
+        ops.gemm_grouped([dict(a=ws.ff[:, img], w=P(p + "ff.net.2.weight"), bias=P(p + "ff.net.2.bias"), out=y2[:, img]),
+                          dict(a=ws.ff[:, txt], w=P(p + "ff_context.net.2.weight"), bias=P(p + "ff_context.net.2.bias"),
+                               out=y2[:, txt])])
+        ops.gate_res_fwd(x1[:, img], y2[:, img], ch(mi, 5), s[:, img])
+        ops.gate_res_fwd(x1[:, txt], y2[:, txt], ch(mt, 5), s[:, txt])
+
+    def _single_forward(self, j, sv, s, save):
+        m, P, ws, pk = self.m, self.m.p, sv.ws, sv.pk
+        D, H = m.inner_dim, m.num_heads
+        blk, p = pk.single[j], f"single_transformer_blocks.{j}."
+        ch = lambda k: self._chunk(sv, blk.mod, k)  # noqa: E731
+        n = ws.n
+        ops.ln_modulate(s, ch(0), ch(1), out=n)
+        ops.gemm(n, blk.wqkv, blk.bqkv, out=ws.qkv)
+        ops.qkv_post(ws.qkv, ws.q, ws.k, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"), None, None, sv.cos, sv.sin, 0)
+        h1 = self._b("h1", (sv.B, sv.S, 4 * D))
+        ops.gemm(n, P(p + "proj_mlp.weight"), P(p + "proj_mlp.bias"), out=h1)
+        ops.gelu_tanh(h1, ws.cat[:, :, D:])
+        if save:
+            ops.attention_lse(ws.q, ws.k, ws.qkv[:, :, 2 * D:], ws.cat[:, :, :D], self._b("lse", (sv.B, H, sv.S), torch.float32))
+        else:
+            ops.attention(ws.q, ws.k, ws.qkv[:, :, 2 * D:], ws.cat[:, :, :D])
+        y1 = self._b("y1", (sv.B, sv.S, D))
+        ops.gemm(ws.cat, P(p + "proj_out.weight"), P(p + "proj_out.bias"), out=y1)
+        ops.gate_res_fwd(s, y1, ch(2), s)
+
+    # ---- backward ----------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def backward(self, dsample):
+        """dsample: gradient of the loss w.r.t. the forward's output [B, S_img, 64] (bf16).
+        Returns (grads: dict name -> tensor, d_encoder_hidden_states [B, S_txt, joint_dim] bf16)."""
+        sv = self._saved
+        if sv is None:
+            raise RuntimeError("FluxBackward.backward() needs the forward() of the same step first")
+        m, P, ws, pk = self.m, self.m.p, sv.ws, sv.pk
+        D, S_txt, B, S = m.inner_dim, sv.S_txt, sv.B, sv.S
+        nd, ns = len(pk.double), len(pk.single)
+        grads = {}
+        mod = ws.mod
+        g = self._b("g", (B, S, D), zero=True)           # gradient of the residual stream
+        g[:, :S_txt].zero_()
+        dmod_out = self._b("dmod_out", (B, 2 * D), torch.float32)
+        # head: sample = proj_out(LN(h) (1 + scale) + shift); AdaLayerNormContinuous and proj_out are frozen
+        dn = self._b("dn", (B, S, D))
+        ops.gemm(dsample.to(BF16).contiguous(), self.wT("proj_out.weight"), out=dn[:, S_txt:])
+        ops.ln_modulate_bwd(sv.ckpt[nd + ns][:, S_txt:], dn[:, S_txt:], mod[:, pk.mod_out: pk.mod_out + D], g[:, S_txt:], dmod_out)
+        s = ws.s
+        for j in reversed(range(ns)):
+            s.copy_(sv.ckpt[nd + j])
+            self._single_forward(j, sv, s, save=True)
+            self._single_backward(j, sv, g, grads)
+        for i in reversed(range(nd)):
+            s.copy_(sv.ckpt[i])
+            self._double_forward(i, sv, s, save=True)
+            self._double_backward(i, sv, g, grads)
+        d_enc = ops.gemm(g[:, :S_txt], self.wT("context_embedder.weight"))
+        self._saved = None
+        return {k: v for k, v in grads.items() if k in self.trainable}, d_enc
+
+    def _double_backward(self, i, sv, g, grads):
+        m, P, ws, pk = self.m, self.m.p, sv.ws, sv.pk
+        D, H, S_txt, B, S = m.inner_dim, m.num_heads, sv.S_txt, sv.B, sv.S
+        blk, p = pk.double[i], f"transformer_blocks.{i}."
+        mi, mt = blk.mod_img, blk.mod_txt
+        ch = lambda off, j: self._chunk(sv, off, j)  # noqa: E731
+        img, txt = slice(S_txt, None), slice(0, S_txt)
+        x0, x1, y1, y2, n1, n2, h1 = sv.ckpt[i], self._buf["x1"], self._buf["y1"], self._buf["y2"], ws.n, self._buf["n2"], self._buf["h1"]
+        dmod = self._b("dmod_d", (B, 12 * D), torch.float32, zero=True)     # [image 6D | text 6D], chunk order of the block
+        dm_i, dm_t = dmod[:, :6 * D], dmod[:, 6 * D:]
+        dy = self._b("dy", (B, S, D))
+        dff = self._b("dff", (B, S, 4 * D))
+        dn = self._b("dn", (B, S, D))
+        # -- MLP: x2 = x1 + gate_mlp * y2
+        ops.gate_res_bwd(g[:, img], y2[:, img], ch(mi, 5), dy[:, img], dm_i[:, 5 * D:6 * D])
+        ops.gate_res_bwd(g[:, txt], y2[:, txt], ch(mt, 5), dy[:, txt], dm_t[:, 5 * D:6 * D])
+        ops.gemm_grouped([dict(a=dy[:, img], w=self.wT(p + "ff.net.2.weight"), out=dff[:, img]),
+                          dict(a=dy[:, txt], w=self.wT(p + "ff_context.net.2.weight"), out=dff[:, txt])])
+        ops.gelu_bwd(h1, dff, out=dff)
+        ops.gemm_grouped([dict(a=dff[:, img], w=self.wT(p + "ff.net.0.proj.weight"), out=dn[:, img]),
+                          dict(a=dff[:, txt], w=self.wT(p + "ff_context.net.0.proj.weight"), out=dn[:, txt])])
+        ops.ln_modulate_bwd(x1[:, img], dn[:, img], ch(mi, 4), g[:, img], dm_i[:, 3 * D:5 * D], dx_in=g[:, img])
+        ops.ln_modulate_bwd(x1[:, txt], dn[:, txt], ch(mt, 4), g[:, txt], dm_t[:, 3 * D:5 * D], dx_in=g[:, txt])
+        # -- attention output projection: x1 = x0 + gate_msa * y1
+        ops.gate_res_bwd(g[:, img], y1[:, img], ch(mi, 2), dy[:, img], dm_i[:, 2 * D:3 * D])
+        ops.gate_res_bwd(g[:, txt], y1[:, txt], ch(mt, 2), dy[:, txt], dm_t[:, 2 * D:3 * D])
+        do = self._b("do", (B, S, D))
+        ops.gemm_grouped([dict(a=dy[:, img], w=self.wT(p + "attn.to_out.0.weight"), out=do[:, img]),
+                          dict(a=dy[:, txt], w=self.wT(p + "attn.to_add_out.weight"), out=do[:, txt])])
+        if p + "attn.to_out.0.weight" in self.trainable:
+            grads[p + "attn.to_out.0.weight"] = self._wgrad(dy[:, img], ws.o[:, img]).clone()
+            grads[p + "attn.to_out.0.bias"] = ops.colsum(dy[:, img])
+        # -- joint attention
+        dqkv = self._b("dqkv", (B, S, 3 * D))
+        dq, dk = self._b("dq", (B, H, S, 128)), self._b("dk", (B, H, S, 128))
+        dsum = ops.rowdot(do, ws.o, H, out=self._b("dsum", (B, H, S), torch.float32))
+        ops.attention_bwd(ws.q, ws.k, ws.qkv[:, :, 2 * D:], do, self._buf["lse"], dsum, dq, dk, dqkv[:, :, 2 * D:])
+        dw = ops.qkv_post_bwd(dq, dk, ws.qkv, dqkv, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"),
+                              P(p + "attn.norm_added_q.weight"), P(p + "attn.norm_added_k.weight"), sv.cos, sv.sin, S_txt)
+        grads[p + "attn.norm_q.weight"], grads[p + "attn.norm_k.weight"] = dw[0, 0].clone(), dw[1, 0].clone()
+        grads[p + "attn.norm_added_q.weight"], grads[p + "attn.norm_added_k.weight"] = dw[0, 1].clone(), dw[1, 1].clone()
+        ops.gemm_grouped([dict(a=dqkv[:, img], w=self._transposed("packed:" + p + "qkv_img", blk.wqkv_img), out=dn[:, img]),
+                          dict(a=dqkv[:, txt], w=self._transposed("packed:" + p + "qkv_txt", blk.wqkv_txt), out=dn[:, txt])])
+        if p + "attn.to_q.weight" in self.trainable:
+            dwqkv = self._wgrad(dqkv[:, img], n1[:, img])
+            dbqkv = ops.colsum(dqkv[:, img])
+            for k, nm in enumerate(("to_q", "to_k", "to_v")):
+                grads[p + f"attn.{nm}.weight"] = dwqkv[k * D:(k + 1) * D].clone()
+                grads[p + f"attn.{nm}.bias"] = dbqkv[k * D:(k + 1) * D].clone()
+        ops.ln_modulate_bwd(x0[:, img], dn[:, img], ch(mi, 1), g[:, img], dm_i[:, 0:2 * D], dx_in=g[:, img])
+        ops.ln_modulate_bwd(x0[:, txt], dn[:, txt], ch(mt, 1), g[:, txt], dm_t[:, 0:2 * D], dx_in=g[:, txt])
+        if p + "norm1.linear.weight" in self.trainable:
+            grads[p + "norm1.linear.weight"], grads[p + "norm1.linear.bias"] = self._mod_grads(dm_i, ws.act)
+        if p + "norm1_context.linear.weight" in self.trainable:
+            grads[p + "norm1_context.linear.weight"], grads[p + "norm1_context.linear.bias"] = self._mod_grads(dm_t, ws.act)
+
+    def _mod_grads(self, dmod, act):
+        """AdaLN linear mod = W silu(temb) + b:  dW[n, k] = sum_b dmod[b, n] act[b, k],  db[n] = sum_b dmod[b, n] -- two
+        GEMMs whose K dimension is the batch (zero-padded to 64), the second against a matrix of ones."""
+        B, n = dmod.shape
+        D = act.shape[1]
+        dT = self._b(f"dmodT{n}", (n, 64))
+        aT = self._b("actT", (D, 64), zero=True)
+        ones = self._b("onesT", (64, 64), zero=True)
+        ones[:, :B] = 1.0
+        ops.f32_to_bf16_transposed(dmod, dT)
+        ops.transpose(act.unsqueeze(0), torch.as_strided(aT, (1, D, B), (0, 64, 1)))
+        return ops.gemm(dT, aT).clone(), ops.gemm(dT, ones)[:, 0].clone()
+
+    def _single_backward(self, j, sv, g, grads):
+        m, P, ws, pk = self.m, self.m.p, sv.ws, sv.pk
+        D, H, B, S = m.inner_dim, m.num_heads, sv.B, sv.S
+        blk, p = pk.single[j], f"single_transformer_blocks.{j}."
+        ch = lambda k: self._chunk(sv, blk.mod, k)  # noqa: E731
+        x0, y1, n1, h1 = sv.ckpt[len(pk.double) + j], self._buf["y1"], ws.n, self._buf["h1"]
+        dmod = self._b("dmod_s", (B, 3 * D), torch.float32, zero=True)
+        dy = self._b("dy", (B, S, D))
+        do = self._b("do", (B, S, D))
+        dff = self._b("dff", (B, S, 4 * D))
+        dn = self._b("dn", (B, S, D))
+        # x' = x + gate * y, y = proj_out([attn | gelu(mlp)])
+        ops.gate_res_bwd(g, y1, ch(2), dy, dmod[:, 2 * D:3 * D])
+        woT = self.wT(p + "proj_out.weight")                       # [5D, D]: rows [0, D) -> attention, [D, 5D) -> MLP
+        ops.gemm(dy, woT[:D], out=do)
+        ops.gemm(dy, woT[D:], out=dff)
+        ops.gelu_bwd(h1, dff, out=dff)
+        dqkv = self._b("dqkv", (B, S, 3 * D))
+        dq, dk = self._b("dq", (B, H, S, 128)), self._b("dk", (B, H, S, 128))
+        o = ws.cat[:, :, :D]
+        dsum = ops.rowdot(do, o, H, out=self._b("dsum", (B, H, S), torch.float32))
+        ops.attention_bwd(ws.q, ws.k, ws.qkv[:, :, 2 * D:], do, self._buf["lse"], dsum, dq, dk, dqkv[:, :, 2 * D:])
+        dw = ops.qkv_post_bwd(dq, dk, ws.qkv, dqkv, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"), None, None,
+                              sv.cos, sv.sin, 0)
+        grads[p + "attn.norm_q.weight"], grads[p + "attn.norm_k.weight"] = dw[0, 0].clone(), dw[1, 0].clone()
+        ops.gemm(dqkv, self._transposed("packed:" + p + "qkv", blk.wqkv), out=dn)
+        ops.gemm(dff, self.wT(p + "proj_mlp.weight"), out=dn, epilogue=ops.FK_EPI_RES, res=dn)
+        if p + "attn.to_q.weight" in self.trainable:
+            dwqkv = self._wgrad(dqkv, n1)
+            dbqkv = ops.colsum(dqkv)
+            for k, nm in enumerate(("to_q", "to_k", "to_v")):
+                grads[p + f"attn.{nm}.weight"] = dwqkv[k * D:(k + 1) * D].clone()
+                grads[p + f"attn.{nm}.bias"] = dbqkv[k * D:(k + 1) * D].clone()
+        if p + "proj_mlp.weight" in self.trainable:
+            grads[p + "proj_mlp.weight"] = self._wgrad(dff, n1).clone()
+            grads[p + "proj_mlp.bias"] = ops.colsum(dff)
+        if p + "proj_out.weight" in self.trainable:
+            grads[p + "proj_out.weight"] = self._wgrad(dy, ws.cat).clone()
+            grads[p + "proj_out.bias"] = ops.colsum(dy)
+        ops.ln_modulate_bwd(x0, dn, ch(1), g, dmod[:, 0:2 * D], dx_in=g)
+        if p + "norm.linear.weight" in self.trainable:
+            grads[p + "norm.linear.weight"], grads[p + "norm.linear.bias"] = self._mod_grads(dmod, ws.act)

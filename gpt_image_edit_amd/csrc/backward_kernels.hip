@@ -347,6 +347,51 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const bf16_t* a, int64_t a_
   if (chunk == 0 && unit < total) out[((int64_t)b * H + h) * S + s] = d;
 }
 
+// ---- forward helpers of the recomputed (un-fused) block forward ----------------------------------------------------
+// out = bf16(res + bf16(gate_b * y)): the FK_EPI_GATE_RES epilogue applied to an already stored y (same rounding points)
+__global__ __launch_bounds__(256) void gate_res_fwd_kernel(const bf16_t* res, fk_rows rr, const bf16_t* y, fk_rows yr,
+                                                           const bf16_t* gate, int64_t gate_bs, int64_t rpb, bf16_t* out,
+                                                           fk_rows orr, int64_t M, int N) {
+  const int cpr = N / 8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M * cpr; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / cpr;
+    const int col = (int)(i - m * cpr) * 8;
+    const int64_t b = m / rpb;
+    const u32x4_t rw = *(const u32x4_t*)(res + fk_row_offset(rr, m) + col);
+    const u32x4_t yw = *(const u32x4_t*)(y + fk_row_offset(yr, m) + col);
+    const u32x4_t gw = *(const u32x4_t*)(gate + b * gate_bs + col);
+    u32x4_t ow;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float y0 = bf_lo(yw[e]) * bf_lo(gw[e]), y1 = bf_hi(yw[e]) * bf_hi(gw[e]);
+      round_bf_pair(y0, y1);
+      ow[e] = pack_bf2(bf_lo(rw[e]) + y0, bf_hi(rw[e]) + y1);
+    }
+    *(u32x4_t*)(out + fk_row_offset(orr, m) + col) = ow;
+  }
+}
+// y = bf16(gelu_tanh(x)), same function as the FK_EPI_GELU_TANH epilogue
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* x, fk_rows xr, bf16_t* y, fk_rows yr, int64_t M, int N) {
+  const int cpr = N / 8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M * cpr; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / cpr;
+    const int col = (int)(i - m * cpr) * 8;
+    const u32x4_t xw = *(const u32x4_t*)(x + fk_row_offset(xr, m) + col);
+    u32x4_t ow;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ow[e] = pack_bf2(gelu_tanh_f(bf_lo(xw[e])), gelu_tanh_f(bf_hi(xw[e])));
+    *(u32x4_t*)(y + fk_row_offset(yr, m) + col) = ow;
+  }
+}
+// dst[c, ld-padded] (bf16) = src[r, c] (fp32), r < R (<= ld): the [B, n] fp32 modulation gradients as the K-padded
+// operand of the weight-gradient GEMM; columns r >= R are zeroed.
+__global__ __launch_bounds__(256) void f32_to_bf16_t_kernel(const float* src, int64_t src_ld, bf16_t* dst, int ld, int R, int C) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)C * ld) return;
+  const int c = (int)(i / ld), r = (int)(i - (int64_t)c * ld);
+  dst[i] = r < R ? f2bf(src[(int64_t)r * src_ld + c]) : (bf16_t)0;
+}
+
 int pick_chunks(int64_t rows, int per_iter) {
   int64_t c = (rows + per_iter - 1) / per_iter;
   if (c > 64) c = 64;
@@ -453,6 +498,41 @@ extern "C" int fk_qkv_post_bwd_bf16(const void* dq, const void* dk, const void* 
   // dw: [which 2][stream 2 (0 = image, 1 = text)][128]
   hipLaunchKernelGGL(finalize_partials_kernel, dim3(2, 1), dim3(256), 0, stream, ws, dw, 0, nblk, 4 * HD, 0);
   FK_CHECK_LAUNCH("fk_qkv_post_bwd_bf16 (finalize)");
+  return FK_OK;
+}
+
+extern "C" int fk_gate_res_fwd_bf16(const void* res, fk_rows rr, const void* y, fk_rows yr, const void* gate,
+                                    int64_t gate_batch_stride, int64_t rows_per_batch, void* out, fk_rows orr, int64_t M,
+                                    int32_t N, fk_stream_t stream_) {
+  FK_CHECK_ARG(res && y && gate && out && M > 0 && N > 0 && N % 8 == 0 && rows_per_batch > 0, "fk_gate_res_fwd_bf16: bad arguments");
+  FK_CHECK_ARG(FK_ALIGNED16(res) && FK_ALIGNED16(y) && FK_ALIGNED16(gate) && FK_ALIGNED16(out) && rr.ld % 8 == 0 &&
+                   yr.ld % 8 == 0 && orr.ld % 8 == 0 && gate_batch_stride % 8 == 0,
+               "fk_gate_res_fwd_bf16: 16-byte alignment");
+  const int64_t n = M * (N / 8);
+  const int blocks = (int)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256);
+  hipLaunchKernelGGL(gate_res_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)res, rr,
+                     (const bf16_t*)y, yr, (const bf16_t*)gate, gate_batch_stride, rows_per_batch, (bf16_t*)out, orr, M, N);
+  FK_CHECK_LAUNCH("fk_gate_res_fwd_bf16");
+  return FK_OK;
+}
+
+extern "C" int fk_gelu_tanh_bf16(const void* x, fk_rows xr, void* y, fk_rows yr, int64_t M, int32_t N, fk_stream_t stream_) {
+  FK_CHECK_ARG(x && y && M > 0 && N > 0 && N % 8 == 0, "fk_gelu_tanh_bf16: bad arguments");
+  FK_CHECK_ARG(FK_ALIGNED16(x) && FK_ALIGNED16(y) && xr.ld % 8 == 0 && yr.ld % 8 == 0, "fk_gelu_tanh_bf16: 16-byte alignment");
+  const int64_t n = M * (N / 8);
+  const int blocks = (int)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256);
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)x, xr, (bf16_t*)y, yr, M, N);
+  FK_CHECK_LAUNCH("fk_gelu_tanh_bf16");
+  return FK_OK;
+}
+
+extern "C" int fk_f32_to_bf16_transposed(const float* src, int64_t src_ld, void* dst, int32_t dst_ld, int32_t R, int32_t C,
+                                         fk_stream_t stream_) {
+  FK_CHECK_ARG(src && dst && R > 0 && C > 0 && dst_ld >= R, "fk_f32_to_bf16_transposed: bad arguments");
+  const int64_t n = (int64_t)C * dst_ld;
+  hipLaunchKernelGGL(f32_to_bf16_t_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, src, src_ld,
+                     (bf16_t*)dst, dst_ld, R, C);
+  FK_CHECK_LAUNCH("fk_f32_to_bf16_transposed");
   return FK_OK;
 }
 

@@ -385,6 +385,38 @@ def qkv_post_bwd(dq, dk, qkv, dqkv, wq_img, wk_img, wq_txt, wk_txt, cos, sin, s_
     return dw
 
 
+def gate_res_fwd(res, y, gate, out):
+    """out = res + gate[b] * y with the fused epilogue's rounding; res / y / out: [B,R,N] views, gate: [B,N] view."""
+    _need_cuda(res, y, gate, out)
+    B, R, N = y.shape
+    M, r1 = rows_of(y)
+    _, r0 = rows_of(res)
+    _, r2 = rows_of(out)
+    libfk.check(libfk.load().fk_gate_res_fwd_bf16(_ptr(res), r0, _ptr(y), r1, _ptr(gate), gate.stride(0), R, _ptr(out), r2, M, N,
+                                                 _stream()), "fk_gate_res_fwd_bf16")
+    return out
+
+
+def gelu_tanh(x, out):
+    """out = gelu_tanh(x) (bf16, the GEMM epilogue's function); x / out: [M,N] or [B,R,N] views."""
+    _need_cuda(x, out)
+    M, r0 = rows_of(x)
+    _, r1 = rows_of(out)
+    libfk.check(libfk.load().fk_gelu_tanh_bf16(_ptr(x), r0, _ptr(out), r1, M, x.shape[-1], _stream()), "fk_gelu_tanh_bf16")
+    return out
+
+
+def f32_to_bf16_transposed(src, dst):
+    """dst[c, r] = bf16(src[r, c]) for an fp32 [R,C] view and a bf16 [C, ld >= R] buffer (extra columns zeroed)."""
+    _need_cuda(src, dst)
+    R, C = src.shape
+    if src.dtype != torch.float32 or src.stride(1) != 1 or dst.dtype != BF16 or not dst.is_contiguous() or dst.shape[0] != C:
+        raise ValueError("f32_to_bf16_transposed: fp32 [R,C] view -> contiguous bf16 [C, ld]")
+    libfk.check(libfk.load().fk_f32_to_bf16_transposed(_ptr(src), src.stride(0), _ptr(dst), dst.shape[1], R, C, _stream()),
+                "fk_f32_to_bf16_transposed")
+    return dst
+
+
 def colsum(x, out=None):
     """fp32 [N] = sum over the rows of a [M,N] / [B,R,N] view (bias gradients)."""
     _need_cuda(x)

@@ -1,0 +1,80 @@
+"""One optimisation step of the denoiser on the HIP path (BASELINE.json configs[4]).
+
+Counterpart of the body of the reference's training loop, ``train_denoiser.py:935-1181``, for the shipped FLUX-Kontext
+configuration (continuous timesteps, unit loss weights, guidance 1.0, AdamW, global-norm clipping at 1.0,
+``only_tune_image_branch``): noisy input mixed and packed (``fk_flow_noisy_tokens_bf16``), MMDiT forward with one
+checkpoint per block and backward (``backward.FluxBackward``), flow-matching loss fused with its gradient
+(``fk_flow_loss_bf16``), squared gradient norm (``fk_sumsq``) and AdamW with the clipping coefficient folded in and the
+bf16 parameter copy written in the same pass (``fk_adamw_step``).  The step's scalars (which parameters train, sigma
+sampling, shift) are ``training.py``; the data-parallel exchange is ``zero.py``.  No torch arithmetic touches an
+activation, gradient or parameter.
+"""
+import torch
+
+from . import helpers, ops
+from .backward import FluxBackward
+
+BF16 = torch.bfloat16
+
+
+class DenoiserTrainStep:
+    def __init__(self, model, lr=1e-6, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, trainable=None):
+        self.model = model
+        self.bw = FluxBackward(model, trainable)
+        self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.step_count = 0
+        self.state = {}     # name -> (fp32 master, exp_avg, exp_avg_sq)
+
+    def _state(self, name):
+        st = self.state.get(name)
+        if st is None:
+            p = self.model.p(name)
+            st = (p.detach().float().contiguous(), torch.zeros(p.shape, device=p.device, dtype=torch.float32),
+                  torch.zeros(p.shape, device=p.device, dtype=torch.float32))
+            self.state[name] = st
+        return st
+
+    @torch.no_grad()
+    def forward_backward(self, model_input, cond_latents, noise, sigmas, prompt_embeds, pooled, guidance_scale=1.0):
+        """(loss fp64 [1], grads, d_prompt_embeds) for one batch of equally sized samples; model_input / noise fp32
+        [B,16,h,w] (VAE latents already shifted and scaled), cond_latents the same or None, sigmas fp32 [B]."""
+        dev = self.model.device
+        B, C, h, w = model_input.shape
+        S_tgt = (h // 2) * (w // 2)
+        S_cond = 0 if cond_latents is None else (cond_latents.shape[2] // 2) * (cond_latents.shape[3] // 2)
+        tokens = torch.empty(B, S_tgt + S_cond, 4 * C, device=dev, dtype=BF16)
+        ops.flow_noisy_tokens(model_input.contiguous(), noise.contiguous(), sigmas.contiguous(), out=tokens[:, :S_tgt])
+        ids = helpers._prepare_latent_image_ids(B, h // 2, w // 2, dev, BF16)
+        if cond_latents is not None:
+            ch, cw = cond_latents.shape[2], cond_latents.shape[3]
+            tokens[:, S_tgt:].copy_(helpers._pack_latents(cond_latents.to(BF16), B, C, ch, cw))
+            cids = helpers._prepare_latent_image_ids(B, ch // 2, cw // 2, dev, BF16)
+            cids[..., 0] = 1
+            ids = torch.cat([ids, cids], dim=0)
+        txt_ids = torch.zeros(prompt_embeds.shape[1], 3, device=dev, dtype=BF16)
+        guidance = torch.full([B], guidance_scale, device=dev, dtype=torch.float32)
+        timestep = (sigmas * 1000.0).to(BF16) / 1000            # `timesteps / 1000` as the model receives it (:1073)
+        pred = self.bw.forward(tokens, prompt_embeds, pooled, timestep, ids, txt_ids, guidance)
+        loss, grad = ops.flow_loss(pred[:, :S_tgt], model_input.contiguous(), noise.contiguous())
+        dsample = torch.zeros_like(pred)
+        dsample[:, :S_tgt].copy_(grad)
+        grads, d_enc = self.bw.backward(dsample)
+        return loss, grads, d_enc
+
+    @torch.no_grad()
+    def optimizer_step(self, grads):
+        """Global-norm clipping + AdamW on fp32 masters; the bf16 parameters of the model are rewritten in the same pass."""
+        names = sorted(grads)
+        sumsq = ops.sumsq([grads[k].contiguous() for k in names])
+        self.step_count += 1
+        for k in names:
+            master, m1, m2 = self._state(k)
+            ops.adamw_step(master, grads[k].contiguous(), m1, m2, self.step_count, self.lr, self.betas, self.eps,
+                           self.weight_decay, grad_sumsq=sumsq, max_grad_norm=self.max_grad_norm, param_bf16=self.model.p(k).data)
+        self.bw.refresh()
+        return sumsq
+
+    def step(self, **batch):
+        loss, grads, d_enc = self.forward_backward(**batch)
+        sumsq = self.optimizer_step(grads)
+        return dict(loss=loss, grad_sumsq=sumsq, d_prompt_embeds=d_enc, grads=grads)

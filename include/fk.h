@@ -189,6 +189,16 @@ int fk_gelu_bwd_bf16(const void* h, const void* df, void* out, int64_t n, fk_str
 int fk_qkv_post_bwd_bf16(const void* dq, const void* dk, const void* qkv, void* dqkv, const void* wq_img, const void* wk_img,
                          const void* wq_txt, const void* wk_txt, const float* cos, const float* sin, float* dw, float* ws,
                          int32_t B, int32_t S, int32_t S_txt, int32_t H, float eps, fk_stream_t stream);
+/* Un-fused pieces of the block forward that the recomputation (gradient checkpointing, train_denoiser.py:486) runs so
+ * that the pre-gate / pre-activation tensors exist: out = bf16(res + bf16(gate[b] * y)) (the FK_EPI_GATE_RES epilogue on a
+ * stored y) and y = bf16(gelu_tanh(x)) (the FK_EPI_GELU_TANH epilogue on a stored x); same rounding points. */
+int fk_gate_res_fwd_bf16(const void* res, fk_rows rr, const void* y, fk_rows yr, const void* gate, int64_t gate_batch_stride,
+                         int64_t rows_per_batch, void* out, fk_rows orr, int64_t M, int32_t N, fk_stream_t stream);
+int fk_gelu_tanh_bf16(const void* x, fk_rows xr, void* y, fk_rows yr, int64_t M, int32_t N, fk_stream_t stream);
+/* dst[c, r] (bf16, row length dst_ld >= R, columns r >= R zeroed) = src[r, c] (fp32, row stride src_ld): the fp32
+ * modulation-vector gradients [B, n] as the K-padded operand of their weight-gradient GEMM. */
+int fk_f32_to_bf16_transposed(const float* src, int64_t src_ld, void* dst, int32_t dst_ld, int32_t R, int32_t C,
+                              fk_stream_t stream);
 /* out[n] = sum_m x[m, n] (fp32): bias gradients. */
 int fk_colsum_bf16(const void* x, fk_rows xr, int64_t M, int32_t N, float* out, float* ws, fk_stream_t stream);
 /* out[b, h, s] = sum_d a[b, s, h*128 + d] * c[b, s, h*128 + d] (fp32): the softmax-backward row term. */
