@@ -53,21 +53,28 @@ def test_backward_matches_autograd_and_adamw_step():
     refbf = otrain.train_step(sd_bf, trainable, batch, {}, flux_config=cfg, lr=1e-3)
     print(f"loss hip {loss.item():.6f}  fp32-oracle {ref32['loss'].item():.6f}  bf16-oracle {refbf['loss'].item():.6f}")
     assert abs(loss.item() - ref32["loss"].item()) <= max(2 * abs(refbf["loss"].item() - ref32["loss"].item()), 2e-3 * ref32["loss"].item())
-    worst = 0.0
+    worst = worst_bf = 0.0
     for k in trainable:
         e_hip, e_floor = _rel(grads[k].cpu(), ref32["grads"][k]), _rel(refbf["grads"][k], ref32["grads"][k])
-        worst = max(worst, e_hip / max(e_floor, 1e-3))
-        print(f"[grad] {k:55s} hip-vs-fp32 {e_hip:.3e}   bf16-autograd floor {e_floor:.3e}")
+        e_bf = _rel(grads[k].cpu(), refbf["grads"][k])
+        worst, worst_bf = max(worst, e_hip / max(e_floor, 1e-3)), max(worst_bf, e_bf / max(e_floor, 1e-3))
+        print(f"[grad] {k:50s} hip-vs-fp32 {e_hip:.3e}  bf16-autograd floor {e_floor:.3e}  hip-vs-bf16-autograd {e_bf:.3e}")
         assert e_hip <= max(2.0 * e_floor, 2e-2), f"{k}: HIP gradient {e_hip:.3e} from fp32 autograd, floor {e_floor:.3e}"
-    print(f"worst hip / floor ratio {worst:.2f}")
-    # the whole step: clipped AdamW on fp32 masters; compare the updated parameters with the fp32 oracle's
+        # the forward's bf16 rounding points are shared with the bf16 oracle, so the HIP gradient sits much closer to
+        # bf16 autograd than either sits to fp32 autograd
+        assert e_bf <= max(0.6 * e_floor, 2e-2), f"{k}: HIP gradient {e_bf:.3e} from bf16 autograd (floor {e_floor:.3e})"
+    print(f"worst hip / floor ratio {worst:.2f}; worst (hip vs bf16 autograd) / floor {worst_bf:.2f}")
+    # the whole step: global-norm clipping + AdamW on fp32 masters, bf16 copies rewritten -- against the oracle's
+    # optimiser arithmetic fed the SAME (HIP) gradients
+    want_p, _, want_norm = otrain.adamw_step({k: sd32[k] for k in trainable}, {k: grads[k].float().cpu() for k in trainable},
+                                             {}, lr=1e-3)
     norm = ts.optimizer_step(grads).sqrt().item()
-    assert abs(norm - ref32["grad_norm"].item()) <= 2e-2 * ref32["grad_norm"].item()
+    assert abs(norm - want_norm.item()) <= 1e-4 * want_norm.item()
+    assert abs(norm - ref32["grad_norm"].item()) <= 5e-2 * ref32["grad_norm"].item()
     for k in trainable:
         new = model.p(k).detach().float().cpu()
-        want = ref32["params"][k]
-        moved = (want - sd32[k]).abs().max().item()
-        assert (new - want).abs().max().item() <= 0.25 * moved + 2.0 ** -8 * want.abs().max().item(), k
+        assert (new - want_p[k]).abs().max().item() <= 2.0 ** -8 * want_p[k].abs().max().item() + 1e-6, k   # bf16 copy of the fp32 master
+        assert (ts.state[k][0].cpu() - want_p[k]).abs().max().item() <= 1e-5, k                              # the master itself
     # and the model keeps running after the update (fused weight copies and transposes are refreshed)
     loss3, _, _ = ts.forward_backward(**dev_batch)
     assert torch.isfinite(loss3).all() and loss3.item() != loss.item()
