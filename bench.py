@@ -24,6 +24,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   extra        : the 1024 x 1024 half of BASELINE.json's metric (`single_1024x1024_28step`, same run, after the
                  timed region: 1 warm-up + 3 timed edits per GPU, its own roofline) and the prompt-encode time
                  T_prompt / T_e2e of SURVEY.md section 8(d);
+  extra.cfg5_* : one stage-2 optimisation step of the denoiser (BASELINE.json configs[4]) on this GPU, samples/s;
   dist         : world size and backend as torch.distributed reports them.
 
 Other workloads (`--workload`): cfg 3 (`cfg3_batch32_1024x1024_28step`), cfg 4 (`cfg4_batch256_dp8`: 32 edits per
@@ -260,6 +261,55 @@ def prompt_encode_time(device, batch=1):
     return bench_prompt_encode(device, batch=batch)
 
 
+def train_step_bench(device, steps=3, warmup=1, world=1):
+    """BASELINE.json configs[4] on this rank's GPU: one stage-2 optimisation step of the denoiser at 1024^2, batch 1 per
+    GPU (S_txt = 512 + 4096 target + 4096 condition tokens), the parameters the reference un-freezes
+    (`only_tune_image_branch`), one activation checkpoint per block, AdamW on ZeRO-2-sharded fp32 state (with world > 1:
+    fp32 gradient reduce-scatter + bf16 parameter all-gather over RCCL).  Synthetic latents / embeddings / weights."""
+    from gpt_image_edit_amd import flux_spec
+    from gpt_image_edit_amd.train_step import DenoiserTrainStep
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+
+    def flops_forward(S, D=3072, n_double=19, n_single=38):   # BASELINE.md section 2 (embedders omitted)
+        nb = n_double + n_single
+        return nb * 24 * D * D * S + nb * 4 * S * S * D + 2 * (n_double * 12 + n_single * 3 + 2) * D * D
+    model = HipFluxTransformer2DModel(dict(flux_spec.FLUX_KONTEXT_CONFIG), device=device, init="synthetic", seed=0)
+    ts = DenoiserTrainStep(model, sharded=True)
+    g = torch.Generator(device=device).manual_seed(7)
+    B, h, w, S_txt = 1, 128, 128, 512
+    batch = dict(model_input=torch.randn(B, 16, h, w, generator=g, device=device),
+                 cond_latents=torch.randn(B, 16, h, w, generator=g, device=device),
+                 noise=torch.randn(B, 16, h, w, generator=g, device=device),
+                 sigmas=torch.rand(B, generator=g, device=device) * 0.8 + 0.1,
+                 prompt_embeds=torch.randn(B, S_txt, 4096, generator=g, device=device).to(BF),
+                 pooled=torch.randn(B, 768, generator=g, device=device).to(BF))
+    for _ in range(warmup):
+        out = ts.step(**batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = ts.step(**batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(out["loss"]).all()
+    S = S_txt + 2 * (h // 2) * (w // 2)
+    n_train = sum(ts.model.p(k).numel() for k in ts.bw.trainable)
+    fwd = flops_forward(S)
+    return {"value": B * world / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "n_gpus": world, "steps": steps, "warmup": warmup,
+            "loss": float(out["loss"].item()), "trainable_params": n_train, "seq_len": S,
+            "forward_tflop": fwd / 1e12,
+            "model_tflops_3x_forward": 3 * fwd / dt / 1e12,
+            "frac_of_mfma_peak_3x_forward": 3 * fwd / dt / 1e12 / PEAK_BF16_TFLOPS,
+            "what": "train_denoiser.py stage-2 step: noisy tokens, MMDiT forward with one checkpoint per block, flow-matching "
+                    "loss + gradient, backward (block recompute + adjoints; weight gradients for the un-frozen subset only), "
+                    "global-norm clip + AdamW (ZeRO-2 layout); `model_tflops_3x_forward` prices the step at the conventional "
+                    "3 x forward FLOPs (the recompute and the 8-product attention backward are not credited)"}
+
+
 def timed_edits(pipe, inp, steps, warmup, world, device, backend):
     from gpt_image_edit_amd import dp
 
@@ -381,6 +431,12 @@ def main():
             extra["prompt_encode"] = pe
         except Exception as e:  # the extras must never cost the contract line
             extra["prompt_encode"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            torch.cuda.empty_cache()
+            extra["cfg5_train_step_1024x1024_bs1"] = train_step_bench(device)
+            torch.cuda.empty_cache()
+        except Exception as e:
+            extra["cfg5_train_step_1024x1024_bs1"] = {"error": f"{type(e).__name__}: {e}"}
     if extra:
         result["extra"] = extra
     if rank == 0 and world == 1 and args.cpu_baseline != "none":

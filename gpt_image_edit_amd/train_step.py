@@ -18,12 +18,25 @@ BF16 = torch.bfloat16
 
 
 class DenoiserTrainStep:
-    def __init__(self, model, lr=1e-6, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, trainable=None):
+    def __init__(self, model, lr=1e-6, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, trainable=None,
+                 sharded=False, group=None):
+        """sharded=True: the optimiser state lives in ``zero.ShardedAdamW`` (ZeRO-2: one flat bf16 parameter buffer the
+        model's trainable tensors become views of, fp32 gradients reduce-scattered over the data-parallel ranks, this
+        rank's slice of master + moments updated, parameters all-gathered); works unchanged with one process."""
         self.model = model
         self.bw = FluxBackward(model, trainable)
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.step_count = 0
         self.state = {}     # name -> (fp32 master, exp_avg, exp_avg_sq)
+        self.opt = None
+        if sharded:
+            from .zero import ShardedAdamW
+            names = sorted(self.bw.trainable)
+            self.opt = ShardedAdamW({k: model.p(k).data for k in names}, lr=lr, betas=betas, eps=eps,
+                                    weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group)
+            for k in names:
+                model.p(k).data = self.opt.params[k]     # the forward now reads views of the flat buffer
+            model._packed = None
 
     def _state(self, name):
         st = self.state.get(name)
@@ -65,6 +78,13 @@ class DenoiserTrainStep:
     def optimizer_step(self, grads):
         """Global-norm clipping + AdamW on fp32 masters; the bf16 parameters of the model are rewritten in the same pass."""
         names = sorted(grads)
+        if self.opt is not None:
+            for k in names:
+                self.opt.grads[k].copy_(grads[k])        # bf16 / fp32 -> the flat fp32 gradient buffer (a cast, no arithmetic)
+            norm = self.opt.step()
+            self.step_count = self.opt.step_count
+            self.bw.refresh()
+            return norm * norm
         sumsq = ops.sumsq([grads[k].contiguous() for k in names])
         self.step_count += 1
         for k in names:

@@ -240,7 +240,8 @@ class HipFluxTransformer2DModel(nn.Module):
         if not hidden_states.is_cuda:
             raise RuntimeError("HipFluxTransformer2DModel needs GPU tensors: there is no CPU fallback")
         if joint_attention_kwargs and joint_attention_kwargs.get("attention_mask") is not None:
-            raise NotImplementedError("attention_mask (multi-resolution training batches) is not supported")
+            raise NotImplementedError("attention_mask (padded multi-resolution training batches, train_denoiser.py:1086-1091) "
+                                      "is not supported: batch equally sized samples (cfg 5 trains bs 1 per GPU)")
         c, D, H = self.config, self.inner_dim, self.num_heads
         pk = self._packed or self.pack_weights()
         B, S_img, _ = hidden_states.shape
@@ -331,6 +332,10 @@ class HipFluxTransformer2DModel(nn.Module):
             return (sample,)
         return SimpleNamespace(sample=sample)
 
-    # reference training code calls this on the denoiser (train_denoiser.py:486); inference-only here
+    # The reference training code calls this on the denoiser (train_denoiser.py:486).  The training path of this
+    # package (backward.FluxBackward / train_step.DenoiserTrainStep) ALWAYS keeps one checkpoint per block and
+    # recomputes the block in the backward pass, so there is nothing to switch: the call is accepted and recorded.
+    gradient_checkpointing = True
+
     def enable_gradient_checkpointing(self):
-        raise NotImplementedError("training (cfg 5) is a later row of SURVEY.md section 8(f)")
+        self.gradient_checkpointing = True

@@ -78,3 +78,27 @@ def test_backward_matches_autograd_and_adamw_step():
     # and the model keeps running after the update (fused weight copies and transposes are refreshed)
     loss3, _, _ = ts.forward_backward(**dev_batch)
     assert torch.isfinite(loss3).all() and loss3.item() != loss.item()
+
+
+def test_sharded_optimizer_layout_gives_the_same_step():
+    """DenoiserTrainStep(sharded=True) -- parameters as views of one flat bf16 buffer, fp32 flat gradients, ZeRO-2 state
+    (zero.ShardedAdamW; one process here) -- must update the model exactly like the per-tensor path."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd.train_step import DenoiserTrainStep
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    cfg, sd_bf, batch, trainable = _setup(B=1, S_txt=40, h=8, w=12, seed=3)
+    dev_batch = {k: v.cuda() for k, v in batch.items()}
+    out = []
+    for sharded in (False, True):
+        model = HipFluxTransformer2DModel(cfg, device="cuda")
+        model.load_state_dict(sd_bf)
+        model.enable_gradient_checkpointing()          # accepted: the training path always checkpoints per block
+        ts = DenoiserTrainStep(model, lr=1e-3, sharded=sharded)
+        r1 = ts.step(**dev_batch)
+        r2 = ts.step(**dev_batch)                      # second step runs on the refreshed fused / transposed weights
+        out.append((r1["loss"].item(), r2["loss"].item(), {k: model.p(k).detach().clone() for k in trainable}))
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert out[0][1] != out[0][0]
+    for k in trainable:
+        assert torch.equal(out[0][2][k], out[1][2][k]), k
