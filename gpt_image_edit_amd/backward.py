@@ -4,7 +4,8 @@ Counterpart of what ``accelerator.backward(loss)`` (reference ``train_denoiser.p
 denoiser with ``enable_gradient_checkpointing()`` (``:486``): the forward keeps ONE tensor per block -- the residual
 stream entering it -- and the backward walks the blocks in reverse, re-running each block's forward with its pre-gate /
 pre-activation tensors stored (un-fused epilogues, same rounding points, hence the same values as the inference
-forward) and then its adjoint.  Gradients are produced for the parameters the reference un-freezes
+forward) and then its adjoint.  The attention output and its row statistics are kept as well, so the recomputation
+skips the attention kernel.  Gradients are produced for the parameters the reference un-freezes
 (``train_denoiser.py:70-119``, ``training.trainable_names``): in every double block the image-stream ``attn.to_q / to_k
 / to_v / to_out.0``, ``attn.norm_q / norm_k`` and ``norm1.linear``; in every single block ``attn.to_q / to_k / to_v``,
 ``attn.norm_q / norm_k`` and ``norm.linear`` -- plus the gradient w.r.t. ``encoder_hidden_states`` (for the
@@ -104,7 +105,12 @@ class FluxBackward:
                         ws.p_emb, ws.temb, ws.act, ws.mod)
         nblk = len(pk.double) + len(pk.single)
         ckpt = self._b("ckpt", (nblk + 1, B, S, D))
-        sv = SimpleNamespace(B=B, S=S, S_txt=S_txt, S_img=S_img, cos=cos, sin=sin, ckpt=ckpt, enc=enc, hs=hs, ws=ws, pk=pk)
+        # besides the block inputs, the attention output and its row statistics are kept (3 GB at 1024^2, bs 1): the
+        # recomputation then skips the one kernel that costs as much as the block's four linears together
+        o_ckpt = self._b("o_ckpt", (nblk, B, S, D))
+        lse_ckpt = self._b("lse_ckpt", (nblk, B, m.num_heads, S), torch.float32)
+        sv = SimpleNamespace(B=B, S=S, S_txt=S_txt, S_img=S_img, cos=cos, sin=sin, ckpt=ckpt, o_ckpt=o_ckpt, lse_ckpt=lse_ckpt,
+                             enc=enc, hs=hs, ws=ws, pk=pk, nd=len(pk.double))
         for i in range(len(pk.double)):
             ckpt[i].copy_(s)
             self._double_forward(i, sv, s, save=False)
@@ -137,13 +143,12 @@ class FluxBackward:
                           dict(a=n[:, txt], w=blk.wqkv_txt, bias=blk.bqkv_txt, out=ws.qkv[:, txt])])
         ops.qkv_post(ws.qkv, ws.q, ws.k, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"),
                      P(p + "attn.norm_added_q.weight"), P(p + "attn.norm_added_k.weight"), sv.cos, sv.sin, S_txt)
-        if save:
-            ops.attention_lse(ws.q, ws.k, ws.qkv[:, :, 2 * D:], ws.o, self._b("lse", (sv.B, H, sv.S), torch.float32))
-        else:
-            ops.attention(ws.q, ws.k, ws.qkv[:, :, 2 * D:], ws.o)
+        o = sv.o_ckpt[i]
+        if not save:   # the training forward computes and keeps it; the recomputation reads it back
+            ops.attention_lse(ws.q, ws.k, ws.qkv[:, :, 2 * D:], o, sv.lse_ckpt[i])
         y1 = self._b("y1", (sv.B, sv.S, D))
-        ops.gemm_grouped([dict(a=ws.o[:, img], w=P(p + "attn.to_out.0.weight"), bias=P(p + "attn.to_out.0.bias"), out=y1[:, img]),
-                          dict(a=ws.o[:, txt], w=P(p + "attn.to_add_out.weight"), bias=P(p + "attn.to_add_out.bias"), out=y1[:, txt])])
+        ops.gemm_grouped([dict(a=o[:, img], w=P(p + "attn.to_out.0.weight"), bias=P(p + "attn.to_out.0.bias"), out=y1[:, img]),
+                          dict(a=o[:, txt], w=P(p + "attn.to_add_out.weight"), bias=P(p + "attn.to_add_out.bias"), out=y1[:, txt])])
         x1 = self._b("x1", (sv.B, sv.S, D)) if save else s
         ops.gate_res_fwd(s[:, img], y1[:, img], ch(mi, 2), x1[:, img])
         ops.gate_res_fwd(s[:, txt], y1[:, txt], ch(mt, 2), x1[:, txt])
@@ -173,10 +178,10 @@ class FluxBackward:
         h1 = self._b("h1", (sv.B, sv.S, 4 * D))
         ops.gemm(n, P(p + "proj_mlp.weight"), P(p + "proj_mlp.bias"), out=h1)
         ops.gelu_tanh(h1, ws.cat[:, :, D:])
-        if save:
-            ops.attention_lse(ws.q, ws.k, ws.qkv[:, :, 2 * D:], ws.cat[:, :, :D], self._b("lse", (sv.B, H, sv.S), torch.float32))
-        else:
-            ops.attention(ws.q, ws.k, ws.qkv[:, :, 2 * D:], ws.cat[:, :, :D])
+        o = sv.o_ckpt[sv.nd + j]
+        if not save:
+            ops.attention_lse(ws.q, ws.k, ws.qkv[:, :, 2 * D:], o, sv.lse_ckpt[sv.nd + j])
+        ws.cat[:, :, :D].copy_(o)          # proj_out reads [attn | mlp] as one K = 5D operand
         y1 = self._b("y1", (sv.B, sv.S, D))
         ops.gemm(ws.cat, P(p + "proj_out.weight"), P(p + "proj_out.bias"), out=y1)
         ops.gate_res_fwd(s, y1, ch(2), s)
@@ -243,14 +248,15 @@ class FluxBackward:
         do = self._b("do", (B, S, D))
         ops.gemm_grouped([dict(a=dy[:, img], w=self.wT(p + "attn.to_out.0.weight"), out=do[:, img]),
                           dict(a=dy[:, txt], w=self.wT(p + "attn.to_add_out.weight"), out=do[:, txt])])
+        o, lse = sv.o_ckpt[i], sv.lse_ckpt[i]
         if p + "attn.to_out.0.weight" in self.trainable:
-            grads[p + "attn.to_out.0.weight"] = self._wgrad(dy[:, img], ws.o[:, img]).clone()
+            grads[p + "attn.to_out.0.weight"] = self._wgrad(dy[:, img], o[:, img]).clone()
             grads[p + "attn.to_out.0.bias"] = ops.colsum(dy[:, img])
         # -- joint attention
         dqkv = self._b("dqkv", (B, S, 3 * D))
         dq, dk = self._b("dq", (B, H, S, 128)), self._b("dk", (B, H, S, 128))
-        dsum = ops.rowdot(do, ws.o, H, out=self._b("dsum", (B, H, S), torch.float32))
-        ops.attention_bwd(ws.q, ws.k, ws.qkv[:, :, 2 * D:], do, self._buf["lse"], dsum, dq, dk, dqkv[:, :, 2 * D:])
+        dsum = ops.rowdot(do, o, H, out=self._b("dsum", (B, H, S), torch.float32))
+        ops.attention_bwd(ws.q, ws.k, ws.qkv[:, :, 2 * D:], do, lse, dsum, dq, dk, dqkv[:, :, 2 * D:])
         dw = ops.qkv_post_bwd(dq, dk, ws.qkv, dqkv, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"),
                               P(p + "attn.norm_added_q.weight"), P(p + "attn.norm_added_k.weight"), sv.cos, sv.sin, S_txt)
         grads[p + "attn.norm_q.weight"], grads[p + "attn.norm_k.weight"] = dw[0, 0].clone(), dw[1, 0].clone()
@@ -302,9 +308,9 @@ class FluxBackward:
         ops.gelu_bwd(h1, dff, out=dff)
         dqkv = self._b("dqkv", (B, S, 3 * D))
         dq, dk = self._b("dq", (B, H, S, 128)), self._b("dk", (B, H, S, 128))
-        o = ws.cat[:, :, :D]
+        o, lse = sv.o_ckpt[len(pk.double) + j], sv.lse_ckpt[len(pk.double) + j]
         dsum = ops.rowdot(do, o, H, out=self._b("dsum", (B, H, S), torch.float32))
-        ops.attention_bwd(ws.q, ws.k, ws.qkv[:, :, 2 * D:], do, self._buf["lse"], dsum, dq, dk, dqkv[:, :, 2 * D:])
+        ops.attention_bwd(ws.q, ws.k, ws.qkv[:, :, 2 * D:], do, lse, dsum, dq, dk, dqkv[:, :, 2 * D:])
         dw = ops.qkv_post_bwd(dq, dk, ws.qkv, dqkv, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"), None, None,
                               sv.cos, sv.sin, 0)
         grads[p + "attn.norm_q.weight"], grads[p + "attn.norm_k.weight"] = dw[0, 0].clone(), dw[1, 0].clone()

@@ -22,17 +22,26 @@ namespace {
 
 constexpr int HD = 128;
 
-// out[b * out_bs + c] (+)= sum over `nparts` partial rows of part[(b * nparts + p) * n + c]
+// out[b * out_bs + c] (+)= sum over `nparts` partial rows of part[(b * nparts + p) * n + c], in a fixed order:
+// block = 64 columns x 4 part-groups (group g sums parts g, g + 4, ...), then the four group sums in order.
 __global__ __launch_bounds__(256) void finalize_partials_kernel(const float* part, float* out, int64_t out_bs, int nparts,
                                                                 int n, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   const int b = blockIdx.y;
-  if (c >= n) return;
-  const float* p = part + ((int64_t)b * nparts) * n + c;
   float s = 0.f;
-  for (int i = 0; i < nparts; ++i) s += p[(int64_t)i * n];
-  float* o = out + (int64_t)b * out_bs + c;
-  *o = accumulate ? *o + s : s;
+  if (c < n) {
+    const float* p = part + ((int64_t)b * nparts) * n + c;
+    for (int i = grp; i < nparts; i += 4) s += p[(int64_t)i * n];
+  }
+  red[grp][cl] = s;
+  __syncthreads();
+  if (grp == 0 && c < n) {
+    const float t = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+    float* o = out + (int64_t)b * out_bs + c;
+    *o = accumulate ? *o + t : t;
+  }
 }
 
 // ---- LN + modulate backward ----------------------------------------------------------------------------------------
@@ -43,6 +52,7 @@ __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(const bf16_t* x, f
                                                               fk_rows dxi, bf16_t* dx_out, fk_rows dxo, float* part,
                                                               int64_t rpb, float eps) {
   constexpr int D = NV * 512;
+  __shared__ float red[2 * D];   // the workgroup's column partials (dshift | dscale), waves added one after the other
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int chunk = blockIdx.x, nchunks = gridDim.x, b = blockIdx.y;
   float gsc[NV][8];
@@ -138,15 +148,23 @@ __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(const bf16_t* x, f
       *(u32x4_t*)(op + i * 512) = ow;
     }
   }
-  // column partials: one row per wave, [b][chunk * 4 + wave][2][D]; the finalising kernel sums them in fixed order
-  float* po = part + (((int64_t)b * nchunks + chunk) * 4 + wave) * (2 * D) + lane * 8;
+  // column partials of the workgroup: the four waves accumulate into LDS in wave order (fixed order -> deterministic),
+  // every lane touching only its own columns; one row [2][D] per workgroup goes to the workspace
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    *(f32x4_t*)(po + i * 512) = f32x4_t{a_sh[i][0], a_sh[i][1], a_sh[i][2], a_sh[i][3]};
-    *(f32x4_t*)(po + i * 512 + 4) = f32x4_t{a_sh[i][4], a_sh[i][5], a_sh[i][6], a_sh[i][7]};
-    *(f32x4_t*)(po + D + i * 512) = f32x4_t{a_sc[i][0], a_sc[i][1], a_sc[i][2], a_sc[i][3]};
-    *(f32x4_t*)(po + D + i * 512 + 4) = f32x4_t{a_sc[i][4], a_sc[i][5], a_sc[i][6], a_sc[i][7]};
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = i * 512 + lane * 8 + e;
+          red[c] = wv == 0 ? a_sh[i][e] : red[c] + a_sh[i][e];
+          red[D + c] = wv == 0 ? a_sc[i][e] : red[D + c] + a_sc[i][e];
+        }
+    }
+    __syncthreads();
   }
+  float* po = part + ((int64_t)b * nchunks + chunk) * (2 * D);
+  for (int c = threadIdx.x * 4; c < 2 * D; c += 256 * 4) *(f32x4_t*)(po + c) = *(const f32x4_t*)(red + c);
 }
 
 // ---- gate * y + residual backward ----------------------------------------------------------------------------------
@@ -392,9 +410,9 @@ __global__ __launch_bounds__(256) void f32_to_bf16_t_kernel(const float* src, in
   dst[i] = r < R ? f2bf(src[(int64_t)r * src_ld + c]) : (bf16_t)0;
 }
 
-int pick_chunks(int64_t rows, int per_iter) {
+int pick_chunks(int64_t rows, int per_iter, int max_chunks = 64) {
   int64_t c = (rows + per_iter - 1) / per_iter;
-  if (c > 64) c = 64;
+  if (c > max_chunks) c = max_chunks;
   if (c < 1) c = 1;
   return (int)c;
 }
@@ -416,9 +434,9 @@ extern "C" int fk_ln_modulate_bwd_bf16(const void* x, fk_rows xr, const void* dn
   FK_CHECK_ARG(xr.ld % 8 == 0 && dnr.ld % 8 == 0 && dxo.ld % 8 == 0 && mod_batch_stride % 8 == 0 && (!dx_in || dxi.ld % 8 == 0),
                "fk_ln_modulate_bwd_bf16: strides must be multiples of 8 elements");
   hipStream_t stream = (hipStream_t)stream_;
-  int chunks = pick_chunks(rows_per_batch, 4 * 16);
-  while (chunks > 1 && (int64_t)B * chunks * 4 * 2 * D > fk_bwd_ws_floats()) chunks /= 2;
-  FK_CHECK_ARG((int64_t)B * chunks * 4 * 2 * D <= fk_bwd_ws_floats(), "fk_ln_modulate_bwd_bf16: workspace too small");
+  int chunks = pick_chunks(rows_per_batch, 4 * 4, 512);
+  while (chunks > 1 && (int64_t)B * chunks * 2 * D > fk_bwd_ws_floats()) chunks /= 2;
+  FK_CHECK_ARG((int64_t)B * chunks * 2 * D <= fk_bwd_ws_floats(), "fk_ln_modulate_bwd_bf16: workspace too small");
   const dim3 grid(chunks, B), block(256);
 #define FK_LNB_CASE(NV)                                                                                                   \
   case NV * 512:                                                                                                          \
@@ -436,10 +454,10 @@ extern "C" int fk_ln_modulate_bwd_bf16(const void* x, fk_rows xr, const void* dn
 #undef FK_LNB_CASE
   FK_CHECK_LAUNCH("fk_ln_modulate_bwd_bf16");
   // partial rows are [b][chunk][2][D]: dshift = first D of each, dscale = second D
-  const dim3 fgrid((2 * D + 255) / 256, B);
+  const dim3 fgrid((2 * D + 63) / 64, B);
   // one pass writes both: treat the 2D-wide row as one vector when dscale follows dshift at +D ...
   if (dscale == dshift + D) {
-    hipLaunchKernelGGL(finalize_partials_kernel, fgrid, block, 0, stream, ws, dshift, dmod_batch_stride, chunks * 4, 2 * D, 0);
+    hipLaunchKernelGGL(finalize_partials_kernel, fgrid, block, 0, stream, ws, dshift, dmod_batch_stride, chunks, 2 * D, 0);
   } else {
     fk_set_error("fk_ln_modulate_bwd_bf16: dscale must be dshift + D (the (shift, scale) chunk pair of the modulation vector)");
     return FK_EINVAL;
@@ -457,12 +475,13 @@ extern "C" int fk_gate_res_bwd_bf16(const void* dout, fk_rows dor, const void* y
                    yr.ld % 8 == 0 && dyr.ld % 8 == 0 && gate_batch_stride % 8 == 0,
                "fk_gate_res_bwd_bf16: 16-byte alignment");
   hipStream_t stream = (hipStream_t)stream_;
-  const int chunks = pick_chunks(rows_per_batch, 16);
+  int chunks = pick_chunks(rows_per_batch, 16, 256);
+  while (chunks > 1 && (int64_t)B * chunks * N > fk_bwd_ws_floats()) chunks /= 2;
   FK_CHECK_ARG((int64_t)B * chunks * N <= fk_bwd_ws_floats(), "fk_gate_res_bwd_bf16: workspace too small");
   hipLaunchKernelGGL(gate_res_bwd_kernel, dim3(chunks, B, (N + 2047) / 2048), dim3(256), 0, stream, (const bf16_t*)dout, dor,
                      (const bf16_t*)y, yr, (const bf16_t*)gate, gate_batch_stride, (bf16_t*)dy, dyr, ws, rows_per_batch, N);
   FK_CHECK_LAUNCH("fk_gate_res_bwd_bf16");
-  hipLaunchKernelGGL(finalize_partials_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, ws, dgate, dgate_batch_stride,
+  hipLaunchKernelGGL(finalize_partials_kernel, dim3((N + 63) / 64, B), dim3(256), 0, stream, ws, dgate, dgate_batch_stride,
                      chunks, N, 0);
   FK_CHECK_LAUNCH("fk_gate_res_bwd_bf16 (finalize)");
   return FK_OK;
@@ -496,7 +515,7 @@ extern "C" int fk_qkv_post_bwd_bf16(const void* dq, const void* dk, const void* 
                      cos, sin, ws, B, S, S_txt, H, eps);
   FK_CHECK_LAUNCH("fk_qkv_post_bwd_bf16");
   // dw: [which 2][stream 2 (0 = image, 1 = text)][128]
-  hipLaunchKernelGGL(finalize_partials_kernel, dim3(2, 1), dim3(256), 0, stream, ws, dw, 0, nblk, 4 * HD, 0);
+  hipLaunchKernelGGL(finalize_partials_kernel, dim3(4 * HD / 64, 1), dim3(256), 0, stream, ws, dw, 0, nblk, 4 * HD, 0);
   FK_CHECK_LAUNCH("fk_qkv_post_bwd_bf16 (finalize)");
   return FK_OK;
 }
@@ -539,12 +558,13 @@ extern "C" int fk_f32_to_bf16_transposed(const float* src, int64_t src_ld, void*
 extern "C" int fk_colsum_bf16(const void* x, fk_rows xr, int64_t M, int32_t N, float* out, float* ws, fk_stream_t stream_) {
   FK_CHECK_ARG(x && out && ws && M > 0 && N > 0 && N % 8 == 0, "fk_colsum_bf16: bad arguments");
   FK_CHECK_ARG(FK_ALIGNED16(x) && xr.ld % 8 == 0, "fk_colsum_bf16: 16-byte alignment");
-  const int chunks = pick_chunks(M, 32);
+  int chunks = pick_chunks(M, 32, 256);
+  while (chunks > 1 && (int64_t)chunks * N > fk_bwd_ws_floats()) chunks /= 2;
   FK_CHECK_ARG((int64_t)chunks * N <= fk_bwd_ws_floats(), "fk_colsum_bf16: workspace too small");
   hipStream_t stream = (hipStream_t)stream_;
   hipLaunchKernelGGL(colsum_kernel, dim3(chunks, 1, (N + 2047) / 2048), dim3(256), 0, stream, (const bf16_t*)x, xr, ws, M, N);
   FK_CHECK_LAUNCH("fk_colsum_bf16");
-  hipLaunchKernelGGL(finalize_partials_kernel, dim3((N + 255) / 256, 1), dim3(256), 0, stream, ws, out, 0, chunks, N, 0);
+  hipLaunchKernelGGL(finalize_partials_kernel, dim3((N + 63) / 64, 1), dim3(256), 0, stream, ws, out, 0, chunks, N, 0);
   FK_CHECK_LAUNCH("fk_colsum_bf16 (finalize)");
   return FK_OK;
 }
