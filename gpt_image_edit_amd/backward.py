@@ -1,10 +1,12 @@
 """MMDiT training forward + backward on the HIP kernels.
 
 Counterpart of what ``accelerator.backward(loss)`` (reference ``train_denoiser.py:1172``) does to the FLUX-Kontext
-denoiser with ``enable_gradient_checkpointing()`` (``:486``): the forward keeps ONE tensor per block -- the residual
-stream entering it -- and the backward walks the blocks in reverse, re-running each block's forward with its pre-gate /
-pre-activation tensors stored (un-fused epilogues, same rounding points, hence the same values as the inference
-forward) and then its adjoint.  The attention output and its row statistics are kept as well, so the recomputation
+denoiser.  Two activation policies: (a) the reference's ``enable_gradient_checkpointing()`` (``:486``, forced by 80 GB
+GPUs): the forward keeps ONE tensor per block -- the residual stream entering it -- and the backward walks the blocks in
+reverse, re-running each block's forward with its pre-gate / pre-activation tensors stored (un-fused epilogues, same
+rounding points, hence the same values as the inference forward) and then its adjoint; (b) with 288 GB of HBM the
+forward simply keeps every block's intermediates (37 GB at 1024^2, batch 1) and nothing is recomputed -- the default
+whenever it fits.  The attention output and its row statistics are kept as well, so the recomputation
 skips the attention kernel.  Gradients are produced for the parameters the reference un-freezes
 (``train_denoiser.py:70-119``, ``training.trainable_names``): in every double block the image-stream ``attn.to_q / to_k
 / to_v / to_out.0``, ``attn.norm_q / norm_k`` and ``norm1.linear``; in every single block ``attn.to_q / to_k / to_v``,
@@ -38,8 +40,12 @@ def _pad64(n):
 class FluxBackward:
     """Training forward / backward around a ``HipFluxTransformer2DModel`` (which keeps owning the parameters)."""
 
-    def __init__(self, model, trainable=None):
+    def __init__(self, model, trainable=None, store_activations="auto", activation_budget_bytes=96 << 30):
+        """store_activations: True = keep every block's intermediates from the forward (no recomputation: 37 GB at
+        1024^2, bs 1 -- sized for 288 GB of HBM, where the reference's 80 GB GPUs force checkpointing); False = one
+        checkpoint per block + recomputation in the backward; "auto" = store when it fits ``activation_budget_bytes``."""
         from . import training
+        self.store_activations, self.activation_budget = store_activations, activation_budget_bytes
         self.m = model
         names = list(model.state_dict().keys())
         self.trainable = set(trainable if trainable is not None else training.trainable_names(names))
@@ -73,6 +79,33 @@ class FluxBackward:
             t = (torch.zeros if zero else torch.empty)(shape, device=self.m.device, dtype=dtype)
             self._buf[name] = t
         return t
+
+    def _block_bufs(self, sv, idx, double):
+        """Where block ``idx`` keeps what its backward reads: per-block tensors when activations are stored, the shared
+        workspace (overwritten by every block, refilled by the recomputation) otherwise."""
+        ws, D, H, B, S = sv.ws, self.m.inner_dim, self.m.num_heads, sv.B, sv.S
+        if not sv.store:
+            t = lambda name, *shape: self._b(name, shape)  # noqa: E731
+            nb = SimpleNamespace(n=ws.n, qkv=ws.qkv, q=ws.q, k=ws.k, y1=t("y1", B, S, D), h1=t("h1", B, S, 4 * D))
+            if double:
+                nb.x1, nb.n2, nb.y2 = t("x1", B, S, D), t("n2", B, S, D), t("y2", B, S, D)
+            return nb
+        key = f"blk{idx}"
+        nb = self._buf.get(key)
+        if nb is None or nb.shape != (B, S):
+            e = lambda *shape: torch.empty(shape, device=self.m.device, dtype=BF16)  # noqa: E731
+            nb = SimpleNamespace(shape=(B, S), n=e(B, S, D), qkv=e(B, S, 3 * D), q=e(B, H, S, 128), k=e(B, H, S, 128),
+                                 y1=e(B, S, D), h1=e(B, S, 4 * D))
+            if double:
+                nb.x1, nb.n2, nb.y2 = e(B, S, D), e(B, S, D), e(B, S, D)
+            self._buf[key] = nb
+        return nb
+
+    def _should_store(self, B, S, nd, ns):
+        if self.store_activations != "auto":
+            return bool(self.store_activations)
+        unit = B * S * self.m.inner_dim * 2
+        return (nd * 14 + ns * 11) * unit <= self.activation_budget
 
     # ---- weight gradient: dW[N, K] = dY^T X over the rows of two [B, R, *] views ---------------------------------------
     def _wgrad(self, dy, x, out=None):
@@ -110,13 +143,14 @@ class FluxBackward:
         o_ckpt = self._b("o_ckpt", (nblk, B, S, D))
         lse_ckpt = self._b("lse_ckpt", (nblk, B, m.num_heads, S), torch.float32)
         sv = SimpleNamespace(B=B, S=S, S_txt=S_txt, S_img=S_img, cos=cos, sin=sin, ckpt=ckpt, o_ckpt=o_ckpt, lse_ckpt=lse_ckpt,
-                             enc=enc, hs=hs, ws=ws, pk=pk, nd=len(pk.double))
+                             enc=enc, hs=hs, ws=ws, pk=pk, nd=len(pk.double),
+                             store=self._should_store(B, S, len(pk.double), len(pk.single)))
         for i in range(len(pk.double)):
             ckpt[i].copy_(s)
-            self._double_forward(i, sv, s, save=False)
+            self._double_forward(i, sv, s, save=sv.store, first=True)
         for j in range(len(pk.single)):
             ckpt[len(pk.double) + j].copy_(s)
-            self._single_forward(j, sv, s, save=False)
+            self._single_forward(j, sv, s, save=sv.store, first=True)
         ckpt[nblk].copy_(s)
         mod = ws.mod
         n_img = ws.n[:, S_txt:]
@@ -128,61 +162,64 @@ class FluxBackward:
         D = self.m.inner_dim
         return sv.ws.mod[:, off + j * D: off + (j + 1) * D]
 
-    def _double_forward(self, i, sv, s, save):
-        """One FluxTransformerBlock on the joint buffer ``s`` (in place).  save=True: the un-fused form that leaves
-        n1, raw qkv, q, k, o, lse, y1 (pre-gate), x1, n2, h1 (pre-GELU), f, y2 in the buffers the backward reads."""
+    def _double_forward(self, i, sv, s, save, first=False):
+        """One FluxTransformerBlock on the joint buffer ``s`` (in place), un-fused epilogues.  save=True leaves n1, raw
+        qkv, q, k, y1 (pre-gate), x1, n2, h1 (pre-GELU), y2 in the block's buffers for the backward; ``first`` = the
+        training forward (computes and keeps the attention output; the recomputation reads it back)."""
         m, P, ws, pk = self.m, self.m.p, sv.ws, sv.pk
         D, H, S_txt = m.inner_dim, m.num_heads, sv.S_txt
         blk, p = pk.double[i], f"transformer_blocks.{i}."
         mi, mt = blk.mod_img, blk.mod_txt
         ch = lambda off, j: self._chunk(sv, off, j)  # noqa: E731
-        n = ws.n
+        bb = self._block_bufs(sv, i, True)
+        n, qkv = bb.n, bb.qkv
         img, txt = slice(S_txt, None), slice(0, S_txt)
         ops.ln_modulate2(s, ch(mt, 0), ch(mt, 1), ch(mi, 0), ch(mi, 1), S_txt, out=n)
-        ops.gemm_grouped([dict(a=n[:, img], w=blk.wqkv_img, bias=blk.bqkv_img, out=ws.qkv[:, img]),
-                          dict(a=n[:, txt], w=blk.wqkv_txt, bias=blk.bqkv_txt, out=ws.qkv[:, txt])])
-        ops.qkv_post(ws.qkv, ws.q, ws.k, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"),
+        ops.gemm_grouped([dict(a=n[:, img], w=blk.wqkv_img, bias=blk.bqkv_img, out=qkv[:, img]),
+                          dict(a=n[:, txt], w=blk.wqkv_txt, bias=blk.bqkv_txt, out=qkv[:, txt])])
+        ops.qkv_post(qkv, bb.q, bb.k, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"),
                      P(p + "attn.norm_added_q.weight"), P(p + "attn.norm_added_k.weight"), sv.cos, sv.sin, S_txt)
         o = sv.o_ckpt[i]
-        if not save:   # the training forward computes and keeps it; the recomputation reads it back
-            ops.attention_lse(ws.q, ws.k, ws.qkv[:, :, 2 * D:], o, sv.lse_ckpt[i])
-        y1 = self._b("y1", (sv.B, sv.S, D))
+        if first:
+            ops.attention_lse(bb.q, bb.k, qkv[:, :, 2 * D:], o, sv.lse_ckpt[i])
+        y1 = bb.y1
         ops.gemm_grouped([dict(a=o[:, img], w=P(p + "attn.to_out.0.weight"), bias=P(p + "attn.to_out.0.bias"), out=y1[:, img]),
                           dict(a=o[:, txt], w=P(p + "attn.to_add_out.weight"), bias=P(p + "attn.to_add_out.bias"), out=y1[:, txt])])
-        x1 = self._b("x1", (sv.B, sv.S, D)) if save else s
+        x1 = bb.x1 if save else s
         ops.gate_res_fwd(s[:, img], y1[:, img], ch(mi, 2), x1[:, img])
         ops.gate_res_fwd(s[:, txt], y1[:, txt], ch(mt, 2), x1[:, txt])
-        n2 = self._b("n2", (sv.B, sv.S, D))
+        n2 = bb.n2
         ops.ln_modulate2(x1, ch(mt, 3), ch(mt, 4), ch(mi, 3), ch(mi, 4), S_txt, out=n2)
-        h1 = self._b("h1", (sv.B, sv.S, 4 * D))
+        h1 = bb.h1
         ops.gemm_grouped([dict(a=n2[:, img], w=P(p + "ff.net.0.proj.weight"), bias=P(p + "ff.net.0.proj.bias"), out=h1[:, img]),
                           dict(a=n2[:, txt], w=P(p + "ff_context.net.0.proj.weight"), bias=P(p + "ff_context.net.0.proj.bias"),
                                out=h1[:, txt])])
         ops.gelu_tanh(h1, ws.ff)
-        y2 = self._b("y2", (sv.B, sv.S, D))
+        y2 = bb.y2
         ops.gemm_grouped([dict(a=ws.ff[:, img], w=P(p + "ff.net.2.weight"), bias=P(p + "ff.net.2.bias"), out=y2[:, img]),
                           dict(a=ws.ff[:, txt], w=P(p + "ff_context.net.2.weight"), bias=P(p + "ff_context.net.2.bias"),
                                out=y2[:, txt])])
         ops.gate_res_fwd(x1[:, img], y2[:, img], ch(mi, 5), s[:, img])
         ops.gate_res_fwd(x1[:, txt], y2[:, txt], ch(mt, 5), s[:, txt])
 
-    def _single_forward(self, j, sv, s, save):
+    def _single_forward(self, j, sv, s, save, first=False):
         m, P, ws, pk = self.m, self.m.p, sv.ws, sv.pk
         D, H = m.inner_dim, m.num_heads
         blk, p = pk.single[j], f"single_transformer_blocks.{j}."
         ch = lambda k: self._chunk(sv, blk.mod, k)  # noqa: E731
-        n = ws.n
+        bb = self._block_bufs(sv, sv.nd + j, False)
+        n, qkv = bb.n, bb.qkv
         ops.ln_modulate(s, ch(0), ch(1), out=n)
-        ops.gemm(n, blk.wqkv, blk.bqkv, out=ws.qkv)
-        ops.qkv_post(ws.qkv, ws.q, ws.k, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"), None, None, sv.cos, sv.sin, 0)
-        h1 = self._b("h1", (sv.B, sv.S, 4 * D))
+        ops.gemm(n, blk.wqkv, blk.bqkv, out=qkv)
+        ops.qkv_post(qkv, bb.q, bb.k, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"), None, None, sv.cos, sv.sin, 0)
+        h1 = bb.h1
         ops.gemm(n, P(p + "proj_mlp.weight"), P(p + "proj_mlp.bias"), out=h1)
         ops.gelu_tanh(h1, ws.cat[:, :, D:])
         o = sv.o_ckpt[sv.nd + j]
-        if not save:
-            ops.attention_lse(ws.q, ws.k, ws.qkv[:, :, 2 * D:], o, sv.lse_ckpt[sv.nd + j])
+        if first:
+            ops.attention_lse(bb.q, bb.k, qkv[:, :, 2 * D:], o, sv.lse_ckpt[sv.nd + j])
         ws.cat[:, :, :D].copy_(o)          # proj_out reads [attn | mlp] as one K = 5D operand
-        y1 = self._b("y1", (sv.B, sv.S, D))
+        y1 = bb.y1
         ops.gemm(ws.cat, P(p + "proj_out.weight"), P(p + "proj_out.bias"), out=y1)
         ops.gate_res_fwd(s, y1, ch(2), s)
 
@@ -208,12 +245,14 @@ class FluxBackward:
         ops.ln_modulate_bwd(sv.ckpt[nd + ns][:, S_txt:], dn[:, S_txt:], mod[:, pk.mod_out: pk.mod_out + D], g[:, S_txt:], dmod_out)
         s = ws.s
         for j in reversed(range(ns)):
-            s.copy_(sv.ckpt[nd + j])
-            self._single_forward(j, sv, s, save=True)
+            if not sv.store:
+                s.copy_(sv.ckpt[nd + j])
+                self._single_forward(j, sv, s, save=True)
             self._single_backward(j, sv, g, grads)
         for i in reversed(range(nd)):
-            s.copy_(sv.ckpt[i])
-            self._double_forward(i, sv, s, save=True)
+            if not sv.store:
+                s.copy_(sv.ckpt[i])
+                self._double_forward(i, sv, s, save=True)
             self._double_backward(i, sv, g, grads)
         d_enc = ops.gemm(g[:, :S_txt], self.wT("context_embedder.weight"))
         self._saved = None
@@ -226,7 +265,8 @@ class FluxBackward:
         mi, mt = blk.mod_img, blk.mod_txt
         ch = lambda off, j: self._chunk(sv, off, j)  # noqa: E731
         img, txt = slice(S_txt, None), slice(0, S_txt)
-        x0, x1, y1, y2, n1, n2, h1 = sv.ckpt[i], self._buf["x1"], self._buf["y1"], self._buf["y2"], ws.n, self._buf["n2"], self._buf["h1"]
+        bb = self._block_bufs(sv, i, True)
+        x0, x1, y1, y2, n1, n2, h1 = sv.ckpt[i], bb.x1, bb.y1, bb.y2, bb.n, bb.n2, bb.h1
         dmod = self._b("dmod_d", (B, 12 * D), torch.float32, zero=True)     # [image 6D | text 6D], chunk order of the block
         dm_i, dm_t = dmod[:, :6 * D], dmod[:, 6 * D:]
         dy = self._b("dy", (B, S, D))
@@ -256,8 +296,8 @@ class FluxBackward:
         dqkv = self._b("dqkv", (B, S, 3 * D))
         dq, dk = self._b("dq", (B, H, S, 128)), self._b("dk", (B, H, S, 128))
         dsum = ops.rowdot(do, o, H, out=self._b("dsum", (B, H, S), torch.float32))
-        ops.attention_bwd(ws.q, ws.k, ws.qkv[:, :, 2 * D:], do, lse, dsum, dq, dk, dqkv[:, :, 2 * D:])
-        dw = ops.qkv_post_bwd(dq, dk, ws.qkv, dqkv, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"),
+        ops.attention_bwd(bb.q, bb.k, bb.qkv[:, :, 2 * D:], do, lse, dsum, dq, dk, dqkv[:, :, 2 * D:])
+        dw = ops.qkv_post_bwd(dq, dk, bb.qkv, dqkv, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"),
                               P(p + "attn.norm_added_q.weight"), P(p + "attn.norm_added_k.weight"), sv.cos, sv.sin, S_txt)
         grads[p + "attn.norm_q.weight"], grads[p + "attn.norm_k.weight"] = dw[0, 0].clone(), dw[1, 0].clone()
         grads[p + "attn.norm_added_q.weight"], grads[p + "attn.norm_added_k.weight"] = dw[0, 1].clone(), dw[1, 1].clone()
@@ -294,7 +334,8 @@ class FluxBackward:
         D, H, B, S = m.inner_dim, m.num_heads, sv.B, sv.S
         blk, p = pk.single[j], f"single_transformer_blocks.{j}."
         ch = lambda k: self._chunk(sv, blk.mod, k)  # noqa: E731
-        x0, y1, n1, h1 = sv.ckpt[len(pk.double) + j], self._buf["y1"], ws.n, self._buf["h1"]
+        bb = self._block_bufs(sv, len(pk.double) + j, False)
+        x0, y1, n1, h1 = sv.ckpt[len(pk.double) + j], bb.y1, bb.n, bb.h1
         dmod = self._b("dmod_s", (B, 3 * D), torch.float32, zero=True)
         dy = self._b("dy", (B, S, D))
         do = self._b("do", (B, S, D))
@@ -310,8 +351,8 @@ class FluxBackward:
         dq, dk = self._b("dq", (B, H, S, 128)), self._b("dk", (B, H, S, 128))
         o, lse = sv.o_ckpt[len(pk.double) + j], sv.lse_ckpt[len(pk.double) + j]
         dsum = ops.rowdot(do, o, H, out=self._b("dsum", (B, H, S), torch.float32))
-        ops.attention_bwd(ws.q, ws.k, ws.qkv[:, :, 2 * D:], do, lse, dsum, dq, dk, dqkv[:, :, 2 * D:])
-        dw = ops.qkv_post_bwd(dq, dk, ws.qkv, dqkv, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"), None, None,
+        ops.attention_bwd(bb.q, bb.k, bb.qkv[:, :, 2 * D:], do, lse, dsum, dq, dk, dqkv[:, :, 2 * D:])
+        dw = ops.qkv_post_bwd(dq, dk, bb.qkv, dqkv, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"), None, None,
                               sv.cos, sv.sin, 0)
         grads[p + "attn.norm_q.weight"], grads[p + "attn.norm_k.weight"] = dw[0, 0].clone(), dw[1, 0].clone()
         ops.gemm(dqkv, self._transposed("packed:" + p + "qkv", blk.wqkv), out=dn)
@@ -326,6 +367,9 @@ class FluxBackward:
             grads[p + "proj_mlp.weight"] = self._wgrad(dff, n1).clone()
             grads[p + "proj_mlp.bias"] = ops.colsum(dff)
         if p + "proj_out.weight" in self.trainable:
+            if sv.store:   # cat is shared scratch: rebuild [attn | gelu(mlp)] of this block
+                ws.cat[:, :, :D].copy_(o)
+                ops.gelu_tanh(h1, ws.cat[:, :, D:])
             grads[p + "proj_out.weight"] = self._wgrad(dy, ws.cat).clone()
             grads[p + "proj_out.bias"] = ops.colsum(dy)
         ops.ln_modulate_bwd(x0, dn, ch(1), g, dmod[:, 0:2 * D], dx_in=g)

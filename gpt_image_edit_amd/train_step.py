@@ -19,12 +19,12 @@ BF16 = torch.bfloat16
 
 class DenoiserTrainStep:
     def __init__(self, model, lr=1e-6, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, trainable=None,
-                 sharded=False, group=None):
+                 sharded=False, group=None, store_activations="auto"):
         """sharded=True: the optimiser state lives in ``zero.ShardedAdamW`` (ZeRO-2: one flat bf16 parameter buffer the
         model's trainable tensors become views of, fp32 gradients reduce-scattered over the data-parallel ranks, this
         rank's slice of master + moments updated, parameters all-gathered); works unchanged with one process."""
         self.model = model
-        self.bw = FluxBackward(model, trainable)
+        self.bw = FluxBackward(model, trainable, store_activations=store_activations)
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.step_count = 0
         self.state = {}     # name -> (fp32 master, exp_avg, exp_avg_sq)

@@ -90,11 +90,12 @@ def test_sharded_optimizer_layout_gives_the_same_step():
     cfg, sd_bf, batch, trainable = _setup(B=1, S_txt=40, h=8, w=12, seed=3)
     dev_batch = {k: v.cuda() for k, v in batch.items()}
     out = []
-    for sharded in (False, True):
+    # also: activations stored (no recomputation) vs one checkpoint per block + recomputation -- same values either way
+    for sharded, store in ((False, False), (True, True)):
         model = HipFluxTransformer2DModel(cfg, device="cuda")
         model.load_state_dict(sd_bf)
-        model.enable_gradient_checkpointing()          # accepted: the training path always checkpoints per block
-        ts = DenoiserTrainStep(model, lr=1e-3, sharded=sharded)
+        model.enable_gradient_checkpointing()          # accepted (train_denoiser.py:486)
+        ts = DenoiserTrainStep(model, lr=1e-3, sharded=sharded, store_activations=store)
         r1 = ts.step(**dev_batch)
         r2 = ts.step(**dev_batch)                      # second step runs on the refreshed fused / transposed weights
         out.append((r1["loss"].item(), r2["loss"].item(), {k: model.p(k).detach().clone() for k in trainable}))
