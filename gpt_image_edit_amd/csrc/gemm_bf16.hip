@@ -303,14 +303,19 @@ static int validate_gemm(const fk_gemm_args& p) {
   }
   FK_CHECK_ARG(p.epilogue >= FK_EPI_NONE && p.epilogue <= FK_EPI_QKV, "fk_gemm_bf16: unknown epilogue %d", p.epilogue);
   if (p.epilogue == FK_EPI_QKV) {
-    FK_CHECK_ARG(!p.out_fp32 && p.q_out && p.k_out && p.wq && p.wk && p.rope_cos && p.rope_sin,
-                 "fk_gemm_bf16: FK_EPI_QKV needs q_out/k_out/wq/wk/rope tables");
+    FK_CHECK_ARG(!p.out_fp32 && p.q_out && p.k_out && p.wq && p.wk && p.rope_cs,
+                 "fk_gemm_bf16: FK_EPI_QKV needs q_out/k_out/wq/wk/rope_cs");
     // N = 3*H*128: q | k | v columns; N = 2*H*128: the q | k columns only (the v columns as a plain GEMM of their own)
     FK_CHECK_ARG(p.qkv_heads > 0 && (p.N == 3 * p.qkv_heads * 128 || p.N == 2 * p.qkv_heads * 128) && p.qkv_s_total > 0 &&
                      p.qkv_s_offset >= 0,
                  "fk_gemm_bf16: FK_EPI_QKV needs N = 3*H*128 (q | k | v) or 2*H*128 (q | k)");
+    {
+      const int64_t nb = p.c.rows_per_batch > 0 ? (p.M + p.c.rows_per_batch - 1) / p.c.rows_per_batch : 1;
+      FK_CHECK_ARG(nb * p.qkv_heads * p.qkv_s_total < (int64_t)1 << 31,
+                   "fk_gemm_bf16: FK_EPI_QKV head-major outputs are limited to 2^31 rows");
+    }
     FK_CHECK_ARG(((uintptr_t)p.q_out % 16 == 0) && ((uintptr_t)p.k_out % 16 == 0) && ((uintptr_t)p.wq % 16 == 0) &&
-                     ((uintptr_t)p.wk % 16 == 0) && ((uintptr_t)p.rope_cos % 16 == 0) && ((uintptr_t)p.rope_sin % 16 == 0),
+                     ((uintptr_t)p.wk % 16 == 0) && ((uintptr_t)p.rope_cs % 16 == 0),
                  "fk_gemm_bf16: FK_EPI_QKV pointers must be 16-byte aligned");
   }
   return FK_OK;

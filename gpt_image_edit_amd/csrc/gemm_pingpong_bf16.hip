@@ -106,6 +106,21 @@ struct TileRows {
   FK_DEV int off(int ml) const { return ml * ld + crossed(ml) * wrap; }
 };
 
+// sum over the 16 lanes of a DPP row, every lane receiving the total: four row-rotate adds on the VALU (no LDS
+// round trips).  Bit-identical to the xor butterfly 8, 4, 2, 1: after the step of distance d the partial sums have
+// period d within the row, so "rotate by d" and "xor d" name the same partner value.
+template <int N>
+FK_DEV float row_ror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+FK_DEV float row16_sum(float v) {
+  v += row_ror<8>(v);
+  v += row_ror<4>(v);
+  v += row_ror<2>(v);
+  v += row_ror<1>(v);
+  return v;
+}
+
 // tile selection: XCD chunking over the whole grid, then problem, then grouped (GROUP_M deep) order
 template <int BN>
 FK_DEV void select_tile(const GroupArgs& ga, int& pi, int& m0, int& n0) {
@@ -231,7 +246,7 @@ FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& 
 #pragma unroll
     for (int j0 = 0; j0 < ITERS; j0 += U) {
       u32x4_t y[U];
-      f32x4_t c0[U], c1[U], s0[U], s1[U];
+      f32x4_t t0[U], t1[U];   // (cos, sin) of the chunk's four rotary pairs
       int srow[U], bidx[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -242,10 +257,9 @@ FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& 
         const int nb = crow.crossed(mlc);
         bidx[u] = crow.b0 + nb;
         srow[u] = p.qkv_s_offset + crow.r0 + mlc - nb * crow.rpb;
-        const float* cp = p.rope_cos + (int64_t)srow[u] * 128 + dch;
-        const float* sp = p.rope_sin + (int64_t)srow[u] * 128 + dch;
-        c0[u] = *(const f32x4_t*)cp; c1[u] = *(const f32x4_t*)(cp + 4);
-        s0[u] = *(const f32x4_t*)sp; s1[u] = *(const f32x4_t*)(sp + 4);
+        const float* tp = p.rope_cs + (int64_t)srow[u] * 128 + dch;   // pair dch/2 + e at floats 2e, 2e + 1
+        t0[u] = *(const f32x4_t*)tp;
+        t1[u] = *(const f32x4_t*)(tp + 4);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -258,11 +272,10 @@ FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& 
           xv[2 * e + 1] = bf_hi(y[u][e]);
           ss += xv[2 * e] * xv[2 * e] + xv[2 * e + 1] * xv[2 * e + 1];
         }
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
-        const float rs = rsqrtf(ss * (1.0f / 128) + 1e-6f);
-        const float cs[8] = {c0[u][0], c0[u][1], c0[u][2], c0[u][3], c1[u][0], c1[u][1], c1[u][2], c1[u][3]};
-        const float sn[8] = {s0[u][0], s0[u][1], s0[u][2], s0[u][3], s1[u][0], s1[u][1], s1[u][2], s1[u][3]};
+        ss = row16_sum(ss);
+        const float rs = __builtin_amdgcn_rsqf(ss * (1.0f / 128) + 1e-6f);   // argument >= 1e-6: no denormal scaling
+        const float cs[4] = {t0[u][0], t0[u][2], t1[u][0], t1[u][2]};
+        const float sn[4] = {t0[u][1], t0[u][3], t1[u][1], t1[u][3]};
         u32x4_t ow;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -271,12 +284,13 @@ FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& 
           re *= bf_lo(ww[e]);
           im *= bf_hi(ww[e]);
           round_bf_pair(re, im);
-          const float o0 = __fadd_rn(__fmul_rn(re, cs[2 * e]), __fmul_rn(-im, sn[2 * e]));
-          const float o1 = __fadd_rn(__fmul_rn(im, cs[2 * e + 1]), __fmul_rn(re, sn[2 * e + 1]));
+          const float o0 = __fadd_rn(__fmul_rn(re, cs[e]), __fmul_rn(-im, sn[e]));
+          const float o1 = __fadd_rn(__fmul_rn(im, cs[e]), __fmul_rn(re, sn[e]));
           ow[e] = pack_bf2(o0, o1);
         }
-        if (ml <= mlast && n < p.N)
-          *(u32x4_t*)(dst + (((int64_t)bidx[u] * p.qkv_heads + head) * p.qkv_s_total + srow[u]) * 128 + dch) = ow;
+        // head-major row index in 32 bits (the launcher checks batches * heads * s_total < 2^31)
+        const int hrow = (bidx[u] * p.qkv_heads + head) * p.qkv_s_total + srow[u];
+        if (ml <= mlast && n < p.N) *(u32x4_t*)(dst + (int64_t)hrow * 128 + dch) = ow;
       }
     }
     return;

@@ -30,7 +30,7 @@ class GemmArgs(ctypes.Structure):
         ("gate", c_vp), ("gate_batch_stride", c_i64), ("gate_rows_per_batch", c_i64),
         ("M", c_i32), ("N", c_i32), ("K", c_i32),
         ("epilogue", c_i32), ("out_fp32", c_i32), ("alpha", c_f32),
-        ("q_out", c_vp), ("k_out", c_vp), ("wq", c_vp), ("wk", c_vp), ("rope_cos", c_vp), ("rope_sin", c_vp),
+        ("q_out", c_vp), ("k_out", c_vp), ("wq", c_vp), ("wk", c_vp), ("rope_cs", c_vp), ("reserved_ptr_", c_vp),
         ("qkv_s_offset", c_i32), ("qkv_s_total", c_i32), ("qkv_heads", c_i32), ("reserved_", c_i32),
     ]
 

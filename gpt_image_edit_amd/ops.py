@@ -28,6 +28,17 @@ def _need_cuda(*ts):
             raise RuntimeError("gpt_image_edit_amd ops need GPU tensors: the HIP path has no CPU fallback")
 
 
+def pack_rope(cos, sin):
+    """FluxPosEmbed's cos / sin [S, 128] (each value repeated over the two columns of its rotary pair) -> the
+    [S, 64, 2] (cos, sin)-per-pair table the fused QKV epilogue reads.  Step-invariant: callers on the hot path
+    pack once (transformer._rope) and pass ``cs``; passing cos / sin packs per call and checks the repetition."""
+    if cos.shape != sin.shape or cos.dim() != 2 or cos.shape[1] != 128:
+        raise ValueError("cos / sin must be [S, 128]")
+    if not (torch.equal(cos[:, 0::2], cos[:, 1::2]) and torch.equal(sin[:, 0::2], sin[:, 1::2])):
+        raise ValueError("cos / sin do not repeat over the columns of a rotary pair: not FluxPosEmbed tables")
+    return torch.stack([cos[:, 0::2], sin[:, 0::2]], dim=-1).to(torch.float32).contiguous()
+
+
 def rows_of(t):
     """(M, Rows) for a [M, K] or [B, R, K] tensor (or view) whose last dimension is contiguous."""
     if t.stride(-1) != 1:
@@ -73,10 +84,13 @@ def _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv=None):
     args.M, args.N, args.K = M, N, K
     args.epilogue, args.out_fp32, args.alpha = epilogue, int(out_fp32), float(alpha)
     if epilogue == FK_EPI_QKV:
-        _need_cuda(qkv["q_out"], qkv["k_out"], qkv["wq"], qkv["wk"], qkv["cos"], qkv["sin"])
+        cs = qkv["cs"] if "cs" in qkv else pack_rope(qkv["cos"], qkv["sin"])
+        _need_cuda(qkv["q_out"], qkv["k_out"], qkv["wq"], qkv["wk"], cs)
+        if cs.dtype != torch.float32 or not cs.is_contiguous() or tuple(cs.shape) != (qkv["q_out"].shape[2], 64, 2):
+            raise ValueError("cs must be a contiguous fp32 [S_total, 64, 2] table (see pack_rope)")
         args.q_out, args.k_out = qkv["q_out"].data_ptr(), qkv["k_out"].data_ptr()
         args.wq, args.wk = qkv["wq"].data_ptr(), qkv["wk"].data_ptr()
-        args.rope_cos, args.rope_sin = qkv["cos"].data_ptr(), qkv["sin"].data_ptr()
+        args.rope_cs = cs.data_ptr()
         args.qkv_s_offset, args.qkv_s_total, args.qkv_heads = qkv["s_offset"], qkv["q_out"].shape[2], qkv["q_out"].shape[1]
     return args, out
 
@@ -85,7 +99,8 @@ def gemm(a, w, bias=None, out=None, epilogue=FK_EPI_NONE, res=None, gate=None, o
     """out = epilogue(a @ w.T + bias).  a: [M,K] / [B,R,K] view; w: [N,K]; out likewise (may alias res).
 
     gate: [B, N] view (row stride = batch stride); used with FK_EPI_GATE_RES and a 3-D ``a``.
-    qkv (FK_EPI_QKV): dict(q_out, k_out [B,H,S_total,128], wq, wk [128], cos, sin fp32 [S_total,128], s_offset)
+    qkv (FK_EPI_QKV): dict(q_out, k_out [B,H,S_total,128], wq, wk [128], cs fp32 [S_total,64,2] (pack_rope; or cos, sin
+    fp32 [S_total,128], packed per call), s_offset)
     -- the fused QKV projection: q / k thirds get RMSNorm + RoPE + head-major layout, the v third lands in out.
     """
     args, out = _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv)

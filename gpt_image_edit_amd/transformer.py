@@ -157,7 +157,7 @@ class HipFluxTransformer2DModel(nn.Module):
         self._ws = {key: ws}  # keep only the latest shape
         return ws
 
-    def _rope(self, txt_ids, img_ids):
+    def _rope(self, txt_ids, img_ids, packed=False):
         # Step-invariant: keyed on the identity of the id tensors (the pipeline passes the same objects for
         # all 28 steps), so the hot loop never reads ids back to the host.  Strong refs keep the ids alive.
         key = (id(txt_ids), id(img_ids), txt_ids._version, img_ids._version)
@@ -167,9 +167,9 @@ class HipFluxTransformer2DModel(nn.Module):
             i2 = img_ids[0] if img_ids.dim() == 3 else img_ids
             ids = torch.cat([t2.float().cpu(), i2.float().cpu()], dim=0)
             cos, sin = rope_tables(ids, self.config.axes_dims_rope)
-            hit = (cos.to(self.device), sin.to(self.device), txt_ids, img_ids)
+            hit = (cos.to(self.device), sin.to(self.device), txt_ids, img_ids, ops.pack_rope(cos, sin).to(self.device))
             self._rope_cache = {key: hit}
-        return hit[0], hit[1]
+        return hit[4] if packed else (hit[0], hit[1])
 
     # ---- conditioning: temb and the modulation vectors of every block ------------------------------------
     def _conditioning(self, timestep, guidance, pooled, tproj, e1, t_emb, g_emb, p_emb, temb, act, mod):
@@ -248,6 +248,7 @@ class HipFluxTransformer2DModel(nn.Module):
         S_txt = encoder_hidden_states.shape[1]
         ws = self._workspace(B, S_txt, S_img)
         cos, sin = self._rope(txt_ids, img_ids)
+        cs = self._rope(txt_ids, img_ids, packed=True)   # (cos, sin) per rotary pair: what the fused QKV epilogue reads
         if cos.shape[0] != ws.S:
             raise ValueError(f"txt_ids + img_ids give {cos.shape[0]} positions for a sequence of {ws.S}")
         hs = hidden_states.to(BF16).contiguous()
@@ -279,10 +280,10 @@ class HipFluxTransformer2DModel(nn.Module):
             if FUSE_QKV:  # RMSNorm + RoPE + head-major q / k come out of the projection GEMM's epilogue
                 ops.gemm_grouped([dict(a=n_img, w=blk.wqkv_img, bias=blk.bqkv_img, out=ws.qkv[:, S_txt:],
                                        qkv=dict(q_out=ws.q, k_out=ws.k, wq=P(p + "attn.norm_q.weight"),
-                                                wk=P(p + "attn.norm_k.weight"), cos=cos, sin=sin, s_offset=S_txt)),
+                                                wk=P(p + "attn.norm_k.weight"), cs=cs, s_offset=S_txt)),
                                   dict(a=n_txt, w=blk.wqkv_txt, bias=blk.bqkv_txt, out=ws.qkv[:, :S_txt],
                                        qkv=dict(q_out=ws.q, k_out=ws.k, wq=P(p + "attn.norm_added_q.weight"),
-                                                wk=P(p + "attn.norm_added_k.weight"), cos=cos, sin=sin, s_offset=0))],
+                                                wk=P(p + "attn.norm_added_k.weight"), cs=cs, s_offset=0))],
                                  epilogue=ops.FK_EPI_QKV)
             else:
                 ops.gemm_grouped([dict(a=n_img, w=blk.wqkv_img, bias=blk.bqkv_img, out=ws.qkv[:, S_txt:]),
@@ -311,7 +312,7 @@ class HipFluxTransformer2DModel(nn.Module):
             if FUSE_QKV:
                 ops.gemm(n, blk.wqkv, blk.bqkv, out=ws.qkv, epilogue=ops.FK_EPI_QKV,
                          qkv=dict(q_out=ws.q, k_out=ws.k, wq=P(p + "attn.norm_q.weight"),
-                                  wk=P(p + "attn.norm_k.weight"), cos=cos, sin=sin, s_offset=0))
+                                  wk=P(p + "attn.norm_k.weight"), cs=cs, s_offset=0))
             else:
                 ops.gemm(n, blk.wqkv, blk.bqkv, out=ws.qkv)
                 ops.qkv_post(ws.qkv, ws.q, ws.k, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"), None, None,

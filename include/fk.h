@@ -89,7 +89,10 @@ typedef struct fk_gemm_args {
    * m / c.rows_per_batch; c.rows_per_batch <= 0: one batch): */
   void* q_out; void* k_out;      /* bf16 [B, H, S_total, 128] */
   const void* wq; const void* wk;/* bf16 [128] RMSNorm weights of this stream (norm_q/norm_k or norm_added_*) */
-  const float* rope_cos; const float* rope_sin; /* fp32 [S_total, 128] */
+  const float* rope_cs;          /* fp32 [S_total, 64, 2]: (cos, sin) of every rotary pair (FluxPosEmbed repeats each
+                                  * value over the two columns of its pair, so the [S,128] cos / sin tables hold
+                                  * every number twice; the epilogue reads 512 B per token row instead of 1 KiB) */
+  const void* reserved_ptr_;
   int32_t qkv_s_offset, qkv_s_total, qkv_heads;
   int32_t reserved_;
 } fk_gemm_args;
