@@ -263,10 +263,12 @@ def prompt_encode_time(device, batch=1):
 
 def train_step_bench(device, steps=3, warmup=1, world=1):
     """BASELINE.json configs[4] on this rank's GPU: one stage-2 optimisation step of the denoiser at 1024^2, batch 1 per
-    GPU (S_txt = 512 + 4096 target + 4096 condition tokens), the parameters the reference un-freezes
-    (`only_tune_image_branch`), one activation checkpoint per block, AdamW on ZeRO-2-sharded fp32 state (with world > 1:
+    GPU (S_txt = 256 projected VLM tokens + 256 T5 prefix tokens, + 4096 target + 4096 condition tokens), the parameters
+    the reference un-freezes (`only_tune_image_branch` subset of the MMDiT + the denoise_projector), activations stored
+    or one checkpoint per block (`auto`), AdamW on ZeRO-2-sharded fp32 state (with world > 1:
     fp32 gradient reduce-scatter + bf16 parameter all-gather over RCCL).  Synthetic latents / embeddings / weights."""
     from gpt_image_edit_amd import flux_spec
+    from gpt_image_edit_amd.projector import HipDenoiseProjector
     from gpt_image_edit_amd.train_step import DenoiserTrainStep
     from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
 
@@ -274,14 +276,17 @@ def train_step_bench(device, steps=3, warmup=1, world=1):
         nb = n_double + n_single
         return nb * 24 * D * D * S + nb * 4 * S * S * D + 2 * (n_double * 12 + n_single * 3 + 2) * D * D
     model = HipFluxTransformer2DModel(dict(flux_spec.FLUX_KONTEXT_CONFIG), device=device, init="synthetic", seed=0)
-    ts = DenoiserTrainStep(model, sharded=True)
+    projector = HipDenoiseProjector(device=device, init="synthetic", seed=1)
+    ts = DenoiserTrainStep(model, sharded=True, projector=projector)
     g = torch.Generator(device=device).manual_seed(7)
-    B, h, w, S_txt = 1, 128, 128, 512
+    B, h, w, L_vlm, L_t5 = 1, 128, 128, 256, 256
+    S_txt = L_vlm + L_t5
     batch = dict(model_input=torch.randn(B, 16, h, w, generator=g, device=device),
                  cond_latents=torch.randn(B, 16, h, w, generator=g, device=device),
                  noise=torch.randn(B, 16, h, w, generator=g, device=device),
                  sigmas=torch.rand(B, generator=g, device=device) * 0.8 + 0.1,
-                 prompt_embeds=torch.randn(B, S_txt, 4096, generator=g, device=device).to(BF),
+                 vlm_hidden=torch.randn(B, L_vlm, 3584, generator=g, device=device).to(BF),
+                 prefix_prompt_embeds=torch.randn(B, L_t5, 4096, generator=g, device=device).to(BF),
                  pooled=torch.randn(B, 768, generator=g, device=device).to(BF))
     for _ in range(warmup):
         out = ts.step(**batch)
@@ -297,15 +302,15 @@ def train_step_bench(device, steps=3, warmup=1, world=1):
     dt = (time.perf_counter() - t0) / steps
     assert torch.isfinite(out["loss"]).all()
     S = S_txt + 2 * (h // 2) * (w // 2)
-    n_train = sum(ts.model.p(k).numel() for k in ts.bw.trainable)
+    n_train = sum(ts._param(k).numel() for k in ts.trainable_names())
     fwd = flops_forward(S)
     return {"value": B * world / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "n_gpus": world, "steps": steps, "warmup": warmup,
             "loss": float(out["loss"].item()), "trainable_params": n_train, "seq_len": S,
             "forward_tflop": fwd / 1e12,
             "model_tflops_3x_forward": 3 * fwd / dt / 1e12,
             "frac_of_mfma_peak_3x_forward": 3 * fwd / dt / 1e12 / PEAK_BF16_TFLOPS,
-            "what": "train_denoiser.py stage-2 step: noisy tokens, MMDiT forward with one checkpoint per block, flow-matching "
-                    "loss + gradient, backward (block recompute + adjoints; weight gradients for the un-frozen subset only), "
+            "what": "train_denoiser.py stage-2 step: denoise_projector on the VLM states, noisy tokens, MMDiT forward, flow-matching "
+                    "loss + gradient, backward (adjoints; weight gradients for the un-frozen subset + the projector), "
                     "global-norm clip + AdamW (ZeRO-2 layout); `model_tflops_3x_forward` prices the step at the conventional "
                     "3 x forward FLOPs (the recompute and the 8-product attention backward are not credited)"}
 

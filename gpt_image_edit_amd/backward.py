@@ -37,6 +37,20 @@ def _pad64(n):
     return (n + 63) // 64 * 64
 
 
+def wgrad(buf, dy, x, out=None):
+    """Weight gradient dW[N, K] = dY^T X over the rows of two [B, R, *] views: both operands transposed into K-major
+    buffers whose row count is padded to the GEMM's 64 (the pad columns stay zero), then one fk_gemm_bf16.
+    ``buf(name, shape, zero=...)`` hands out the caller's cached workspace tensors."""
+    B, R, N = dy.shape
+    K = x.shape[-1]
+    Mp = _pad64(B * R)
+    dyT = buf(f"dyT{N}x{Mp}", (N, Mp), zero=True)
+    xT = buf(f"xT{K}x{Mp}", (K, Mp), zero=True)
+    ops.transpose(dy, torch.as_strided(dyT, (B, N, R), (R, Mp, 1)))
+    ops.transpose(x, torch.as_strided(xT, (B, K, R), (R, Mp, 1)))
+    return ops.gemm(dyT, xT, out=out)
+
+
 class FluxBackward:
     """Training forward / backward around a ``HipFluxTransformer2DModel`` (which keeps owning the parameters)."""
 
@@ -107,16 +121,8 @@ class FluxBackward:
         unit = B * S * self.m.inner_dim * 2
         return (nd * 14 + ns * 11) * unit <= self.activation_budget
 
-    # ---- weight gradient: dW[N, K] = dY^T X over the rows of two [B, R, *] views ---------------------------------------
     def _wgrad(self, dy, x, out=None):
-        B, R, N = dy.shape
-        K = x.shape[-1]
-        Mp = _pad64(B * R)
-        dyT = self._b(f"dyT{N}x{Mp}", (N, Mp), zero=True)
-        xT = self._b(f"xT{K}x{Mp}", (K, Mp), zero=True)
-        ops.transpose(dy, torch.as_strided(dyT, (B, N, R), (R, Mp, 1)))
-        ops.transpose(x, torch.as_strided(xT, (B, K, R), (R, Mp, 1)))
-        return ops.gemm(dyT, xT, out=out)
+        return wgrad(self._b, dy, x, out)
 
     # ---- forward (training): the inference kernels, one checkpoint per block -------------------------------------------
     @torch.no_grad()

@@ -7,6 +7,7 @@
 //   fk_gate_res_bwd_bf16      adjoint of the FK_EPI_GATE_RES epilogue:  out = res + gate_b * y
 //                             -> dy = dout * gate_b, dgate_b = sum_s dout * y          (dres = dout, no kernel needed)
 //   fk_gelu_bwd_bf16          adjoint of FK_EPI_GELU_TANH:  dh = df * gelu_tanh'(h)
+//   fk_silu_bwd_bf16          adjoint of FK_EPI_SILU (denoise_projector):  dh = df * silu'(h)
 //   fk_qkv_post_bwd_bf16      adjoint of fk_qkv_post_bf16 (RoPE, per-head RMSNorm with weight, head-major layout)
 //                             -> d(raw q | k) into the [B, S, 3D] gradient buffer, d(norm weights)
 //   fk_colsum_bf16            bias gradients: out[n] = sum_m x[m, n]
@@ -214,14 +215,21 @@ FK_DEV float gelu_tanh_grad(float x) {
   const float du = k0 * fmaf(3.0f * k1, x2, 1.0f);
   return sg + x * sg * (1.0f - sg) * 2.0f * du;
 }
-__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* h, const bf16_t* df, bf16_t* out, int64_t n8) {
+// y = x * sigmoid(x):  y' = sg (1 + x (1 - sg))
+FK_DEV float silu_grad(float x) {
+  const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+  return sg * fmaf(x, 1.0f - sg, 1.0f);
+}
+template <bool SILU>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t* h, const bf16_t* df, bf16_t* out, int64_t n8) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
     const u32x4_t hw = *(const u32x4_t*)(h + i * 8);
     const u32x4_t dw = *(const u32x4_t*)(df + i * 8);
     u32x4_t ow;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      ow[e] = pack_bf2(bf_lo(dw[e]) * gelu_tanh_grad(bf_lo(hw[e])), bf_hi(dw[e]) * gelu_tanh_grad(bf_hi(hw[e])));
+      ow[e] = SILU ? pack_bf2(bf_lo(dw[e]) * silu_grad(bf_lo(hw[e])), bf_hi(dw[e]) * silu_grad(bf_hi(hw[e])))
+                   : pack_bf2(bf_lo(dw[e]) * gelu_tanh_grad(bf_lo(hw[e])), bf_hi(dw[e]) * gelu_tanh_grad(bf_hi(hw[e])));
     *(u32x4_t*)(out + i * 8) = ow;
   }
 }
@@ -487,15 +495,22 @@ extern "C" int fk_gate_res_bwd_bf16(const void* dout, fk_rows dor, const void* y
   return FK_OK;
 }
 
-extern "C" int fk_gelu_bwd_bf16(const void* h, const void* df, void* out, int64_t n, fk_stream_t stream_) {
-  FK_CHECK_ARG(h && df && out && n > 0 && n % 8 == 0, "fk_gelu_bwd_bf16: bad arguments");
-  FK_CHECK_ARG(FK_ALIGNED16(h) && FK_ALIGNED16(df) && FK_ALIGNED16(out), "fk_gelu_bwd_bf16: 16-byte alignment");
+template <bool SILU>
+static int act_bwd(const char* name, const void* h, const void* df, void* out, int64_t n, fk_stream_t stream_) {
+  FK_CHECK_ARG(h && df && out && n > 0 && n % 8 == 0, "%s: bad arguments", name);
+  FK_CHECK_ARG(FK_ALIGNED16(h) && FK_ALIGNED16(df) && FK_ALIGNED16(out), "%s: 16-byte alignment", name);
   const int64_t n8 = n / 8;
   const int blocks = (int)((n8 + 255) / 256 > 65536 ? 65536 : (n8 + 255) / 256);
-  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)h, (const bf16_t*)df,
-                     (bf16_t*)out, n8);
-  FK_CHECK_LAUNCH("fk_gelu_bwd_bf16");
+  hipLaunchKernelGGL(act_bwd_kernel<SILU>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)h,
+                     (const bf16_t*)df, (bf16_t*)out, n8);
+  FK_CHECK_LAUNCH(name);
   return FK_OK;
+}
+extern "C" int fk_gelu_bwd_bf16(const void* h, const void* df, void* out, int64_t n, fk_stream_t stream_) {
+  return act_bwd<false>("fk_gelu_bwd_bf16", h, df, out, n, stream_);
+}
+extern "C" int fk_silu_bwd_bf16(const void* h, const void* df, void* out, int64_t n, fk_stream_t stream_) {
+  return act_bwd<true>("fk_silu_bwd_bf16", h, df, out, n, stream_);
 }
 
 extern "C" int fk_qkv_post_bwd_bf16(const void* dq, const void* dk, const void* qkv, void* dqkv, const void* wq_img,

@@ -65,6 +65,7 @@ SIGNATURES = {
     "fk_ln_modulate_bwd_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_i64, c_i64, c_vp, Rows, c_vp, Rows, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_f32, c_vp]),
     "fk_gate_res_bwd_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_i64, c_i64, c_vp, Rows, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp]),
     "fk_gelu_bwd_bf16": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "fk_silu_bwd_bf16": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "fk_qkv_post_bwd_bf16": (c_i32, [c_vp] * 12 + [c_i32] * 4 + [c_f32, c_vp]),
     "fk_gate_res_fwd_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_i64, c_i64, c_vp, Rows, c_i64, c_i32, c_vp]),
     "fk_gelu_tanh_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_i64, c_i32, c_vp]),

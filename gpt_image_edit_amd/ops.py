@@ -385,6 +385,17 @@ def gelu_bwd(h, df, out=None):
     return out
 
 
+def silu_bwd(h, df, out=None):
+    """out = df * silu'(h) (contiguous tensors of one shape)."""
+    _need_cuda(h, df)
+    if not (h.is_contiguous() and df.is_contiguous()):
+        raise ValueError("silu_bwd takes contiguous tensors")
+    if out is None:
+        out = torch.empty_like(df)
+    libfk.check(libfk.load().fk_silu_bwd_bf16(_ptr(h), _ptr(df), _ptr(out), h.numel(), _stream()), "fk_silu_bwd_bf16")
+    return out
+
+
 def qkv_post_bwd(dq, dk, qkv, dqkv, wq_img, wk_img, wq_txt, wk_txt, cos, sin, s_txt, eps=1e-6):
     """Adjoint of :func:`qkv_post`; returns dw fp32 [2 (q,k)][2 (image,text)][128]."""
     _need_cuda(dq, dk, qkv, dqkv, cos, sin)

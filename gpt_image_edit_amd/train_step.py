@@ -8,6 +8,15 @@ checkpoint per block and backward (``backward.FluxBackward``), flow-matching los
 bf16 parameter copy written in the same pass (``fk_adamw_step``).  The step's scalars (which parameters train, sigma
 sampling, shift) are ``training.py``; the data-parallel exchange is ``zero.py``.  No torch arithmetic touches an
 activation, gradient or parameter.
+
+With ``projector=`` the ``denoise_projector`` trains along (it is in the reference's trainable set,
+``train_denoiser.py:71-119``): ``vlm_hidden`` -- the frozen VLM's last hidden states -- goes through
+``HipDenoiseProjector.forward_train``, the optional T5 ``prefix_prompt_embeds`` are appended as the reference's
+``UnivaDenoiseTower.forward`` does (``modeling_univa_denoise_tower.py:62-70``), and the gradient of ``prompt_embeds``
+that the MMDiT backward returns is carried through both Linears.  Its parameters appear as ``denoise_projector.*``.
+The reference builds a ``joint_attention_kwargs['attention_mask']`` for padded multi-resolution batches
+(``train_denoiser.py:907-916``) but ``UnivaDenoiseTower.forward`` pops it without passing it on
+(``modeling_univa_denoise_tower.py:77``), so no mask ever reaches the attention: there is none here either.
 """
 import torch
 
@@ -19,11 +28,12 @@ BF16 = torch.bfloat16
 
 class DenoiserTrainStep:
     def __init__(self, model, lr=1e-6, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, trainable=None,
-                 sharded=False, group=None, store_activations="auto"):
+                 sharded=False, group=None, store_activations="auto", projector=None):
         """sharded=True: the optimiser state lives in ``zero.ShardedAdamW`` (ZeRO-2: one flat bf16 parameter buffer the
         model's trainable tensors become views of, fp32 gradients reduce-scattered over the data-parallel ranks, this
         rank's slice of master + moments updated, parameters all-gathered); works unchanged with one process."""
         self.model = model
+        self.projector = projector
         self.bw = FluxBackward(model, trainable, store_activations=store_activations)
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.step_count = 0
@@ -31,27 +41,52 @@ class DenoiserTrainStep:
         self.opt = None
         if sharded:
             from .zero import ShardedAdamW
-            names = sorted(self.bw.trainable)
-            self.opt = ShardedAdamW({k: model.p(k).data for k in names}, lr=lr, betas=betas, eps=eps,
+            names = sorted(self.trainable_names())
+            self.opt = ShardedAdamW({k: self._param(k).data for k in names}, lr=lr, betas=betas, eps=eps,
                                     weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group)
             for k in names:
-                model.p(k).data = self.opt.params[k]     # the forward now reads views of the flat buffer
+                self._param(k).data = self.opt.params[k]     # the forward now reads views of the flat buffer
             model._packed = None
+
+    PROJ = "denoise_projector."
+
+    def trainable_names(self):
+        names = set(self.bw.trainable)
+        if self.projector is not None:
+            names |= {self.PROJ + k for k in self.projector.state_dict()}
+        return names
+
+    def _param(self, name):
+        if name.startswith(self.PROJ):
+            return self.projector.p(name[len(self.PROJ):])
+        return self.model.p(name)
 
     def _state(self, name):
         st = self.state.get(name)
         if st is None:
-            p = self.model.p(name)
+            p = self._param(name)
             st = (p.detach().float().contiguous(), torch.zeros(p.shape, device=p.device, dtype=torch.float32),
                   torch.zeros(p.shape, device=p.device, dtype=torch.float32))
             self.state[name] = st
         return st
 
     @torch.no_grad()
-    def forward_backward(self, model_input, cond_latents, noise, sigmas, prompt_embeds, pooled, guidance_scale=1.0):
+    def forward_backward(self, model_input, cond_latents, noise, sigmas, prompt_embeds=None, pooled=None, guidance_scale=1.0,
+                         vlm_hidden=None, prefix_prompt_embeds=None):
         """(loss fp64 [1], grads, d_prompt_embeds) for one batch of equally sized samples; model_input / noise fp32
-        [B,16,h,w] (VAE latents already shifted and scaled), cond_latents the same or None, sigmas fp32 [B]."""
+        [B,16,h,w] (VAE latents already shifted and scaled), cond_latents the same or None, sigmas fp32 [B].
+        Either ``prompt_embeds`` (projector frozen / absent) or ``vlm_hidden`` [B,L,3584] (+ optional T5 prefix)."""
         dev = self.model.device
+        n_proj = 0
+        if vlm_hidden is not None:
+            if self.projector is None or prompt_embeds is not None:
+                raise ValueError("vlm_hidden needs projector= at construction and excludes prompt_embeds")
+            prompt_embeds = self.projector.forward_train(vlm_hidden)
+            n_proj = prompt_embeds.shape[1]
+            if prefix_prompt_embeds is not None:
+                prompt_embeds = torch.cat([prompt_embeds, prefix_prompt_embeds.to(BF16)], dim=1)
+        elif prompt_embeds is None:
+            raise ValueError("one of prompt_embeds / vlm_hidden is required")
         B, C, h, w = model_input.shape
         S_tgt = (h // 2) * (w // 2)
         S_cond = 0 if cond_latents is None else (cond_latents.shape[2] // 2) * (cond_latents.shape[3] // 2)
@@ -72,6 +107,9 @@ class DenoiserTrainStep:
         dsample = torch.zeros_like(pred)
         dsample[:, :S_tgt].copy_(grad)
         grads, d_enc = self.bw.backward(dsample)
+        if n_proj:
+            for k, g in self.projector.backward(d_enc[:, :n_proj]).items():
+                grads[self.PROJ + k] = g
         return loss, grads, d_enc
 
     @torch.no_grad()
@@ -79,8 +117,11 @@ class DenoiserTrainStep:
         """Global-norm clipping + AdamW on fp32 masters; the bf16 parameters of the model are rewritten in the same pass."""
         names = sorted(grads)
         if self.opt is not None:
-            for k in names:
-                self.opt.grads[k].copy_(grads[k])        # bf16 / fp32 -> the flat fp32 gradient buffer (a cast, no arithmetic)
+            for k, flat in self.opt.grads.items():       # bf16 / fp32 -> the flat fp32 gradient buffer (a cast, no arithmetic)
+                if k in grads:
+                    flat.copy_(grads[k])
+                else:
+                    flat.zero_()                         # e.g. the projector on a batch that came with ready prompt_embeds
             norm = self.opt.step()
             self.step_count = self.opt.step_count
             self.bw.refresh()
@@ -90,7 +131,7 @@ class DenoiserTrainStep:
         for k in names:
             master, m1, m2 = self._state(k)
             ops.adamw_step(master, grads[k].contiguous(), m1, m2, self.step_count, self.lr, self.betas, self.eps,
-                           self.weight_decay, grad_sumsq=sumsq, max_grad_norm=self.max_grad_norm, param_bf16=self.model.p(k).data)
+                           self.weight_decay, grad_sumsq=sumsq, max_grad_norm=self.max_grad_norm, param_bf16=self._param(k).data)
         self.bw.refresh()
         return sumsq
 

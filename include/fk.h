@@ -187,6 +187,9 @@ int fk_gate_res_bwd_bf16(const void* dout, fk_rows dor, const void* y, fk_rows y
                          int64_t dgate_batch_stride, float* ws, int32_t B, int32_t N, fk_stream_t stream);
 /* out = df * gelu_tanh'(h) over n elements (h = the Linear's bf16 output before the activation); out may alias df. */
 int fk_gelu_bwd_bf16(const void* h, const void* df, void* out, int64_t n, fk_stream_t stream);
+/* The same for FK_EPI_SILU (the denoise_projector's activation, modeling_univa_denoise_tower.py:36-41; the projector is
+ * among the parameters train_denoiser.py:71-119 trains). */
+int fk_silu_bwd_bf16(const void* h, const void* df, void* out, int64_t n, fk_stream_t stream);
 /* Adjoint of fk_qkv_post_bf16: dq, dk [B, H, S, 128] -> the q and k thirds of dqkv [B, S, 3*H*128] (gradient of the raw
  * projection `qkv`), and dw [2 (q, k)][2 (image, text)][128] fp32 = gradients of the RMSNorm weights. */
 int fk_qkv_post_bwd_bf16(const void* dq, const void* dk, const void* qkv, void* dqkv, const void* wq_img, const void* wk_img,

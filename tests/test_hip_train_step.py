@@ -103,3 +103,63 @@ def test_sharded_optimizer_layout_gives_the_same_step():
     assert out[0][1] != out[0][0]
     for k in trainable:
         assert torch.equal(out[0][2][k], out[1][2][k]), k
+
+
+def test_projector_trains_along():
+    """denoise_projector (in the reference's trainable set, train_denoiser.py:71-119): forward_train == forward bit for
+    bit, its backward against fp32 autograd of the same Sequential on the host, and the train step carrying the gradient
+    of prompt_embeds into it (per-tensor and sharded optimiser layouts update it identically)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.nn.functional as F
+    from gpt_image_edit_amd.projector import HipDenoiseProjector
+    from gpt_image_edit_amd.train_step import DenoiserTrainStep
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    B, L = 2, 37
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, L, 3584, generator=g).to(BF)
+    dy = (torch.randn(B, L, 4096, generator=g) * 0.1).to(BF)
+    proj = HipDenoiseProjector(device="cuda", init="synthetic", seed=7)
+    sd = {k: v.detach().cpu() for k, v in proj.state_dict().items()}
+    y = proj(x.cuda())
+    y_train = proj.forward_train(x.cuda())
+    assert torch.equal(y, y_train)
+    grads = proj.backward(dy.cuda())
+    with pytest.raises(RuntimeError):
+        proj.backward(dy.cuda())                      # the saved activations are consumed
+    w = {k: v.float().requires_grad_(True) for k, v in sd.items()}
+    h1 = F.linear(x.float(), w["0.weight"], w["0.bias"])
+    ref = F.linear(F.silu(h1), w["2.weight"], w["2.bias"])
+    ref.backward(dy.float())
+    assert _rel(y.cpu(), ref.detach()) < 1e-2
+    for k in sd:
+        e = _rel(grads[k].cpu(), w[k].grad)
+        print(f"[projector grad] {k:10s} rel {e:.3e}")
+        assert e < 1.5e-2, k                          # bf16 activations / bf16 gradient storage vs fp32 autograd
+    # inside the step
+    cfg, sd_bf, batch, trainable = _setup(B=B, S_txt=24, h=8, w=8, seed=9)
+    dev_batch = {k: v.cuda() for k, v in batch.items() if k != "prompt_embeds"}
+    dev_batch.update(vlm_hidden=x.cuda(), prefix_prompt_embeds=batch["prompt_embeds"].cuda())
+    out = []
+    for sharded in (False, True):
+        model = HipFluxTransformer2DModel(cfg, device="cuda")
+        model.load_state_dict(sd_bf)
+        pj = HipDenoiseProjector(device="cuda", init="synthetic", seed=7)
+        ts = DenoiserTrainStep(model, lr=1e-3, sharded=sharded, projector=pj)
+        assert ts.trainable_names() == set(trainable) | {"denoise_projector." + k for k in sd}
+        r = ts.step(**dev_batch)
+        assert set(r["grads"]) == ts.trainable_names()
+        assert r["d_prompt_embeds"].shape == (B, L + 24, 4096)
+        # the projector's share of the step is exactly its backward on the leading L rows of d(prompt_embeds)
+        pj2 = HipDenoiseProjector(device="cuda", init="synthetic", seed=7)
+        pj2.forward_train(x.cuda())
+        g2 = pj2.backward(r["d_prompt_embeds"][:, :L])
+        for k in sd:
+            assert torch.equal(g2[k], r["grads"]["denoise_projector." + k]), k
+            assert r["grads"]["denoise_projector." + k].float().abs().max().item() > 0
+        r2 = ts.step(**dev_batch)
+        out.append((r["loss"].item(), r2["loss"].item(), {k: pj.p(k).detach().clone() for k in sd}))
+        assert any(not torch.equal(out[-1][2][k].cpu(), sd[k]) for k in sd), "the projector did not move"
+    assert out[0][:2] == out[1][:2]
+    for k in sd:
+        assert torch.equal(out[0][2][k], out[1][2][k]), k
