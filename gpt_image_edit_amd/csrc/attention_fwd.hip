@@ -76,7 +76,7 @@ FK_DEV void wait_vmcnt() {
 // the probabilities enter the PV product as TWO bf16 terms (p = hi + lo, 16 mantissa bits instead of 8), so that
 // the result can be held against an fp32 reference at rtol 1e-3 / atol 1e-4 -- with one bf16 term the rounding of
 // P alone (2^-9 per term) sits above that tolerance whatever the kernel does.
-template <int NW, int STAGES, bool F32OUT>
+template <int NW, int STAGES, bool F32OUT, bool ILV>
 __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnParams p) {
   constexpr int QBLK = NW * 32;
   constexpr int LOADS = 32 / NW;      // DMA instructions per wave per tile (16 K pieces + 16 V pieces / NW)
@@ -234,60 +234,159 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
   // maximum) -> pack -> 8 PV MFMAs.  Only one 32 x 32 score block is live at a time.
   // MASK = the tile holds keys >= S (only ever the last tile), FIRST = tile 0 of the first attempt (sets the
   // exponent reference): compiled as separate copies so the steady-state loop carries no selects.
+  // ILV: the same arithmetic in another order.  Per wave: QK(0); then QK(1) with the exponentials of block 0 issued in
+  // the shadow of its MFMAs; then PV(0) with the exponentials of block 1 in the shadow; then PV(1).  The interleave is
+  // pinned (sched_group_barrier: one MFMA, then its share of VALU / transcendental work); hipcc by itself emits the
+  // phases back to back.  Bit-identical results; which order is faster depends on the clock the kernel runs at
+  // (profiles/r02_attention_variants.txt), so the launcher chooses.
+  // MASK = the tile holds keys >= S (only ever the last tile), FIRST = tile 0 of the first attempt (sets the
+  // exponent reference): compiled as separate copies so the steady-state loop carries no selects.
   auto do_tile = [&](int kt, auto mask_tag, auto first_tag) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    const char* sb = acquire_tile(kt);
-    float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      f32x16_t s = scores(sb, kb, kt, mask_tag);
-      if constexpr (FIRST) {
-        if (kb == 0) m_ref = block_max(s) + REF_BIAS;   // reference = row maximum over the first 32 keys + bias
-      }
-      const float nm = -m_ref;
-      // ---- softmax numerators (log2 domain; raw v_exp_f32, denormal results may flush) ----------------------
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, nm));
-        s[r] = pv;
-        psum += pv;
-      }
-      // ---- O^T += V^T P^T for the two 16-key steps of this half ------------------------------------------------
-      bf16x8_t vf[3];
-      vf[0] = v_frag(sb, 2 * kb, 0);
-      vf[1] = v_frag(sb, 2 * kb, 1);
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the leading reads (two transpose reads per fragment)
-      bf16x8_t pf, pf_lo;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int st = 2 * kb + (i >> 2), df = i & 3;
-        if (df == 0) {
-          const int r0 = 8 * (i >> 2);
-          u32x4_t pw;
-          pw[0] = pack_bf2(s[r0 + 0], s[r0 + 1]);
-          pw[1] = pack_bf2(s[r0 + 2], s[r0 + 3]);
-          pw[2] = pack_bf2(s[r0 + 4], s[r0 + 5]);
-          pw[3] = pack_bf2(s[r0 + 6], s[r0 + 7]);
-          pf = __builtin_bit_cast(bf16x8_t, pw);
-          if constexpr (F32OUT) {
-            u32x4_t pl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              pl[e] = pack_bf2(s[r0 + 2 * e] - bf_lo(pw[e]), s[r0 + 2 * e + 1] - bf_hi(pw[e]));
-            pf_lo = __builtin_bit_cast(bf16x8_t, pl);
+    if constexpr (!ILV) {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      const char* sb = acquire_tile(kt);
+      float psum = 0.f;
+  #pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16_t s = scores(sb, kb, kt, mask_tag);
+        if constexpr (FIRST) {
+          if (kb == 0) m_ref = block_max(s) + REF_BIAS;   // reference = row maximum over the first 32 keys + bias
+        }
+        const float nm = -m_ref;
+        // ---- softmax numerators (log2 domain; raw v_exp_f32, denormal results may flush) ----------------------
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, nm));
+          s[r] = pv;
+          psum += pv;
+        }
+        // ---- O^T += V^T P^T for the two 16-key steps of this half ------------------------------------------------
+        bf16x8_t vf[3];
+        vf[0] = v_frag(sb, 2 * kb, 0);
+        vf[1] = v_frag(sb, 2 * kb, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the leading reads (two transpose reads per fragment)
+        bf16x8_t pf, pf_lo;
+  #pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int st = 2 * kb + (i >> 2), df = i & 3;
+          if (df == 0) {
+            const int r0 = 8 * (i >> 2);
+            u32x4_t pw;
+            pw[0] = pack_bf2(s[r0 + 0], s[r0 + 1]);
+            pw[1] = pack_bf2(s[r0 + 2], s[r0 + 3]);
+            pw[2] = pack_bf2(s[r0 + 4], s[r0 + 5]);
+            pw[3] = pack_bf2(s[r0 + 6], s[r0 + 7]);
+            pf = __builtin_bit_cast(bf16x8_t, pw);
+            if constexpr (F32OUT) {
+              u32x4_t pl;
+  #pragma unroll
+              for (int e = 0; e < 4; ++e)
+                pl[e] = pack_bf2(s[r0 + 2 * e] - bf_lo(pw[e]), s[r0 + 2 * e + 1] - bf_hi(pw[e]));
+              pf_lo = __builtin_bit_cast(bf16x8_t, pl);
+            }
+          }
+          if (i + 2 < 8) vf[(i + 2) % 3] = v_frag(sb, 2 * kb + ((i + 2) >> 2), (i + 2) & 3);
+          o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % 3], pf, o[df], 0, 0, 0);
+          if constexpr (F32OUT) o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % 3], pf_lo, o[df], 0, 0, 0);
+          else {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the two transpose reads of this slot first ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // ... then its MFMA
           }
         }
-        if (i + 2 < 8) vf[(i + 2) % 3] = v_frag(sb, 2 * kb + ((i + 2) >> 2), (i + 2) & 3);
-        o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % 3], pf, o[df], 0, 0, 0);
-        if constexpr (F32OUT) o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % 3], pf_lo, o[df], 0, 0, 0);
-        else {
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the two transpose reads of this slot first ...
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // ... then its MFMA
+      }
+      l_run += psum;
+      release_tile();
+      } else {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      constexpr bool MASK = decltype(mask_tag)::value;
+      const char* sb = acquire_tile(kt);
+      float psum = 0.f;
+      f32x16_t s0 = scores(sb, 0, kt, mask_tag);
+      if constexpr (FIRST) m_ref = block_max(s0) + REF_BIAS;   // reference = row maximum over the first 32 keys + bias
+      const float nm = -m_ref;
+      // softmax numerators of two scores (log2 domain; raw v_exp_f32, denormal results may flush)
+      auto expo2 = [&](f32x16_t& s, int r) {
+  #pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(s[r + e], p.scale_log2, nm));
+          s[r + e] = pv;
+          psum += pv;
+        }
+      };
+      auto pack8 = [&](const f32x16_t& s, int r0, bf16x8_t& pf, bf16x8_t& pf_lo) {
+        u32x4_t pw;
+        pw[0] = pack_bf2(s[r0 + 0], s[r0 + 1]);
+        pw[1] = pack_bf2(s[r0 + 2], s[r0 + 3]);
+        pw[2] = pack_bf2(s[r0 + 4], s[r0 + 5]);
+        pw[3] = pack_bf2(s[r0 + 6], s[r0 + 7]);
+        pf = __builtin_bit_cast(bf16x8_t, pw);
+        if constexpr (F32OUT) {
+          u32x4_t pl;
+  #pragma unroll
+          for (int e = 0; e < 4; ++e)
+            pl[e] = pack_bf2(s[r0 + 2 * e] - bf_lo(pw[e]), s[r0 + 2 * e + 1] - bf_hi(pw[e]));
+          pf_lo = __builtin_bit_cast(bf16x8_t, pl);
+        }
+      };
+      // ---- S^T of block 1 under which block 0's exponentials run ---------------------------------------------------
+      f32x16_t s1;
+      {
+        bf16x8_t kf[3];
+        kf[0] = k_frag(sb, 1, 0);
+        kf[1] = k_frag(sb, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+  #pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          if (kk + 2 < 8) kf[(kk + 2) % 3] = k_frag(sb, 1, kk + 2);
+          s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk % 3], qf[kk], kk == 0 ? f32x16_t{} : s1, 0, 0, 0);
+          expo2(s0, 2 * kk);
+          if constexpr (!F32OUT) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the DS read of this slot
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // its MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // two scale-and-shift FMAs
+            __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);   // two exponentials
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // two row-sum adds
+          }
+        }
+        if constexpr (MASK) {
+          const int kbase = kt * KVBLK + 32 + 4 * hh;
+  #pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kbase + (r & 3) + 8 * (r >> 2) >= p.S) s1[r] = -1.0e30f;
         }
       }
-    }
-    l_run += psum;
-    release_tile();
+      // ---- O^T += V^T P^T: block 0 (block 1's exponentials in the shadow), then block 1 ------------------------------
+  #pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const f32x16_t& sp = kb == 0 ? s0 : s1;
+        bf16x8_t vf[3];
+        vf[0] = v_frag(sb, 2 * kb, 0);
+        vf[1] = v_frag(sb, 2 * kb, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the leading reads (two transpose reads per fragment)
+        bf16x8_t pf, pf_lo;
+  #pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int st = 2 * kb + (i >> 2), df = i & 3;
+          if (df == 0) pack8(sp, 8 * (i >> 2), pf, pf_lo);
+          if (i + 2 < 8) vf[(i + 2) % 3] = v_frag(sb, 2 * kb + ((i + 2) >> 2), (i + 2) & 3);
+          o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % 3], pf, o[df], 0, 0, 0);
+          if constexpr (F32OUT) o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % 3], pf_lo, o[df], 0, 0, 0);
+          if (kb == 0) expo2(s1, 2 * i);
+          if constexpr (!F32OUT) {
+            if (df == 0) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // the four packs this MFMA group consumes
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the two transpose reads of this slot
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // its MFMA
+            if (kb == 0) {
+              __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+          }
+        }
+      }
+      l_run += psum;
+      release_tile();
+      }
   };
 
   using TT = std::true_type;
@@ -423,10 +522,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
 // (2) rotating waves 4..7 by one phase so that softmax of one wave meets MFMA of its SIMD partner
 // (4-stage ring): 725 TF vs 844.  PMC: matrix pipe 48 % busy, VALU 52 %, no LDS bank conflicts.
 
-template <int NW, int STAGES, bool F32OUT>
+template <int NW, int STAGES, bool F32OUT, bool ILV>
 int launch(const AttnParams& p, hipStream_t stream) {
   constexpr int SMEM = STAGES * STAGE_BYTES + 16;   // ring + the restart flag word
-  auto kern = attention_fwd_kernel<NW, STAGES, F32OUT>;
+  auto kern = attention_fwd_kernel<NW, STAGES, F32OUT, ILV>;
   FK_ENSURE_MAX_LDS(kern, SMEM, "fk_attention_fwd_bf16");
   const int nqb = (p.S + NW * 32 - 1) / (NW * 32);
   hipLaunchKernelGGL(kern, dim3(nqb * p.H * p.B), dim3(NW * 64), SMEM, stream, p);
@@ -434,6 +533,21 @@ int launch(const AttnParams& p, hipStream_t stream) {
   return FK_OK;
 }
 
+
+// FK_ATTN_ILV=0|1 forces the instruction order of the main loop (A/B measurement); default: by grid size.
+static bool use_interleaved(const AttnParams& p) {
+  static int ov = -2;
+  if (ov == -2) {
+    const char* e = getenv("FK_ATTN_ILV");
+    ov = e ? atoi(e) : -1;
+  }
+  if (ov >= 0) return ov != 0;
+  // Measured (profiles/r02_attention_variants.txt): isolated, the interleaved order is +3-4 % on grids of many rounds
+  // (B = 4, S = 8704: 1157 vs 1114 TF/s) and -2 % on 1-3 round grids; inside an edit, where the kernel runs at the
+  // clock the neighbouring GEMMs leave it, it is +1.7 % at S = 8704, B = 1 and even at S = 2560 (240 workgroups).
+  const int64_t nwg = (int64_t)((p.S + 255) / 256) * p.H * p.B;
+  return nwg >= 512;
+}
 
 int attention_entry(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H, int32_t S, int64_t v_ld,
                     int64_t v_batch_stride, int64_t o_ld, int64_t o_batch_stride, float scale, bool f32out,
@@ -455,7 +569,8 @@ int attention_entry(const void* q, const void* k, const void* v, void* o, int32_
   p.B = B; p.H = H; p.S = S; p.v_ld = v_ld; p.v_bs = v_batch_stride; p.o_ld = o_ld; p.o_bs = o_batch_stride;
   p.scale_log2 = scale * 1.4426950408889634f;
   p.lse = lse;
-  return f32out ? launch<8, 3, true>(p, stream) : launch<8, 3, false>(p, stream);
+  if (f32out) return launch<8, 3, true, false>(p, stream);
+  return use_interleaved(p) ? launch<8, 3, false, true>(p, stream) : launch<8, 3, false, false>(p, stream);
 }
 
 }  // namespace
