@@ -1,0 +1,46 @@
+"""Register / scratch budget of the hot kernels, read from the code hipcc generates for gfx950 (no GPU needed).
+
+A hot loop whose accumulator arrays the compiler could not keep in registers still computes the right numbers -- 25x
+slower (private-segment arrays; it happened once when the attention tile body was wrapped in a second lambda).  The
+parity tests cannot see that, this one can: every MFMA kernel must stay within the 256-VGPR budget of two waves per
+SIMD with at most a few spilled dwords, none of them arrays.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpt_image_edit_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+# file -> (kernel-name substring, max private-segment bytes per lane)
+BUDGET = {
+    "attention_fwd.hip": [("attention_fwd_kernel", 64)],
+    "attention_bwd.hip": [("attention_bwd_kernel", 64)],
+    "gemm_pingpong_bf16.hip": [("gemm8_kernel", 0), ("gemm9_kernel", 0)],
+}
+
+
+@pytest.mark.parametrize("src", sorted(BUDGET))
+def test_hot_kernels_keep_their_accumulators_in_registers(src, tmp_path):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path / (src + ".s")
+    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-value", "-Wno-unused-result", "-S",
+           "--cuda-device-only", os.path.join(CSRC, src), "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    text = out.read_text()
+    meta = re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n"
+                      r"\s+\.vgpr_spill_count:\s+(\d+)", text)
+    assert meta, "no kernel metadata found in the generated assembly"
+    seen = 0
+    for name, scratch, vgprs, spills in meta:
+        for key, max_scratch in BUDGET[src]:
+            if key in name:
+                seen += 1
+                assert int(vgprs) <= 256, f"{name}: {vgprs} VGPRs"
+                assert int(scratch) <= max_scratch, f"{name}: {scratch} B of scratch per lane (arrays in private memory?)"
+                assert int(spills) <= 16, f"{name}: {spills} spilled VGPRs"
+    assert seen >= len(BUDGET[src]), f"expected kernels {BUDGET[src]} in {src}"
