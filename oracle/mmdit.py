@@ -5,7 +5,9 @@ installed, no network): this restates the published algorithm as summarised in S
 Appendix A.1.  Anchors in the reference: the transformer is called at
 ``univa/utils/flux_pipeline.py:1067-1077``, ``univa/models/modeling_univa_denoise_tower.py:103-110``
 and ``univa/models/qwen2p5vl/modeling_univa_qwen2p5vl.py:355``; parameter names are corroborated
-by ``train_denoiser.py:74-119``.
+by ``train_denoiser.py:74-119``.  Second opinions on the building blocks (AdaLayerNorm-Zero / -Continuous chunk order
+and modulation, GELU(tanh) feed-forward, interleaved-pair RoPE, RMSNorm cast order) from independent implementations
+installed with transformers: ``tests/test_oracle_third_party.py``; the wiring of the blocks stays unpinned.
 
 All functions are functional over a flat state dict ``sd`` with the diffusers key names
  and run in whatever dtype the tensors carry: fp32 tensors give the

@@ -1,6 +1,9 @@
 """Oracle: FLUX ``AutoencoderKL`` encode/decode (diffusers 0.32.2).  TEST INFRASTRUCTURE.
 
-PARITY UNPINNED against the real third-party source; restated from SURVEY.md Appendix A.3.
+PARITY UNPINNED against the real third-party source (diffusers is not installable here); restated from SURVEY.md
+Appendix A.3.  Second opinion: the whole encoder and decoder are held to an INDEPENDENT implementation of the same
+taming-lineage topology that IS installed (transformers' ``JanusVQVAEEncoder`` / ``JanusVQVAEDecoder`` configured to the
+FLUX VAE's sizes) on shared seeded weights, ``tests/test_oracle_third_party.py``.
 Reference call sites: ``univa/utils/flux_pipeline.py:604-611`` (encode + ``mode()``),
 ``:1127-1129`` (decode); ``train_denoiser.py:428-432,887,895,1505``.
 
