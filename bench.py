@@ -152,7 +152,7 @@ def roofline_of(fam, workload):
         except Exception as e:  # a malformed side file must not cost the bench line
             traffic_note = f"unreadable {TRAFFIC_FILE}: {e}"
     rl = {
-        "kernel": "gemm8_kernel<*> + gemm2_kernel<*> + gemm5_kernel<*> + gemm_bf16_kernel<*> (bf16 MFMA GEMM family: all MMDiT / VAE linears)",
+        "kernel": "gemm8_kernel<*> + gemm9_kernel<*> + gemm_bf16_kernel<*> (bf16 MFMA GEMM family: all MMDiT / VAE linears)",
         "bound": "mfma", "achieved": gm["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": gm["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
         "launches_per_edit": gm["launches"], "ms_per_edit": gm["ms"], "algorithmic_tflop_per_edit": gm["flops"] / 1e12,

@@ -16,9 +16,14 @@ run_pass() {  # tag, counters...
   python $ROOT/tools/pmc_dump.py /tmp/tr_$tag $OUT/$tag.txt >> $OUT/$tag.log 2>&1
 }
 : > $OUT/passes.txt
-run_pass time
-run_pass fetch FETCH_SIZE
-run_pass write WRITE_SIZE
-run_pass hit TCC_HIT_sum TCC_MISS_sum
-run_pass req TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
+PASSES=${PMC_PASSES:-"time fetch write hit req"}   # subset to save GPU time, e.g. PMC_PASSES="time fetch write"
+for pass in $PASSES; do
+  case $pass in
+    time) run_pass time ;;
+    fetch) run_pass fetch FETCH_SIZE ;;
+    write) run_pass write WRITE_SIZE ;;
+    hit) run_pass hit TCC_HIT_sum TCC_MISS_sum ;;
+    req) run_pass req TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum ;;
+  esac
+done
 cat $OUT/passes.txt

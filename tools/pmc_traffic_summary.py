@@ -110,7 +110,7 @@ def main(d, out_stem):
                      f"{rd / 1e6:.1f} + {wr / 1e6:.1f} | {(rd + wr) / alg:.2f} | {(rd + wr) / (us * 1e-6) / 1e9:.0f} | "
                      f"{alg / (us * 1e-6) / 1e9:.0f} | {tf:.0f} | {hit * 100:.1f} % |")
         js[it["name"]] = dict(avg_us=us, alg_bytes=alg, hbm_read_bytes=rd, hbm_write_bytes=wr, ratio=(rd + wr) / alg,
-                              l2_hit=hit, tflops=tf, note=it.get("note", ""))
+                              l2_hit=hit, tflops=tf, note=it.get("note", ""), kernel=kern)
         if "families" in passes["time"][i]:
             lines_f = ["", f"### {it['name']}: by kernel family (per decode)", "",
                        "| family | launches | us | counted MB rd | counted MB wr | GB/s (counted) |", "|---|---|---|---|---|---|"]
