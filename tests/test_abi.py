@@ -64,3 +64,25 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{f} imports the oracle"
+
+
+def test_pack_rope_is_the_per_pair_view_of_the_flux_tables():
+    """ops.pack_rope (host-side, no GPU): FluxPosEmbed's [S,128] cos / sin -> the [S,64,2] table of the fused QKV
+    epilogue; anything that is not repeated over the columns of a rotary pair is refused."""
+    import pytest
+    import torch
+    from gpt_image_edit_amd import ops
+    from gpt_image_edit_amd.transformer import rope_tables
+    from oracle.helpers import prepare_latent_image_ids
+    ids = torch.cat([torch.zeros(5, 3), prepare_latent_image_ids(3, 4)])
+    cos, sin = rope_tables(ids)
+    cs = ops.pack_rope(cos, sin)
+    assert cs.shape == (17, 64, 2) and cs.dtype == torch.float32 and cs.is_contiguous()
+    assert torch.equal(cs[..., 0], cos[:, 0::2]) and torch.equal(cs[..., 0], cos[:, 1::2])
+    assert torch.equal(cs[..., 1], sin[:, 0::2]) and torch.equal(cs[..., 1], sin[:, 1::2])
+    bad = cos.clone()
+    bad[3, 1] += 1e-3
+    with pytest.raises(ValueError):
+        ops.pack_rope(bad, sin)
+    with pytest.raises(ValueError):
+        ops.pack_rope(cos[:, :64], sin[:, :64])
