@@ -90,8 +90,12 @@ def run_edit(pipe, inp, steps28=28):
 
 
 def instrumented_edit(pipe, inp):
-    """Per-kernel-family HIP-event timing of one edit (events recorded on the launch stream)."""
-    from gpt_image_edit_amd import ops
+    """Per-kernel-family HIP-event timing of one edit (events recorded on the launch stream).  For this pass the single
+    blocks' MLP-up GEMM, which the timed edits run on a second stream beside the QKV GEMM and the attention
+    (transformer.OVERLAP_MLP), is kept on the launch stream: a launch's duration can only be bracketed -- and priced
+    against the roofline -- when nothing else shares the chip with it."""
+    from gpt_image_edit_amd import ops, transformer
+    overlap, transformer.OVERLAP_MLP = transformer.OVERLAP_MLP, False
     rec = {"gemm": [], "attention": [], "conv": []}
     st = torch.cuda.current_stream()
 
@@ -131,6 +135,7 @@ def instrumented_edit(pipe, inp):
         torch.cuda.synchronize()
     finally:
         ops.gemm, ops.gemm_grouped, ops.attention, ops.conv2d_nhwc = orig
+        transformer.OVERLAP_MLP = overlap
     out = {}
     for fam, lst in rec.items():
         ms = sum(e0.elapsed_time(e1) for _, e0, e1 in lst)

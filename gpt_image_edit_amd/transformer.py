@@ -30,6 +30,9 @@ from . import flux_spec, ops
 BF16 = torch.bfloat16
 # FK_FUSE_QKV=0 keeps RMSNorm+RoPE as the separate fk_qkv_post_bf16 pass (A/B measurement, identical results)
 FUSE_QKV = os.environ.get("FK_FUSE_QKV", "1") != "0"
+# FK_OVERLAP_MLP=0 / 1: never / always run the single blocks' MLP-up GEMM on a second stream (A/B measurement, identical
+# results); default "auto": by the attention grid's last-round waste (HipFluxTransformer2DModel._overlap_pays)
+OVERLAP_MLP = {"0": False, "1": True}.get(os.environ.get("FK_OVERLAP_MLP", "auto"), "auto")
 
 
 def rope_tables(ids, axes_dim=(16, 56, 56), theta=10000.0):
@@ -156,6 +159,21 @@ class HipFluxTransformer2DModel(nn.Module):
         )
         self._ws = {key: ws}  # keep only the latest shape
         return ws
+
+    def _overlap_pays(self, B, S, cus=256):
+        """Second stream for the single blocks' MLP-up GEMM?  Yes when the attention grid (256 query rows per workgroup,
+        one workgroup per CU) needs more than one round and leaves >= 8 % of its rounds' CU-time empty."""
+        nwg = B * self.num_heads * ((S + 255) // 256)
+        rounds = (nwg + cus - 1) // cus
+        return nwg > cus and (rounds * cus - nwg) / (rounds * cus) >= 0.08
+
+    def _side_stream(self):
+        st = self.__dict__.get("_side")
+        if st is None:
+            st = torch.cuda.Stream(device=self.device)
+            self.__dict__["_side"] = st
+            self.__dict__["_side_events"] = (torch.cuda.Event(), torch.cuda.Event())
+        return st
 
     def _rope(self, txt_ids, img_ids, packed=False):
         # Step-invariant: keyed on the identity of the id tensors (the pipeline passes the same objects for
@@ -305,10 +323,29 @@ class HipFluxTransformer2DModel(nn.Module):
                                    out=cx, res=cx, gate=chunk(mt, 5))], epilogue=ops.FK_EPI_GATE_RES)
 
         # -- single-stream blocks on the joint sequence ------------------------------------------------------
+        # Every launch is a grid of whole-CU workgroups that runs in rounds of 256; at batch 1 the last round of each is
+        # partly empty (attention 240 / 816 workgroups, GEMMs 1.6-6.4 rounds).  The block's MLP-up GEMM depends only on
+        # the normalised input, so it goes to a second stream and its tiles fill the CUs the QKV GEMM's and the
+        # attention's last rounds leave idle; one event pair per block, same kernels, same numbers.  Measured (one box,
+        # images/s without / with): S = 2560 0.977 / 0.959, S = 5632 0.355 / 0.370, S = 8704 0.238 / 0.244 -- it pays
+        # where the attention grid wastes a good part of its last round, and costs where one round holds everything.
+        use_side = self._overlap_pays(B, ws.S) if OVERLAP_MLP == "auto" else OVERLAP_MLP
+        side = self._side_stream() if use_side else None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            ev_n, ev_mlp = self._side_events
         for i, blk in enumerate(pk.single):
             p = f"single_transformer_blocks.{i}."
             m0 = blk.mod  # chunks: shift, scale, gate
             ops.ln_modulate(s, chunk(m0, 0), chunk(m0, 1), out=n)
+            if side is not None:
+                # the MLP branch needs only n: it runs beside the QKV projection and the attention
+                ev_n.record(main)
+                side.wait_event(ev_n)
+                with torch.cuda.stream(side):
+                    ops.gemm(n, P(p + "proj_mlp.weight"), P(p + "proj_mlp.bias"), out=ws.cat[:, :, D:],
+                             epilogue=ops.FK_EPI_GELU_TANH)
+                    ev_mlp.record(side)
             if FUSE_QKV:
                 ops.gemm(n, blk.wqkv, blk.bqkv, out=ws.qkv, epilogue=ops.FK_EPI_QKV,
                          qkv=dict(q_out=ws.q, k_out=ws.k, wq=P(p + "attn.norm_q.weight"),
@@ -317,9 +354,12 @@ class HipFluxTransformer2DModel(nn.Module):
                 ops.gemm(n, blk.wqkv, blk.bqkv, out=ws.qkv)
                 ops.qkv_post(ws.qkv, ws.q, ws.k, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"), None, None,
                              cos, sin, 0)
-            ops.gemm(n, P(p + "proj_mlp.weight"), P(p + "proj_mlp.bias"), out=ws.cat[:, :, D:],
-                     epilogue=ops.FK_EPI_GELU_TANH)
             ops.attention(ws.q, ws.k, ws.qkv[:, :, 2 * D:], ws.cat[:, :, :D])
+            if side is not None:
+                main.wait_event(ev_mlp)
+            else:
+                ops.gemm(n, P(p + "proj_mlp.weight"), P(p + "proj_mlp.bias"), out=ws.cat[:, :, D:],
+                         epilogue=ops.FK_EPI_GELU_TANH)
             ops.gemm(ws.cat, P(p + "proj_out.weight"), P(p + "proj_out.bias"), out=s,
                      epilogue=ops.FK_EPI_GATE_RES, res=s, gate=chunk(m0, 2))
 

@@ -86,3 +86,17 @@ def test_pack_rope_is_the_per_pair_view_of_the_flux_tables():
         ops.pack_rope(bad, sin)
     with pytest.raises(ValueError):
         ops.pack_rope(cos[:, :64], sin[:, :64])
+
+
+def test_second_stream_policy_follows_the_attention_grid():
+    """HipFluxTransformer2DModel._overlap_pays (host logic): the single blocks' MLP-up GEMM goes to a second stream only
+    where the attention grid wastes a good part of its last round (measured: pays at S = 5632 / 8704, B = 1; costs at
+    S = 2560)."""
+    from types import SimpleNamespace
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel as M
+    m = SimpleNamespace(num_heads=24)
+    assert not M._overlap_pays(m, 1, 2560)        # 240 workgroups: one round
+    assert M._overlap_pays(m, 1, 5632)            # 528: 2.06 rounds
+    assert M._overlap_pays(m, 1, 8704)            # 816: 3.19 rounds
+    assert not M._overlap_pays(m, 4, 8704)        # 12.75 rounds: 2 % waste
+    assert not M._overlap_pays(m, 32, 8704)
