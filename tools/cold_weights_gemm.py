@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpt_image_edit_amd import ops  # noqa: E402
 
 BF = torch.bfloat16
-NRING = 12
+NRING = int(os.environ.get("NRING", "12"))   # 2-3 weights still fit the 256 MiB Infinity Cache together
 
 
 def rate(fn, fl, n_per):
