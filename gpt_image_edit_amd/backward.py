@@ -296,7 +296,7 @@ class FluxBackward:
                           dict(a=dy[:, txt], w=self.wT(p + "attn.to_add_out.weight"), out=do[:, txt])])
         o, lse = sv.o_ckpt[i], sv.lse_ckpt[i]
         if p + "attn.to_out.0.weight" in self.trainable:
-            grads[p + "attn.to_out.0.weight"] = self._wgrad(dy[:, img], o[:, img]).clone()
+            grads[p + "attn.to_out.0.weight"] = self._wgrad(dy[:, img], o[:, img])     # ops.gemm hands out a fresh tensor
             grads[p + "attn.to_out.0.bias"] = ops.colsum(dy[:, img])
         # -- joint attention
         dqkv = self._b("dqkv", (B, S, 3 * D))
@@ -313,7 +313,7 @@ class FluxBackward:
             dwqkv = self._wgrad(dqkv[:, img], n1[:, img])
             dbqkv = ops.colsum(dqkv[:, img])
             for k, nm in enumerate(("to_q", "to_k", "to_v")):
-                grads[p + f"attn.{nm}.weight"] = dwqkv[k * D:(k + 1) * D].clone()
+                grads[p + f"attn.{nm}.weight"] = dwqkv[k * D:(k + 1) * D]     # row blocks of this block's own [3D, D] gradient
                 grads[p + f"attn.{nm}.bias"] = dbqkv[k * D:(k + 1) * D].clone()
         ops.ln_modulate_bwd(x0[:, img], dn[:, img], ch(mi, 1), g[:, img], dm_i[:, 0:2 * D], dx_in=g[:, img])
         ops.ln_modulate_bwd(x0[:, txt], dn[:, txt], ch(mt, 1), g[:, txt], dm_t[:, 0:2 * D], dx_in=g[:, txt])
@@ -367,16 +367,16 @@ class FluxBackward:
             dwqkv = self._wgrad(dqkv, n1)
             dbqkv = ops.colsum(dqkv)
             for k, nm in enumerate(("to_q", "to_k", "to_v")):
-                grads[p + f"attn.{nm}.weight"] = dwqkv[k * D:(k + 1) * D].clone()
+                grads[p + f"attn.{nm}.weight"] = dwqkv[k * D:(k + 1) * D]     # row blocks of this block's own [3D, D] gradient
                 grads[p + f"attn.{nm}.bias"] = dbqkv[k * D:(k + 1) * D].clone()
         if p + "proj_mlp.weight" in self.trainable:
-            grads[p + "proj_mlp.weight"] = self._wgrad(dff, n1).clone()
+            grads[p + "proj_mlp.weight"] = self._wgrad(dff, n1)
             grads[p + "proj_mlp.bias"] = ops.colsum(dff)
         if p + "proj_out.weight" in self.trainable:
             if sv.store:   # cat is shared scratch: rebuild [attn | gelu(mlp)] of this block
                 ws.cat[:, :, :D].copy_(o)
                 ops.gelu_tanh(h1, ws.cat[:, :, D:])
-            grads[p + "proj_out.weight"] = self._wgrad(dy, ws.cat).clone()
+            grads[p + "proj_out.weight"] = self._wgrad(dy, ws.cat)
             grads[p + "proj_out.bias"] = ops.colsum(dy)
         ops.ln_modulate_bwd(x0, dn, ch(1), g, dmod[:, 0:2 * D], dx_in=g)
         if p + "norm.linear.weight" in self.trainable:
