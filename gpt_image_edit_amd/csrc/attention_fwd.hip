@@ -502,13 +502,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
   }
 }
 
-// One-wave-per-SIMD schedules (experimental/attention4_fwd.hip: two query blocks per wave half a tile apart;
-// experimental/attention5_fwd.hip: one block, softmax of tile u+1 under the MFMAs of tile u; both with a fixed
-// exponent reference instead of the running rescale, padded LDS rows and register staging) are correct but slower
-// (630-830 and 540-660 TF/s against 790-1060 here): the softmax costs >= 4 VALU instructions per score element,
-// i.e. 7-8 issue slots per MFMA once S read-out, LDS reads and staging are added, more than the 5 that fit an MFMA
-// shadow -- with two waves per SIMD the hardware overlaps one wave's VALU with the other's MFMAs at no issue cost.
-// Not built; kept as a starting point for a hand-allocated version.
+// One-wave-per-SIMD schedules (round 1, git history: two query blocks per wave half a tile apart; one block with the
+// softmax of tile u+1 under the MFMAs of tile u; both with a fixed exponent reference, padded LDS rows and register
+// staging) are correct but slower (630-830 and 540-660 TF/s against 790-1060 here): with a single wave on a SIMD every
+// instruction of the stream -- S read-out, LDS reads, staging, softmax -- takes an issue slot of its own, 7-8 per MFMA
+// against the 5 that fit an MFMA shadow; with two waves per SIMD the hardware overlaps one wave's VALU with the
+// other's MFMAs at no issue cost.
 //
 // Round 2: the two-group ("ping-pong") structure that took the GEMM to 89 % MFMA-busy -- groups of 4 waves alternating
 // between a 16-MFMA phase from registers (S^T of block b+1 and O^T += V^T P^T of block b) and a softmax + LDS-read
@@ -517,10 +516,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
 // MFMA phase starves of issue slots (with s_setprio on the MFMA phase another -3 %), and every phase boundary pays an
 // LDS round trip; free-running waves overlap better than barrier-enforced alternation here.  Removed (git history).
 //
-// Measured dead ends (kept out of the tree, see git history): (1) issuing QK^T of tile t+1 before the softmax
-// of tile t inside one wave (register pressure -> spills, compiler does not interleave: 760 TF vs 844);
-// (2) rotating waves 4..7 by one phase so that softmax of one wave meets MFMA of its SIMD partner
-// (4-stage ring): 725 TF vs 844.  PMC: matrix pipe 48 % busy, VALU 52 %, no LDS bank conflicts.
+// Round-1 dead ends (git history): (1) issuing QK^T of tile t+1 before the softmax of tile t inside one wave WITHOUT
+// pinning the order (spills, the compiler does not interleave: 760 TF vs 844) -- the ILV order above is its working
+// form, within one tile and pinned by sched_group_barrier; (2) rotating waves 4..7 by one phase so that softmax of one
+// wave meets MFMA of its SIMD partner (4-stage ring): 725 TF vs 844.
+// Round-2 probes of the main loop (profiles/r02_attention_variants.txt): v_pk_fma/v_pk_add_f32 for the scale-shift and
+// the row sums (25 fewer VALU per tile) 3-5 % slower; operand fragments read 3-4 MFMAs ahead: no gain; no per-tile
+// barrier (timing probe): +1..6 %.  Counters at B = 4, S = 8704: matrix pipe 52 % busy at 1.86 GHz, waves 37 % parked,
+// 32 % issue-stalled, LDS array ~26 % busy, no bank conflicts.
 
 template <int NW, int STAGES, bool F32OUT, bool ILV>
 int launch(const AttnParams& p, hipStream_t stream) {

@@ -719,7 +719,7 @@ int fk_gemm_last_variant(void) { return g_last_variant; }
 // bn_hint: 128 / 256 force the N tile; 0 = choose per problem.  The 256 x 256 kernel has the higher steady-state
 // rate (measured 1.1-1.2x for large grids), but one workgroup per CU means the grid runs in rounds of #CUs tiles:
 // pick the tile with the better (quantisation efficiency) x (rate).  (A stream-K form of the 256 x 256 kernel that
-// shares the last round's K-iterations among all CUs was built and measured slower: experimental/README.md.)
+// shares the last round's K-iterations among all CUs was built in round 1 and measured 2x slower: DESIGN.md section 4b; git history.)
 int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t stream) {
   GroupArgs ga;
   ga.n = n;
