@@ -1,6 +1,6 @@
 """Within-process interleaved A/B of the large-tile GEMM kernels (fk_gemm_set_variant) and the vendor library on the
 path's shapes: N rounds, every variant once per round, ~0.12 s of back-to-back launches per measurement; prints the
-median and the best TF/s per (shape, variant).  `python tools/ab_gemm8.py [rounds] [epi]`."""
+median and the best TF/s per (shape, variant).  `python tools/ab_gemm_variants.py [rounds] [epi]`."""
 import os
 import statistics
 import sys
