@@ -89,6 +89,32 @@ def test_forward_outputs_do_not_alias():
     assert torch.equal(pos, keep) and not torch.equal(pos, neg)
 
 
+def test_second_stream_gives_the_same_bits():
+    """The single blocks' MLP-up GEMM on the second stream (transformer.OVERLAP_MLP; chosen automatically at S = 5632 /
+    8704, B = 1) is the same launches in another order: forced on and forced off must agree bit for bit, call after
+    call (the event pair per block is what orders the two streams)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd import flux_spec, transformer
+    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=1, num_single_layers=3)
+    model = transformer.HipFluxTransformer2DModel(cfg, device="cuda", init="synthetic", seed=3)
+    hs, enc, pooled, t, gd, img_ids, txt_ids = _inputs(1, 200, 24, 24, cfg, seed=5)       # S = 1352
+    kw = dict(hidden_states=hs.cuda(), timestep=t.cuda(), guidance=gd.cuda(), pooled_projections=pooled.cuda(),
+              encoder_hidden_states=enc.cuda(), txt_ids=txt_ids.cuda(), img_ids=img_ids.cuda(), return_dict=False)
+    saved = transformer.OVERLAP_MLP
+    try:
+        outs = []
+        for mode in (False, True, True, False, True):
+            transformer.OVERLAP_MLP = mode
+            outs.append(model(**kw)[0].clone())
+        torch.cuda.synchronize()
+    finally:
+        transformer.OVERLAP_MLP = saved
+    assert torch.isfinite(outs[0].float()).all()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 def test_state_dict_roundtrip_and_seam():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
