@@ -100,3 +100,21 @@ def test_second_stream_policy_follows_the_attention_grid():
     assert M._overlap_pays(m, 1, 8704)            # 816: 3.19 rounds
     assert not M._overlap_pays(m, 4, 8704)        # 12.75 rounds: 2 % waste
     assert not M._overlap_pays(m, 32, 8704)
+
+
+def test_committed_traffic_side_file_matches_its_source(tmp_path):
+    """profiles/r02_traffic.json (what bench.py reports as roofline.traffic) must be exactly what tools/traffic_json.py
+    derives from the committed counter summary profiles/r02_traffic_items.json -- no hand-edited numbers."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    shutil.copy(os.path.join(ROOT, "profiles", "r02_traffic_items.json"), tmp_path / "t_items.json")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "traffic_json.py"), str(tmp_path / "t")], check=True,
+                   capture_output=True)
+    got = json.load(open(tmp_path / "t.json"))
+    want = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+    assert got == want
+    ent = want["gemm"]["cfg2_single_512x512_28step"]
+    assert ent["hbm_bytes_per_launch"] > ent["algorithmic_bytes_per_launch"] > 0
+    assert "gemm9_kernel" in ent["note"] or "gemm8_kernel" in ent["note"]     # counters of the CURRENT kernels
