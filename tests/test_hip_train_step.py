@@ -64,6 +64,15 @@ def test_backward_matches_autograd_and_adamw_step():
         # bf16 autograd than either sits to fp32 autograd
         assert e_bf <= max(0.6 * e_floor, 2e-2), f"{k}: HIP gradient {e_bf:.3e} from bf16 autograd (floor {e_floor:.3e})"
     print(f"worst hip / floor ratio {worst:.2f}; worst (hip vs bf16 autograd) / floor {worst_bf:.2f}")
+    # the gradient w.r.t. prompt_embeds -- what the denoise_projector's backward continues from -- against autograd too
+
+    def d_prompt(sd, b):
+        pe = b["prompt_embeds"].detach().clone().requires_grad_(True)
+        return torch.autograd.grad(otrain.denoiser_loss(sd, **dict(b, prompt_embeds=pe), flux_config=cfg), pe)[0]
+    dp32, dpbf = d_prompt(sd32, b32), d_prompt(sd_bf, batch)
+    e_hip, e_floor, e_bf = _rel(d_enc.cpu(), dp32), _rel(dpbf, dp32), _rel(d_enc.cpu(), dpbf)
+    print(f"[grad] {'d(prompt_embeds)':50s} hip-vs-fp32 {e_hip:.3e}  bf16-autograd floor {e_floor:.3e}  hip-vs-bf16-autograd {e_bf:.3e}")
+    assert e_hip <= max(2.0 * e_floor, 2e-2) and e_bf <= max(0.6 * e_floor, 2e-2)
     # the whole step: global-norm clipping + AdamW on fp32 masters, bf16 copies rewritten -- against the oracle's
     # optimiser arithmetic fed the SAME (HIP) gradients
     want_p, _, want_norm = otrain.adamw_step({k: sd32[k] for k in trainable}, {k: grads[k].float().cpu() for k in trainable},
