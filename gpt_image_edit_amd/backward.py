@@ -39,13 +39,19 @@ def _pad64(n):
 
 def wgrad(buf, dy, x, out=None):
     """Weight gradient dW[N, K] = dY^T X over the rows of two [B, R, *] views: both operands transposed into K-major
-    buffers whose row count is padded to the GEMM's 64 (the pad columns stay zero), then one fk_gemm_bf16.
+    buffers whose row count is padded to the GEMM's 64 (pad columns zeroed on every call), then one fk_gemm_bf16.
     ``buf(name, shape, zero=...)`` hands out the caller's cached workspace tensors."""
     B, R, N = dy.shape
     K = x.shape[-1]
     Mp = _pad64(B * R)
     dyT = buf(f"dyT{N}x{Mp}", (N, Mp), zero=True)
     xT = buf(f"xT{K}x{Mp}", (K, Mp), zero=True)
+    if B * R < Mp:
+        # the buffers are shared by every call whose token count pads to the same multiple of 64 (VLM length 310, then
+        # 300: both 320) and fk_transpose_bf16 writes only the B*R real columns: clear the <= 63 pad columns each time,
+        # or the previous call's tail would be multiplied into this gradient
+        dyT[:, B * R:].zero_()
+        xT[:, B * R:].zero_()
     ops.transpose(dy, torch.as_strided(dyT, (B, N, R), (R, Mp, 1)))
     ops.transpose(x, torch.as_strided(xT, (B, K, R), (R, Mp, 1)))
     return ops.gemm(dyT, xT, out=out)
@@ -61,29 +67,50 @@ class FluxBackward:
         from . import training
         self.store_activations, self.activation_budget = store_activations, activation_budget_bytes
         self.m = model
-        names = list(model.state_dict().keys())
+        names = list(model._pmap.keys())
         self.trainable = set(trainable if trainable is not None else training.trainable_names(names))
-        self._wT = {}          # name -> W^T (bf16 [in, out]) for the data gradients
+        # every parameter of the 57 blocks has a weight gradient here; the embedders, norm_out and the output
+        # projection do not (the reference never un-freezes them: train_denoiser.py:74-76, :93-95 are commented out)
+        unsupported = sorted(k for k in self.trainable if not self.producible(k))
+        if unsupported:
+            raise NotImplementedError(
+                "FluxBackward has no weight gradient for " + ", ".join(unsupported[:6]) + (" ..." if len(unsupported) > 6 else "")
+                + ": trainable parameters must belong to transformer_blocks.* / single_transformer_blocks.*")
+        self._wT = {}          # name -> (W^T (bf16 [in, out]) for the data gradients, stamp of its source)
         self._buf = {}
         self._saved = None
 
     # ---- transposed weights ------------------------------------------------------------------------------------------
-    def _transposed(self, key, w):
-        t = self._wT.get(key)
-        if t is None:
-            t = torch.empty((w.shape[1], w.shape[0]), device=w.device, dtype=BF16)
+    @staticmethod
+    def producible(name):
+        return name.startswith("transformer_blocks.") or name.startswith("single_transformer_blocks.")
+
+    def _transposed(self, key, w, stamp=None):
+        """W^T for the data gradient, re-made when its source was rewritten (an optimiser step bumps the parameter's
+        version; a re-pack of the fused QKV weights gets a new serial)."""
+        if stamp is None:
+            stamp = (w.data_ptr(), w._version)
+        hit = self._wT.get(key)
+        if hit is None or hit[1] != stamp:
+            t = hit[0] if hit is not None else torch.empty((w.shape[1], w.shape[0]), device=w.device, dtype=BF16)
             ops.transpose(w.unsqueeze(0), t.unsqueeze(0))
-            self._wT[key] = t
-        return t
+            hit = (t, stamp)
+            self._wT[key] = hit
+        return hit[0]
 
     def wT(self, name):
         return self._transposed(name, self.m.p(name))
 
+    def _packedT(self, key, w, pk):
+        return self._transposed("packed:" + key, w, stamp=("pack", pk.serial))
+
     def refresh(self):
-        """After an optimiser step: drop the transposes (and the model's fused copies) of the trainable weights."""
-        for k in list(self._wT):
+        """After an optimiser step through libfk (``fk_adamw_step`` rewrites the bf16 parameters through raw pointers,
+        which torch's version counters do not see): invalidate the transposes of the trainable weights and the model's
+        fused copies.  Updates made by torch itself (a stock optimiser, an all-gather) are caught by the stamps."""
+        for k, (t, _) in list(self._wT.items()):
             if k in self.trainable or k.startswith("packed:"):
-                del self._wT[k]
+                self._wT[k] = (t, None)
         self.m._packed = None
 
     # ---- buffers ---------------------------------------------------------------------------------------------------
@@ -128,7 +155,7 @@ class FluxBackward:
     @torch.no_grad()
     def forward(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids, guidance):
         m, P = self.m, self.m.p
-        pk = m._packed or m.pack_weights()
+        pk = m.packed()
         D = m.inner_dim
         B, S_img, _ = hidden_states.shape
         S_txt = encoder_hidden_states.shape[1]
@@ -281,9 +308,21 @@ class FluxBackward:
         # -- MLP: x2 = x1 + gate_mlp * y2
         ops.gate_res_bwd(g[:, img], y2[:, img], ch(mi, 5), dy[:, img], dm_i[:, 5 * D:6 * D])
         ops.gate_res_bwd(g[:, txt], y2[:, txt], ch(mt, 5), dy[:, txt], dm_t[:, 5 * D:6 * D])
+        T = self.trainable
+        ffs = (("ff", img), ("ff_context", txt))      # only_tune_image_branch: false (train_denoiser.py:96-101) un-freezes the MLPs
+        if any(p + f"{ff}.net.2.weight" in T for ff, _ in ffs):
+            ops.gelu_tanh(h1, ws.ff)                  # ws.ff is shared scratch: this block's GELU output again
+            for ff, sl in ffs:
+                if p + f"{ff}.net.2.weight" in T:
+                    grads[p + f"{ff}.net.2.weight"] = self._wgrad(dy[:, sl], ws.ff[:, sl])
+                    grads[p + f"{ff}.net.2.bias"] = ops.colsum(dy[:, sl])
         ops.gemm_grouped([dict(a=dy[:, img], w=self.wT(p + "ff.net.2.weight"), out=dff[:, img]),
                           dict(a=dy[:, txt], w=self.wT(p + "ff_context.net.2.weight"), out=dff[:, txt])])
         ops.gelu_bwd(h1, dff, out=dff)
+        for ff, sl in ffs:
+            if p + f"{ff}.net.0.proj.weight" in T:
+                grads[p + f"{ff}.net.0.proj.weight"] = self._wgrad(dff[:, sl], n2[:, sl])
+                grads[p + f"{ff}.net.0.proj.bias"] = ops.colsum(dff[:, sl])
         ops.gemm_grouped([dict(a=dff[:, img], w=self.wT(p + "ff.net.0.proj.weight"), out=dn[:, img]),
                           dict(a=dff[:, txt], w=self.wT(p + "ff_context.net.0.proj.weight"), out=dn[:, txt])])
         ops.ln_modulate_bwd(x1[:, img], dn[:, img], ch(mi, 4), g[:, img], dm_i[:, 3 * D:5 * D], dx_in=g[:, img])
@@ -298,6 +337,9 @@ class FluxBackward:
         if p + "attn.to_out.0.weight" in self.trainable:
             grads[p + "attn.to_out.0.weight"] = self._wgrad(dy[:, img], o[:, img])     # ops.gemm hands out a fresh tensor
             grads[p + "attn.to_out.0.bias"] = ops.colsum(dy[:, img])
+        if p + "attn.to_add_out.weight" in self.trainable:
+            grads[p + "attn.to_add_out.weight"] = self._wgrad(dy[:, txt], o[:, txt])
+            grads[p + "attn.to_add_out.bias"] = ops.colsum(dy[:, txt])
         # -- joint attention
         dqkv = self._b("dqkv", (B, S, 3 * D))
         dq, dk = self._b("dq", (B, H, S, 128)), self._b("dk", (B, H, S, 128))
@@ -307,13 +349,19 @@ class FluxBackward:
                               P(p + "attn.norm_added_q.weight"), P(p + "attn.norm_added_k.weight"), sv.cos, sv.sin, S_txt)
         grads[p + "attn.norm_q.weight"], grads[p + "attn.norm_k.weight"] = dw[0, 0].clone(), dw[1, 0].clone()
         grads[p + "attn.norm_added_q.weight"], grads[p + "attn.norm_added_k.weight"] = dw[0, 1].clone(), dw[1, 1].clone()
-        ops.gemm_grouped([dict(a=dqkv[:, img], w=self._transposed("packed:" + p + "qkv_img", blk.wqkv_img), out=dn[:, img]),
-                          dict(a=dqkv[:, txt], w=self._transposed("packed:" + p + "qkv_txt", blk.wqkv_txt), out=dn[:, txt])])
+        ops.gemm_grouped([dict(a=dqkv[:, img], w=self._packedT(p + "qkv_img", blk.wqkv_img, pk), out=dn[:, img]),
+                          dict(a=dqkv[:, txt], w=self._packedT(p + "qkv_txt", blk.wqkv_txt, pk), out=dn[:, txt])])
         if p + "attn.to_q.weight" in self.trainable:
             dwqkv = self._wgrad(dqkv[:, img], n1[:, img])
             dbqkv = ops.colsum(dqkv[:, img])
             for k, nm in enumerate(("to_q", "to_k", "to_v")):
                 grads[p + f"attn.{nm}.weight"] = dwqkv[k * D:(k + 1) * D]     # row blocks of this block's own [3D, D] gradient
+                grads[p + f"attn.{nm}.bias"] = dbqkv[k * D:(k + 1) * D].clone()
+        if p + "attn.add_q_proj.weight" in self.trainable:
+            dwqkv = self._wgrad(dqkv[:, txt], n1[:, txt])
+            dbqkv = ops.colsum(dqkv[:, txt])
+            for k, nm in enumerate(("add_q_proj", "add_k_proj", "add_v_proj")):
+                grads[p + f"attn.{nm}.weight"] = dwqkv[k * D:(k + 1) * D]
                 grads[p + f"attn.{nm}.bias"] = dbqkv[k * D:(k + 1) * D].clone()
         ops.ln_modulate_bwd(x0[:, img], dn[:, img], ch(mi, 1), g[:, img], dm_i[:, 0:2 * D], dx_in=g[:, img])
         ops.ln_modulate_bwd(x0[:, txt], dn[:, txt], ch(mt, 1), g[:, txt], dm_t[:, 0:2 * D], dx_in=g[:, txt])
@@ -361,7 +409,7 @@ class FluxBackward:
         dw = ops.qkv_post_bwd(dq, dk, bb.qkv, dqkv, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"), None, None,
                               sv.cos, sv.sin, 0)
         grads[p + "attn.norm_q.weight"], grads[p + "attn.norm_k.weight"] = dw[0, 0].clone(), dw[1, 0].clone()
-        ops.gemm(dqkv, self._transposed("packed:" + p + "qkv", blk.wqkv), out=dn)
+        ops.gemm(dqkv, self._packedT(p + "qkv", blk.wqkv, pk), out=dn)
         ops.gemm(dff, self.wT(p + "proj_mlp.weight"), out=dn, epilogue=ops.FK_EPI_RES, res=dn)
         if p + "attn.to_q.weight" in self.trainable:
             dwqkv = self._wgrad(dqkv, n1)
@@ -381,3 +429,34 @@ class FluxBackward:
         ops.ln_modulate_bwd(x0, dn, ch(1), g, dmod[:, 0:2 * D], dx_in=g)
         if p + "norm.linear.weight" in self.trainable:
             grads[p + "norm.linear.weight"], grads[p + "norm.linear.bias"] = self._mod_grads(dmod, ws.act)
+
+
+class FluxTrainFunction(torch.autograd.Function):
+    """ONE autograd node for the whole MMDiT: forward = ``FluxBackward.forward``, backward = ``FluxBackward.backward``.
+
+    This is what lets the reference's loop drive the HIP model unchanged: ``model_pred = denoiser(...)`` builds the
+    node, ``accelerator.backward(loss)`` (``train_denoiser.py:1172``) reaches it with d loss / d sample, and the
+    gradients come back as the node's outputs for the parameters passed in (the ones the reference's
+    ``named_modules()`` loop un-froze, ``:538-543``) and for ``encoder_hidden_states`` (-> the ``denoise_projector``
+    and, if it were trainable, the VLM).  Weight gradients are bf16 like the parameters; bias / norm / modulation
+    gradients are reduced in fp32 and rounded once.  No gradient flows to ``hidden_states`` (the noisy latents)."""
+
+    @staticmethod
+    def forward(ctx, bw, names, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
+                guidance, *params):
+        ctx.bw, ctx.names = bw, names
+        ctx.enc_dtype = encoder_hidden_states.dtype
+        ctx.need_enc = encoder_hidden_states.requires_grad
+        return bw.forward(hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids, guidance)
+
+    @staticmethod
+    def backward(ctx, dsample):
+        grads, d_enc = ctx.bw.backward(dsample.contiguous())
+        out = []
+        for n in ctx.names:
+            g = grads.get(n)
+            if g is None:
+                raise RuntimeError(f"FluxBackward produced no gradient for {n}")
+            out.append(g if g.dtype == BF16 else g.to(BF16))
+        d_enc = d_enc.to(ctx.enc_dtype) if ctx.need_enc else None
+        return (None, None, None, d_enc, None, None, None, None, None, *out)

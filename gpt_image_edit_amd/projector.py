@@ -14,11 +14,12 @@ import torch
 from torch import nn
 
 from . import flux_spec, ops
+from .param_tree import ParamTreeMixin, build_param_tree
 
 BF16 = torch.bfloat16
 
 
-class HipDenoiseProjector(nn.Module):
+class HipDenoiseProjector(ParamTreeMixin, nn.Module):
     def __init__(self, input_hidden_size=3584, output_hidden_size=4096, device="cuda", init="empty", seed=0):
         super().__init__()
         shapes = {k[len("denoise_projector."):]: v
@@ -27,15 +28,10 @@ class HipDenoiseProjector(nn.Module):
             state = flux_spec.synthetic_state(shapes, seed=seed, device=device, dtype=BF16)
         else:
             state = {k: torch.empty(s, device=device, dtype=BF16) for k, s in shapes.items()}
-        for k, v in state.items():
-            self.register_parameter(k.replace(".", "__"), nn.Parameter(v, requires_grad=False))
-
-    def state_dict(self, *args, **kwargs):
-        sd = super().state_dict(*args, **kwargs)
-        return type(sd)((k.replace("__", "."), v) for k, v in sd.items())
+        self.__dict__["_pmap"] = build_param_tree(self, state, requires_grad=False)   # children "0" and "2", as nn.Sequential
 
     def load_state_dict(self, state_dict, strict=True, **kwargs):
-        return super().load_state_dict({k.replace(".", "__"): v.to(BF16) for k, v in state_dict.items()}, strict=strict, **kwargs)
+        return super().load_state_dict({k: v.to(BF16) for k, v in state_dict.items()}, strict=strict, **kwargs)
 
     @torch.no_grad()
     def forward(self, hidden_states):
@@ -46,15 +42,11 @@ class HipDenoiseProjector(nn.Module):
         squeeze = x.dim() == 2
         if squeeze:
             x = x.unsqueeze(0)
-        h = ops.gemm(x, getattr(self, "0__weight"), getattr(self, "0__bias"), epilogue=ops.FK_EPI_SILU)
-        y = ops.gemm(h, getattr(self, "2__weight"), getattr(self, "2__bias"))
+        h = ops.gemm(x, self.p("0.weight"), self.p("0.bias"), epilogue=ops.FK_EPI_SILU)
+        y = ops.gemm(h, self.p("2.weight"), self.p("2.bias"))
         return y[0] if squeeze else y
 
     # ---- training ---------------------------------------------------------------------------------------------------
-    def p(self, name):
-        """Parameter by its Sequential name (``0.weight`` ...)."""
-        return getattr(self, name.replace(".", "__"))
-
     def _b(self, name, shape, dtype=BF16, zero=False):
         bufs = self.__dict__.setdefault("_train_bufs", {})
         t = bufs.get(name)

@@ -26,6 +26,7 @@ import torch
 from torch import nn
 
 from . import flux_spec, ops
+from .param_tree import ParamTreeMixin, build_param_tree
 
 BF16 = torch.bfloat16
 # FK_FUSE_QKV=0 keeps RMSNorm+RoPE as the separate fk_qkv_post_bf16 pass (A/B measurement, identical results)
@@ -52,7 +53,11 @@ def rope_tables(ids, axes_dim=(16, 56, 56), theta=10000.0):
     return torch.cat(cos_parts, dim=1).contiguous(), torch.cat(sin_parts, dim=1).contiguous()
 
 
-class HipFluxTransformer2DModel(nn.Module):
+class HipFluxTransformer2DModel(ParamTreeMixin, nn.Module):
+    """Module tree = the diffusers ``FluxTransformer2DModel``'s: ``transformer_blocks.{i}.attn.to_q`` ... are
+    parameter-holding sub-modules (``param_tree.ParamNode``), so the reference's ``named_modules()`` selection
+    (``train_denoiser.py:538-543``), ``named_parameters()`` and ``state_dict()`` see the names of Appendix C."""
+
     def __init__(self, config=None, device="cuda", dtype=BF16, init="empty", seed=0):
         super().__init__()
         if dtype != BF16:
@@ -71,25 +76,17 @@ class HipFluxTransformer2DModel(nn.Module):
         else:
             state = {k: torch.empty(s, device=device, dtype=dtype) for k, s in shapes.items()}
         self._names = list(shapes.keys())
-        for k, v in state.items():
-            self.register_parameter(k.replace(".", "__"), nn.Parameter(v, requires_grad=False))
+        self.__dict__["_pmap"] = build_param_tree(self, state, requires_grad=False)
         self._packed = None
         self._ws = {}
         self._rope_cache = {}
         self._freqs = None
         self._cond = None
 
-    # ---- state dict with the diffusers key names --------------------------------------------------------
-    def p(self, name):
-        return getattr(self, name.replace(".", "__"))
-
-    def state_dict(self, *args, **kwargs):
-        sd = super().state_dict(*args, **kwargs)
-        return type(sd)((k.replace("__", "."), v) for k, v in sd.items())
-
+    # ---- state dict: the module tree carries the diffusers key names (no mangling) ----------------------------
     def load_state_dict(self, state_dict, strict=True, **kwargs):
         self._packed = None
-        return super().load_state_dict({k.replace(".", "__"): v for k, v in state_dict.items()}, strict=strict, **kwargs)
+        return super().load_state_dict(state_dict, strict=strict, **kwargs)
 
     @property
     def dtype(self):
@@ -108,9 +105,30 @@ class HipFluxTransformer2DModel(nn.Module):
         return super()._apply(fn, *a, **k)
 
     # ---- one-time weight packing (fused QKV, all-block modulation) -----------------------------------------
+    def packed(self):
+        """The fused copies, rebuilt when a source parameter was rewritten since they were made (an optimiser step,
+        ``param.data = ...``, an all-gather into the flat ZeRO buffer): the check is one (data_ptr, version) tuple."""
+        pk = self._packed
+        if pk is None or pk.versions != self.param_versions(pk.sources):
+            pk = self.pack_weights()
+        return pk
+
     def pack_weights(self):
         c, D = self.config, self.inner_dim
         pk = SimpleNamespace(double=[], single=[])
+        sources = []
+        for i in range(c.num_layers):
+            p = f"transformer_blocks.{i}."
+            sources += [p + f"attn.{n}.{wb}" for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj")
+                        for wb in ("weight", "bias")]
+            sources += [p + f"{n}.linear.{wb}" for n in ("norm1", "norm1_context") for wb in ("weight", "bias")]
+        for i in range(c.num_single_layers):
+            p = f"single_transformer_blocks.{i}."
+            sources += [p + f"attn.{n}.{wb}" for n in ("to_q", "to_k", "to_v") for wb in ("weight", "bias")]
+            sources += [p + f"norm.linear.{wb}" for wb in ("weight", "bias")]
+        sources += ["norm_out.linear.weight", "norm_out.linear.bias"]
+        pk.sources, pk.versions = sources, self.param_versions(sources)
+        self.__dict__["_pack_serial"] = pk.serial = self.__dict__.get("_pack_serial", 0) + 1
         mod_w, mod_b, off = [], [], 0
         for i in range(c.num_layers):
             p = f"transformer_blocks.{i}."
@@ -227,7 +245,7 @@ class HipFluxTransformer2DModel(nn.Module):
         N times).  A later ``forward(timestep=timesteps[i], guidance=guidance, pooled_projections=...)`` with
         these very tensors reuses row i; any other call computes its conditioning on the fly.  Every row goes
         through the same kernels as the per-step path, so results are bit-identical."""
-        pk = self._packed or self.pack_weights()
+        pk = self.packed()
         N, B = timesteps.shape
         D, dev = self.inner_dim, self.device
         ts = timesteps.contiguous()
@@ -253,19 +271,56 @@ class HipFluxTransformer2DModel(nn.Module):
         return cd.mod[off // cd.step_bytes]
 
     # ---- forward ----------------------------------------------------------------------------------------
-    @torch.no_grad()
     def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None,
                 img_ids=None, txt_ids=None, guidance=None, joint_attention_kwargs=None, return_dict=True,
                 **unused):
         """Same arguments as diffusers' FluxTransformer2DModel.forward as called by the reference
-        pipeline (flux_pipeline.py:1067-1077).  ``timestep`` is t/1000.  Returns ``(sample,)``."""
+        pipeline (flux_pipeline.py:1067-1077) and training loop (train_denoiser.py:1095-1104, through
+        ``UnivaDenoiseTower.forward``).  ``timestep`` is t/1000.  Returns ``(sample,)``.
+
+        Under ``torch.enable_grad()`` with a parameter (or ``encoder_hidden_states``) that requires grad, the call
+        records ONE autograd node (``_FluxTrainFunction``): its forward is ``backward.FluxBackward.forward`` (the HIP
+        training forward), its backward ``FluxBackward.backward`` -- so the reference's ``accelerator.backward(loss)``
+        (``train_denoiser.py:1172``) fills ``.grad`` of exactly the parameters it un-froze and any stock optimiser
+        can step them.  Otherwise (inference) nothing is recorded."""
         if not hidden_states.is_cuda:
             raise RuntimeError("HipFluxTransformer2DModel needs GPU tensors: there is no CPU fallback")
         if joint_attention_kwargs and joint_attention_kwargs.get("attention_mask") is not None:
             raise NotImplementedError("attention_mask (padded multi-resolution training batches, train_denoiser.py:1086-1091) "
                                       "is not supported: batch equally sized samples (cfg 5 trains bs 1 per GPU)")
+        if torch.is_grad_enabled():
+            names = self.grad_parameter_names()
+            if names or (encoder_hidden_states is not None and encoder_hidden_states.requires_grad):
+                sample = self._forward_train(names, hidden_states, encoder_hidden_states, pooled_projections, timestep,
+                                             img_ids, txt_ids, guidance)
+                return SimpleNamespace(sample=sample) if return_dict else (sample,)
+        return self._forward_infer(hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
+                                   guidance, return_dict)
+
+    def grad_parameter_names(self):
+        """Names of the parameters with ``requires_grad`` (what the reference's selection loop un-froze)."""
+        return [n for n, prm in self._pmap.items() if prm.requires_grad]
+
+    def _forward_train(self, names, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
+                       guidance):
+        from .backward import FluxBackward, FluxTrainFunction
+        key = tuple(names)
+        bw = self.__dict__.get("_autograd_bw")
+        if bw is None or bw.trainable_key != key:
+            bw = FluxBackward(self, trainable=names,
+                              store_activations=False if self.gradient_checkpointing else "auto")
+            bw.trainable_key = key
+            self.__dict__["_autograd_bw"] = bw
+        bw.store_activations = False if self.gradient_checkpointing else "auto"
+        params = [self._pmap[n] for n in names]
+        return FluxTrainFunction.apply(bw, names, hidden_states, encoder_hidden_states, pooled_projections, timestep,
+                                       img_ids, txt_ids, guidance, *params)
+
+    @torch.no_grad()
+    def _forward_infer(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
+                       guidance, return_dict):
         c, D, H = self.config, self.inner_dim, self.num_heads
-        pk = self._packed or self.pack_weights()
+        pk = self.packed()
         B, S_img, _ = hidden_states.shape
         S_txt = encoder_hidden_states.shape[1]
         ws = self._workspace(B, S_txt, S_img)
@@ -380,10 +435,45 @@ class HipFluxTransformer2DModel(nn.Module):
             return (sample,)
         return SimpleNamespace(sample=sample)
 
-    # The reference training code calls this on the denoiser (train_denoiser.py:486).  The training path of this
-    # package (backward.FluxBackward / train_step.DenoiserTrainStep) ALWAYS keeps one checkpoint per block and
-    # recomputes the block in the backward pass, so there is nothing to switch: the call is accepted and recorded.
-    gradient_checkpointing = True
+    # The reference training code calls this on the denoiser (train_denoiser.py:486) because its 80 GB GPUs cannot hold
+    # a 1024^2 sample's activations.  Here it selects FluxBackward's recompute policy (one checkpoint per block, the
+    # block re-run in the backward pass: the reference's memory behaviour) for the autograd path; without the call the
+    # training forward keeps every block's intermediates when they fit the activation budget (37 GB at 1024^2, bs 1:
+    # sized for 288 GB of HBM) and nothing is recomputed.  Both policies give bit-identical gradients
+    # (tests/test_hip_train_step.py).  ``DenoiserTrainStep(store_activations=...)`` chooses explicitly.
+    gradient_checkpointing = False
 
     def enable_gradient_checkpointing(self):
         self.gradient_checkpointing = True
+
+    def disable_gradient_checkpointing(self):
+        self.gradient_checkpointing = False
+
+    # ---- HF-style checkpoint IO (train_denoiser.py:493 ``save_pretrained``; cli.py:64-68 ``from_pretrained``) -------
+    def save_pretrained(self, save_directory, max_shard_size=5 << 30, **unused):
+        """Write the diffusers layout of a transformer directory: ``config.json`` (``_class_name``
+        ``FluxTransformer2DModel``) + ``diffusion_pytorch_model*.safetensors`` with the keys of Appendix C."""
+        import json
+        import os as _os
+        from . import checkpoint
+        _os.makedirs(save_directory, exist_ok=True)
+        checkpoint.save_sharded(self.state_dict(), save_directory, max_shard_bytes=int(max_shard_size))
+        cfg = {"_class_name": "FluxTransformer2DModel", "_diffusers_version": "0.32.2"}
+        cfg.update({k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(self.config).items()})
+        with open(_os.path.join(save_directory, "config.json"), "w") as f:
+            json.dump(cfg, f, indent=1)
+        return save_directory
+
+    @classmethod
+    def from_pretrained(cls, directory, device="cuda", subfolder=None, torch_dtype=BF16, **unused):
+        """Load a transformer directory written by diffusers' / this class's ``save_pretrained`` (or a FLUX pipeline
+        directory with ``subfolder='transformer'``)."""
+        import os as _os
+        from . import checkpoint
+        d = _os.path.join(directory, subfolder) if subfolder else directory
+        cfg = checkpoint._config_of(d, flux_spec.FLUX_KONTEXT_CONFIG)
+        model = cls(config=cfg, device=device, dtype=torch_dtype, init="empty")
+        state = checkpoint.read_state_dict(d, dtype=BF16)
+        checkpoint.check_against(flux_spec.flux_param_shapes(cfg), state, f"FLUX transformer at {d}")
+        model.load_state_dict(state, strict=True)
+        return model

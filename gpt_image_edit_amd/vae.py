@@ -16,6 +16,7 @@ import torch
 from torch import nn
 
 from . import flux_spec, ops
+from .param_tree import ParamTreeMixin, build_param_tree
 
 BF16 = torch.bfloat16
 
@@ -55,7 +56,7 @@ class _LatentDist:
         return (self.mean.float() + std * eps).to(self.mean.dtype)
 
 
-class HipAutoencoderKL(nn.Module):
+class HipAutoencoderKL(ParamTreeMixin, nn.Module):
     def __init__(self, config=None, device="cuda", dtype=BF16, init="empty", seed=0):
         super().__init__()
         if dtype != BF16:
@@ -68,23 +69,12 @@ class HipAutoencoderKL(nn.Module):
             state = flux_spec.synthetic_state(shapes, seed=seed, device=device, dtype=dtype)
         else:
             state = {k: torch.empty(s, device=device, dtype=dtype) for k, s in shapes.items()}
-        for k, v in state.items():
-            self.register_parameter(k.replace(".", "__"), nn.Parameter(v, requires_grad=False))
+        self.__dict__["_pmap"] = build_param_tree(self, state, requires_grad=False)   # diffusers module / key names
         self._pk = None
-
-    def p(self, name):
-        return getattr(self, name.replace(".", "__"))
-
-    def has(self, name):
-        return hasattr(self, name.replace(".", "__"))
-
-    def state_dict(self, *args, **kwargs):
-        sd = super().state_dict(*args, **kwargs)
-        return type(sd)((k.replace("__", "."), v) for k, v in sd.items())
 
     def load_state_dict(self, state_dict, strict=True, **kwargs):
         self._pk = None
-        return super().load_state_dict({k.replace(".", "__"): v for k, v in state_dict.items()}, strict=strict, **kwargs)
+        return super().load_state_dict(state_dict, strict=strict, **kwargs)
 
     def _apply(self, fn, *a, **k):
         self._pk = None

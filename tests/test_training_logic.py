@@ -133,3 +133,65 @@ def test_oracle_train_step_selfpin(golden):
                                rtol=1e-3, atol=1e-8)
     np.testing.assert_allclose(res["params"]["single_transformer_blocks.0.attn.norm_q.weight"].numpy(),
                                golden["step_new_norm_q"], rtol=1e-6)
+
+
+def test_reference_named_modules_selection_drives_the_hip_model(golden):
+    """The reference un-freezes by MODULE name (train_denoiser.py:534-548): ``for name, module in
+    lvlm_model.named_modules(): if check_param_is_in_components(name, trainable_components):
+    module.requires_grad_(True)``, after ``lvlm_model.requires_grad_(False)`` (:478-479), then the projector by
+    parameter name (:545-548).  Run exactly that loop on the HIP model nested the way the reference nests it
+    (``lvlm_model.denoise_tower.denoiser`` / ``.denoise_projector``; meta device: names and shapes only) and
+    hold the resulting trainable set against the mask the reference's own functions produced (train.npz)."""
+    from torch import nn
+    from gpt_image_edit_amd.projector import HipDenoiseProjector
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+
+    lvlm = nn.Module()
+    lvlm.denoise_tower = nn.Module()
+    lvlm.denoise_tower.denoiser = HipFluxTransformer2DModel(device="meta", init="empty")
+    lvlm.denoise_tower.denoise_projector = HipDenoiseProjector(device="meta", init="empty")
+    lvlm.requires_grad_(False)
+    lvlm.denoise_tower.denoiser.enable_gradient_checkpointing()           # :486
+    comps = training.get_trainable_params(layers_to_train=list(range(57)), only_img_branch=True)   # pinned above
+    for name, module in lvlm.named_modules():                              # :538-543
+        if training.check_param_is_in_components(name, comps):
+            module.requires_grad_(True)
+    den = lvlm.denoise_tower.denoiser
+    keys = sorted(flux_spec.flux_param_shapes(flux_spec.FLUX_KONTEXT_CONFIG))
+    assert sorted(k for k, _ in den.named_parameters()) == keys           # no name mangling in state_dict / parameters
+    got = np.array([den.p(k).requires_grad for k in keys])
+    assert np.array_equal(got, golden["trainable_img"])
+    assert sorted(den.grad_parameter_names()) == sorted(training.trainable_names(keys))
+    for name, param in lvlm.named_parameters():                            # :545-548 (with_tune_mlp2)
+        if "denoise_tower.denoise_projector" in name:
+            param.requires_grad_(True)
+    n_train = sum(p.numel() for p in lvlm.parameters() if p.requires_grad)
+    assert 4.03e9 < n_train < 4.05e9                                       # SURVEY 8(e): 4.04 B
+    # the text-branch configuration (only_tune_image_branch: false) is accepted by the backward as well
+    from gpt_image_edit_amd.backward import FluxBackward
+    lvlm.requires_grad_(False)
+    comps_all = training.get_trainable_params(only_img_branch=False)
+    for name, module in lvlm.named_modules():
+        if training.check_param_is_in_components(name, comps_all):
+            module.requires_grad_(True)
+    assert np.array_equal(np.array([den.p(k).requires_grad for k in keys]), golden["trainable_all"])
+    FluxBackward(den, trainable=den.grad_parameter_names())               # every name has a weight gradient
+    with pytest.raises(NotImplementedError, match="x_embedder"):
+        FluxBackward(den, trainable=["x_embedder.weight"])
+
+
+def test_save_pretrained_round_trip(tmp_path):
+    """``save_pretrained`` (train_denoiser.py:493) writes the diffusers transformer layout; ``from_pretrained`` and
+    ``checkpoint.read_flux_transformer`` read it back bit for bit."""
+    import json
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    cfg = dict(num_layers=1, num_single_layers=1, num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=32)
+    m = HipFluxTransformer2DModel(config=cfg, device="cpu", init="synthetic", seed=3)
+    d = m.save_pretrained(str(tmp_path / "transformer"), max_shard_size=200_000)
+    raw = json.load(open(os.path.join(d, "config.json")))
+    assert raw["_class_name"] == "FluxTransformer2DModel" and raw["num_layers"] == 1 and raw["axes_dims_rope"] == [16, 56, 56]
+    assert any(f.endswith(".safetensors.index.json") for f in os.listdir(d))     # sharded like the 24 GB original
+    m2 = HipFluxTransformer2DModel.from_pretrained(d, device="cpu")
+    sd, sd2 = m.state_dict(), m2.state_dict()
+    assert list(sd) == list(sd2) and all(torch.equal(sd[k], sd2[k]) for k in sd)
+    assert vars(m2.config) == vars(m.config)
