@@ -33,11 +33,19 @@ class HipDenoiseProjector(ParamTreeMixin, nn.Module):
     def load_state_dict(self, state_dict, strict=True, **kwargs):
         return super().load_state_dict({k: v.to(BF16) for k, v in state_dict.items()}, strict=strict, **kwargs)
 
-    @torch.no_grad()
     def forward(self, hidden_states):
-        """[B, L, 3584] (or [L, 3584]) bf16 -> [B, L, 4096] bf16."""
+        """[B, L, 3584] (or [L, 3584]) bf16 -> [B, L, 4096] bf16.  Under ``torch.enable_grad()`` with trainable
+        parameters (the reference's ``with_tune_mlp2`` / ``only_tune_mlp2``, ``train_denoiser.py:527-548``) the call
+        records one autograd node: forward_train / backward below."""
         if not hidden_states.is_cuda:
             raise RuntimeError("HipDenoiseProjector needs GPU tensors: there is no CPU fallback")
+        if torch.is_grad_enabled() and any(prm.requires_grad for prm in self._pmap.values()):
+            names = ("0.weight", "0.bias", "2.weight", "2.bias")
+            return _ProjectorTrainFunction.apply(self, names, hidden_states, *[self.p(n) for n in names])
+        return self._forward_infer(hidden_states)
+
+    @torch.no_grad()
+    def _forward_infer(self, hidden_states):
         x = hidden_states.to(BF16).contiguous()
         squeeze = x.dim() == 2
         if squeeze:
@@ -93,3 +101,19 @@ class HipDenoiseProjector(ParamTreeMixin, nn.Module):
         grads["0.weight"] = wgrad(self._b, dh1, x)
         grads["0.bias"] = ops.colsum(dh1)
         return grads
+
+
+class _ProjectorTrainFunction(torch.autograd.Function):
+    """Autograd node of the projector: the gradient of ``prompt_embeds`` (from the MMDiT's node) becomes the four
+    parameter gradients.  The VLM upstream is frozen in every configuration the reference ships, so no input gradient."""
+
+    @staticmethod
+    def forward(ctx, proj, names, hidden_states, *params):
+        ctx.proj, ctx.names, ctx.squeeze = proj, names, hidden_states.dim() == 2
+        y = proj.forward_train(hidden_states)
+        return y[0] if ctx.squeeze else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        grads = ctx.proj.backward(dy.unsqueeze(0) if ctx.squeeze else dy)
+        return (None, None, None, *[grads[n].to(BF16) for n in ctx.names])

@@ -97,6 +97,14 @@ class TaskHead(nn.Sequential):
         return bool(logits[0] < logits[1]), logits
 
 
+def text_position_ids(attention_mask):
+    """Text-only branch of the reference's ``get_rope_index`` (``modeling_univa_qwen2p5vl.py:300-303``): position =
+    (number of real tokens before) for real tokens, 1 for padding, the same on the three rope axes -> [3, B, L]."""
+    pos = attention_mask.long().cumsum(-1) - 1
+    pos = pos.masked_fill(attention_mask == 0, 1)
+    return pos.unsqueeze(0).expand(3, -1, -1)
+
+
 def _find_true_blocks(mask_1d):
     """(start, length) of every run of True in a 1-D bool tensor (the image-token runs of one sample)."""
     m = mask_1d.to(torch.int8)
@@ -162,10 +170,15 @@ class UnivaQwen2p5VL(nn.Module):
             embeds = embeds.masked_scatter(image_mask, image_embeds)
             if mm_token_type_ids is None:
                 mm_token_type_ids = self._mm_token_type_ids(input_ids)
+        # The reference derives the 3-D positions from (input_ids, attention_mask) in EVERY case (:451-466 ->
+        # get_rope_index :139-318): with images from the id layout, without them from the mask (:300-303: cumsum - 1,
+        # padding -> 1).  The stock 5.x model only does the former and falls back to arange for a padded text batch.
         position_ids = None
         if pixel_values is not None:
             position_ids, _ = core.get_rope_index(input_ids, mm_token_type_ids=mm_token_type_ids,
                                                   image_grid_thw=image_grid_thw, attention_mask=attention_mask)
+        elif attention_mask is not None and attention_mask.dim() == 2:
+            position_ids = text_position_ids(attention_mask)
         hidden = core.language_model(input_ids=None, position_ids=position_ids, attention_mask=attention_mask,
                                      inputs_embeds=embeds, use_cache=False).last_hidden_state
         if vlm_residual_image_factor > 0.0 and image_embeds is not None:      # :502-505

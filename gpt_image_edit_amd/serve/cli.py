@@ -184,6 +184,48 @@ def main(args):
     chat(args, pipe, tokenizers, text_encoders, device)
 
 
+def smart_resize(height, width, factor=28, min_pixels=4 * 28 * 28, max_pixels=16384 * 28 * 28):
+    """(height, width) the Qwen2-VL front end resizes an image to: both multiples of ``factor`` (= 2 x 14-pixel patches
+    merged 2 x 2), area within [min_pixels, max_pixels], aspect kept as far as the rounding allows.  Restated from the
+    published algorithm of ``qwen-vl-utils`` (``vision_process.smart_resize``; un-pinned third-party dependency of the
+    reference, ``requirements.txt:34``, not installed here), which the reference applies through
+    ``process_vision_info(conversation)`` (``univa/serve/cli.py:189``) with the per-image ``min_pixels = max_pixels =
+    448 * 448`` of ``cli.py:172``."""
+    import math
+    if max(height, width) / min(height, width) > 200:
+        raise ValueError(f"absolute aspect ratio must be smaller than 200, got {max(height, width) / min(height, width)}")
+    h_bar = max(factor, round(height / factor) * factor)
+    w_bar = max(factor, round(width / factor) * factor)
+    if h_bar * w_bar > max_pixels:
+        beta = math.sqrt((height * width) / max_pixels)
+        h_bar = math.floor(height / beta / factor) * factor
+        w_bar = math.floor(width / beta / factor) * factor
+    elif h_bar * w_bar < min_pixels:
+        beta = math.sqrt(min_pixels / (height * width))
+        h_bar = math.ceil(height * beta / factor) * factor
+        w_bar = math.ceil(width * beta / factor) * factor
+    return h_bar, w_bar
+
+
+def vision_inputs(conversation):
+    """``process_vision_info(conversation)[0]`` of the reference's cli (:189): every image entry of the conversation, in
+    order, opened as RGB and resized (PIL's default filter, bicubic) to ``smart_resize`` of its own size under the
+    entry's ``min_pixels`` / ``max_pixels`` -- so that a 448 x 448-pixel budget yields the 16 x 16 merged-patch grid
+    (256 image tokens for a square image) whatever the processor's own defaults are.  None when there is no image."""
+    from PIL import Image
+    out = []
+    for message in conversation:
+        for c in message["content"]:
+            if c.get("type") != "image":
+                continue
+            img = c["image"] if isinstance(c["image"], Image.Image) else Image.open(c["image"])
+            img = img.convert("RGB")
+            w, h = img.size
+            rh, rw = smart_resize(h, w, 28, c.get("min_pixels", 4 * 28 * 28), c.get("max_pixels", 16384 * 28 * 28))
+            out.append(img.resize((rw, rh)))
+    return out or None
+
+
 def load_main_model_and_processor(model_path, device, min_pixels=448 * 448, max_pixels=448 * 448):
     """(model, task_head, processor) like reference cli.py:30-55, built from this package's adaptor: the stock
     Qwen2.5-VL weights of the UniWorld directory, its ``denoise_tower.denoise_projector.*`` on the HIP projector and
@@ -203,8 +245,6 @@ def load_main_model_and_processor(model_path, device, min_pixels=448 * 448, max_
 
 def chat(args, pipe, tokenizers, text_encoders, device):
     """The interactive loop of reference cli.py:118-267 (text and / or image URLs per turn; empty turn exits)."""
-    from PIL import Image
-
     from ..prompt_embedding import encode_prompt
     from ..qwen_adaptor import encode_edit_prompt
     model, task_head, processor = load_main_model_and_processor(args.model_path, device)
@@ -230,8 +270,13 @@ def chat(args, pipe, tokenizers, text_encoders, device):
         conversation.append({"role": "user", "content": content})
         chat_text = processor.apply_chat_template(conversation, tokenize=False, add_generation_prompt=True)
         chat_text = "<|im_end|>\n".join(chat_text.split("<|im_end|>\n")[1:])      # drop the system turn (cli.py:186)
-        images = [Image.open(c["image"]).convert("RGB") for m in conversation for c in m["content"] if c["type"] == "image"]
-        inputs = processor(text=[chat_text], images=images or None, padding=True, return_tensors="pt").to(device)
+        images = vision_inputs(conversation)                                        # process_vision_info (cli.py:189)
+        inputs = processor(text=[chat_text], images=images, padding=True, return_tensors="pt").to(device)
+        if images and getattr(inputs, "image_grid_thw", None) is not None:
+            for im, thw in zip(images, inputs.image_grid_thw.tolist()):                 # the processor must not resize again
+                if (thw[1] * 14, thw[2] * 14) != (im.size[1], im.size[0]):
+                    raise RuntimeError(f"processor re-sized a {im.size[1]} x {im.size[0]} image to grid {thw}: pass "
+                                       "min_pixels / max_pixels = 448 * 448 to AutoProcessor (cli.py:30-35)")
         t5_embeds, pooled = encode_prompt(text_encoders, tokenizers, txt if not args.no_joint_with_t5 else "", 256, device, 1)
         turn = encode_edit_prompt(model, task_head, inputs, t5_embeds, joint_with_t5=not args.no_joint_with_t5)
         if turn["generate"]:

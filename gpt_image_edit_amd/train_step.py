@@ -71,22 +71,12 @@ class DenoiserTrainStep:
         return st
 
     @torch.no_grad()
-    def forward_backward(self, model_input, cond_latents, noise, sigmas, prompt_embeds=None, pooled=None, guidance_scale=1.0,
-                         vlm_hidden=None, prefix_prompt_embeds=None):
-        """(loss fp64 [1], grads, d_prompt_embeds) for one batch of equally sized samples; model_input / noise fp32
-        [B,16,h,w] (VAE latents already shifted and scaled), cond_latents the same or None, sigmas fp32 [B].
-        Either ``prompt_embeds`` (projector frozen / absent) or ``vlm_hidden`` [B,L,3584] (+ optional T5 prefix)."""
+    def prepare_inputs(self, model_input, cond_latents, noise, sigmas, prompt_embeds, pooled, guidance_scale=1.0):
+        """The denoiser's keyword arguments for one batch, as the reference assembles them (``train_denoiser.py:996-1059,
+        1064-1104``): noisy target tokens (mix + 2x2 packing in ONE kernel) followed by the condition tokens, ids with the
+        condition's first coordinate set to 1, zero ``txt_ids``, ``timesteps / 1000`` in bf16, the guidance vector.
+        Returns (kwargs of ``HipFluxTransformer2DModel.forward``, number of target tokens)."""
         dev = self.model.device
-        n_proj = 0
-        if vlm_hidden is not None:
-            if self.projector is None or prompt_embeds is not None:
-                raise ValueError("vlm_hidden needs projector= at construction and excludes prompt_embeds")
-            prompt_embeds = self.projector.forward_train(vlm_hidden)
-            n_proj = prompt_embeds.shape[1]
-            if prefix_prompt_embeds is not None:
-                prompt_embeds = torch.cat([prompt_embeds, prefix_prompt_embeds.to(BF16)], dim=1)
-        elif prompt_embeds is None:
-            raise ValueError("one of prompt_embeds / vlm_hidden is required")
         B, C, h, w = model_input.shape
         S_tgt = (h // 2) * (w // 2)
         S_cond = 0 if cond_latents is None else (cond_latents.shape[2] // 2) * (cond_latents.shape[3] // 2)
@@ -102,7 +92,28 @@ class DenoiserTrainStep:
         txt_ids = torch.zeros(prompt_embeds.shape[1], 3, device=dev, dtype=BF16)
         guidance = torch.full([B], guidance_scale, device=dev, dtype=torch.float32)
         timestep = (sigmas * 1000.0).to(BF16) / 1000            # `timesteps / 1000` as the model receives it (:1073)
-        pred = self.bw.forward(tokens, prompt_embeds, pooled, timestep, ids, txt_ids, guidance)
+        return dict(hidden_states=tokens, encoder_hidden_states=prompt_embeds, pooled_projections=pooled, timestep=timestep,
+                    img_ids=ids, txt_ids=txt_ids, guidance=guidance), S_tgt
+
+    @torch.no_grad()
+    def forward_backward(self, model_input, cond_latents, noise, sigmas, prompt_embeds=None, pooled=None, guidance_scale=1.0,
+                         vlm_hidden=None, prefix_prompt_embeds=None):
+        """(loss fp64 [1], grads, d_prompt_embeds) for one batch of equally sized samples; model_input / noise fp32
+        [B,16,h,w] (VAE latents already shifted and scaled), cond_latents the same or None, sigmas fp32 [B].
+        Either ``prompt_embeds`` (projector frozen / absent) or ``vlm_hidden`` [B,L,3584] (+ optional T5 prefix)."""
+        n_proj = 0
+        if vlm_hidden is not None:
+            if self.projector is None or prompt_embeds is not None:
+                raise ValueError("vlm_hidden needs projector= at construction and excludes prompt_embeds")
+            prompt_embeds = self.projector.forward_train(vlm_hidden)
+            n_proj = prompt_embeds.shape[1]
+            if prefix_prompt_embeds is not None:
+                prompt_embeds = torch.cat([prompt_embeds, prefix_prompt_embeds.to(BF16)], dim=1)
+        elif prompt_embeds is None:
+            raise ValueError("one of prompt_embeds / vlm_hidden is required")
+        inp, S_tgt = self.prepare_inputs(model_input, cond_latents, noise, sigmas, prompt_embeds, pooled, guidance_scale)
+        pred = self.bw.forward(inp["hidden_states"], inp["encoder_hidden_states"], inp["pooled_projections"], inp["timestep"],
+                               inp["img_ids"], inp["txt_ids"], inp["guidance"])
         loss, grad = ops.flow_loss(pred[:, :S_tgt], model_input.contiguous(), noise.contiguous())
         dsample = torch.zeros_like(pred)
         dsample[:, :S_tgt].copy_(grad)

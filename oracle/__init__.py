@@ -15,7 +15,11 @@ Pinning status
   ``_prepare_latent_image_ids``, ``dynamic_resize`` family) is PINNED: checked against golden
   vectors produced by executing the reference's own functions in the build container
   (``oracle/make_golden.py`` -> ``tests/golden/*.npz``).
-* ``oracle.mmdit`` / ``oracle.vae`` / ``oracle.scheduler`` are **parity unpinned** against the
+* ``oracle.scheduler.shifted_sigmas`` (the dynamic shift) is PINNED to the reference's own in-tree restatement of
+  it, ``apply_flux_schedule_shift`` (``train_denoiser.py:972-986``), through ``tests/golden/train.npz``
+  (``tests/test_oracle_golden.py::test_scheduler_shift_pinned_to_the_references_own_restatement``); the Euler step and
+  the linspace grid remain restatements.
+* ``oracle.mmdit`` / ``oracle.vae`` / the rest of ``oracle.scheduler`` are **parity unpinned** against the
   real third-party code: ``diffusers`` is not vendored in the reference and not installed here
   (no network), and the reference holds no tests or golden vectors for this path (SURVEY.md
   section 4 / 8c).  They restate the published diffusers 0.32.2 algorithm,

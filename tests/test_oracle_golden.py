@@ -220,3 +220,29 @@ def test_cli_flags_match_reference_defaults():
     a = cli.build_parser().parse_args(["--model_path", "m", "--flux_path", "f"])
     assert (a.height, a.width, a.num_inference_steps, a.guidance_scale) == (1024, 1024, 28, 3.5)
     assert not (a.no_auto_hw or a.ocr_enhancer or a.no_joint_with_t5)
+
+
+def test_scheduler_shift_pinned_to_the_references_own_restatement(golden_dir):
+    """The one piece of the diffusers scheduler the reference restates IN-TREE: ``apply_flux_schedule_shift``
+    (``train_denoiser.py:972-986``: sigma * e^mu / (1 + (e^mu - 1) sigma), mu = calculate_shift(h w / 4) with the
+    scheduler config's base / max shift) -- algebraically the scheduler's dynamic shift e^mu / (e^mu + 1/sigma - 1).
+    ``tests/golden/train.npz`` holds that function's outputs (executed from the reference's source by
+    ``oracle/make_golden.py::g_train``); both ``oracle.scheduler.shifted_sigmas`` and the product's
+    ``FlowMatchEulerDiscreteScheduler.set_timesteps`` must reproduce them from the same sigmas and resolutions."""
+    from gpt_image_edit_amd import helpers
+    g = _load(golden_dir, "train.npz")
+    sig = g["shift_in"].astype(np.float32)
+    cfg = FlowMatchEulerDiscreteScheduler().config
+    for (h, w), ref in zip(g["shift_hw"], g["shift_out"]):
+        mu = helpers.calculate_shift((int(h) * int(w)) // 4, cfg["base_image_seq_len"], cfg["max_image_seq_len"],
+                                     cfg["base_shift"], cfg["max_shift"])          # flux_pipeline.py:994-999
+        ts, sg = osched.shifted_sigmas(len(sig), mu, sigmas=sig)
+        np.testing.assert_allclose(sg[:-1].numpy(), ref, rtol=3e-6, atol=1e-7)
+        np.testing.assert_allclose(ts.numpy(), ref * 1000.0, rtol=3e-6, atol=1e-4)
+        s = FlowMatchEulerDiscreteScheduler()
+        s.set_timesteps(sigmas=sig, mu=mu, device="cpu")
+        np.testing.assert_allclose(s.sigmas[:-1].numpy(), ref, rtol=3e-6, atol=1e-7)
+        assert np.array_equal(s.sigmas.numpy(), sg.numpy()) and np.array_equal(s.timesteps.numpy(), ts.numpy())
+        assert float(s.sigmas[-1]) == 0.0
+    # mu at the two BASELINE resolutions, as the reference's calculate_shift gives them (helpers.npz pins the function)
+    assert helpers.calculate_shift(4096) == pytest.approx(1.15) and helpers.calculate_shift(1024) == pytest.approx(0.63, abs=5e-3)

@@ -115,3 +115,23 @@ def test_7b_config_matches_the_backbone():
     inp = qa.synthetic_turn(cfg, "cpu")
     assert inp["pixel_values"].shape == (1024, 1176) and inp["input_ids"].shape == (1, 300)     # SURVEY a13 sizes
     assert int((inp["input_ids"] == cfg.image_token_id).sum()) == 256 and inp["input_ids"][0, -1] == 77091
+
+
+def test_padded_text_batch_takes_positions_from_the_mask(tiny):
+    """Reference ``get_rope_index`` text-only branch (modeling_univa_qwen2p5vl.py:300-303): positions follow the
+    attention mask; the stock 5.x model would use arange for a padded batch."""
+    cfg, vlm, proj, inp = tiny
+    model = qa.UnivaQwen2p5VL(vlm, proj)
+    ids = torch.cat([inp["input_ids"][:, -8:], inp["input_ids"][:, -8:]]).clone()
+    am = torch.ones_like(ids)
+    am[1, :3] = 0                                           # second sample left-padded by 3
+    pos = qa.text_position_ids(am)
+    assert pos.shape == (3, 2, 8) and pos[0, 0].tolist() == list(range(8)) and pos[0, 1].tolist() == [1, 1, 1, 0, 1, 2, 3, 4]
+    got = model(input_ids=ids, attention_mask=am, output_type="denoise_embeds")
+    with torch.no_grad():
+        ref = proj(vlm.model(input_ids=ids, attention_mask=am, position_ids=pos).last_hidden_state)
+        plain = proj(vlm.model(input_ids=ids, attention_mask=am).last_hidden_state)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-6)
+    # the un-padded sample is unaffected; the padded one's real tokens see the same RELATIVE positions either way
+    torch.testing.assert_close(got[0], plain[0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(got[1, 3:], plain[1, 3:], rtol=1e-4, atol=1e-5)
