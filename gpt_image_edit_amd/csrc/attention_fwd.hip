@@ -42,6 +42,9 @@ struct AttnParams {
   int64_t o_ld, o_bs;
   float scale_log2;    // scale * log2(e)
   float* lse;          // optional [B, H, S]: log2-domain log-sum-exp of every row (saved for the backward pass)
+  // which query rows this launch covers: the (b, h, 256-row block) list is cut into `subs` workgroups per block (subs x
+  // NW x 32 = 256 rows); workgroup t of the launch works on block t0 + t / subs, rows [sub * NW * 32, (sub + 1) * NW * 32)
+  int t0, subs;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -65,6 +68,7 @@ FK_DEV void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   else static_assert(N == 0, "add the vmcnt literal");
 }
 
@@ -77,7 +81,7 @@ FK_DEV void wait_vmcnt() {
 // the result can be held against an fp32 reference at rtol 1e-3 / atol 1e-4 -- with one bf16 term the rounding of
 // P alone (2^-9 per term) sits above that tolerance whatever the kernel does.
 template <int NW, int STAGES, bool F32OUT, bool ILV>
-__global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel(const AttnParams p) {
   constexpr int QBLK = NW * 32;
   constexpr int LOADS = 32 / NW;      // DMA instructions per wave per tile (16 K pieces + 16 V pieces / NW)
   constexpr int KL = LOADS / 2;       // K pieces per wave (same number of V pieces)
@@ -90,7 +94,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
   const int hh = lane >> 5;   // half
 
   // XCD-aware block order: workgroups of one (b, h) -- which share K / V -- stay on one XCD's L2
-  const int nqb = (p.S + QBLK - 1) / QBLK;
+  constexpr int QSPAN = 256;                // query rows per entry of the block list (QBLK * p.subs)
+  const int nqb = (p.S + QSPAN - 1) / QSPAN;
   int t;
   {
     const int nwg = gridDim.x;
@@ -98,15 +103,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   }
-  const int qb = t % nqb;
-  const int bh = t / nqb;
+  const int tb = p.t0 + t / p.subs, sub = t % p.subs;
+  const int qb = tb % nqb;
+  const int bh = tb / nqb;
   const int b = bh / p.H, h = bh - b * p.H;
+  const int q_row0 = qb * QSPAN + sub * QBLK;
+  if (q_row0 >= p.S) return;                // ragged last block of a light launch: nothing for this workgroup
 
   const bf16_t* Kg = p.k + (int64_t)bh * p.S * HD;
   const bf16_t* Vg = p.v + (int64_t)b * p.v_bs + h * HD;
 
   // ---- Q operand fragments (B operand of S^T = K Q^T): lane holds Q[q][16kk + 8hh .. +8] ----------
-  const int q_row = qb * QBLK + wave * 32 + ql;
+  const int q_row = q_row0 + wave * 32 + ql;
   bf16x8_t qf[8];
   {
     const bf16_t* qp = p.q + ((int64_t)bh * p.S + min(q_row, p.S - 1)) * HD + 8 * hh;
@@ -525,15 +533,44 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const AttnPar
 // barrier (timing probe): +1..6 %.  Counters at B = 4, S = 8704: matrix pipe 52 % busy at 1.86 GHz, waves 37 % parked,
 // 32 % issue-stalled, LDS array ~26 % busy, no bank conflicts.
 
+// blocks [t0, t0 + nblocks) of the (b, h, 256-row block) list, 256 / (NW * 32) workgroups per block
 template <int NW, int STAGES, bool F32OUT, bool ILV>
-int launch(const AttnParams& p, hipStream_t stream) {
+int launch(AttnParams p, hipStream_t stream, int t0, int nblocks) {
   constexpr int SMEM = STAGES * STAGE_BYTES + 16;   // ring + the restart flag word
   auto kern = attention_fwd_kernel<NW, STAGES, F32OUT, ILV>;
   FK_ENSURE_MAX_LDS(kern, SMEM, "fk_attention_fwd_bf16");
-  const int nqb = (p.S + NW * 32 - 1) / (NW * 32);
-  hipLaunchKernelGGL(kern, dim3(nqb * p.H * p.B), dim3(NW * 64), SMEM, stream, p);
+  p.t0 = t0;
+  p.subs = 8 / NW;
+  if (nblocks <= 0) return FK_OK;
+  hipLaunchKernelGGL(kern, dim3(nblocks * p.subs), dim3(NW * 64), SMEM, stream, p);
   FK_CHECK_LAUNCH("fk_attention_fwd_bf16");
   return FK_OK;
+}
+
+// The last, partly filled round of a grid.  One workgroup (8 waves x 32 query rows) per CU means the grid runs in
+// rounds of #CUs blocks; at batch 1 and S = 8704 that is 816 blocks = 3 full rounds + 48 blocks that hold 48 CUs for a
+// whole fourth round while 208 idle.  Those tail blocks are launched as FOUR (or two) workgroups of 2 (4) waves each --
+// 64 (128) query rows against the same K / V stream, one wave per SIMD -- so the tail spreads over 192 CUs and ends
+// early (a lone wave on its SIMD runs ~1.4x faster than two sharing one).  Every query row's arithmetic is the same
+// whichever workgroup shape carries it, so the output is bit-identical to the plain grid (and a sample still equals
+// itself inside any batch).  FK_ATTN_TAIL=0 disables (A/B).
+static int g_attn_tail = -2;
+static int attn_tail_mode() {
+  if (g_attn_tail == -2) {
+    const char* e = getenv("FK_ATTN_TAIL");
+    g_attn_tail = e ? atoi(e) : 1;
+  }
+  return g_attn_tail;
+}
+static int attn_cu_count() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    else return 256;
+  }
+  return cus;
 }
 
 
@@ -572,11 +609,28 @@ int attention_entry(const void* q, const void* k, const void* v, void* o, int32_
   p.B = B; p.H = H; p.S = S; p.v_ld = v_ld; p.v_bs = v_batch_stride; p.o_ld = o_ld; p.o_bs = o_batch_stride;
   p.scale_log2 = scale * 1.4426950408889634f;
   p.lse = lse;
-  if (f32out) return launch<8, 3, true, false>(p, stream);
-  return use_interleaved(p) ? launch<8, 3, false, true>(p, stream) : launch<8, 3, false, false>(p, stream);
+  const int nblk = ((S + 255) / 256) * H * B;
+  if (f32out) return launch<8, 3, true, false>(p, stream, 0, nblk);
+  const int G = attn_cu_count();
+  int tail = 0, tail_waves = 0;                     // blocks handed to light workgroups, waves per light workgroup
+  if (attn_tail_mode() && nblk > G && nblk % G != 0) {
+    const int rem = nblk % G;
+    if (4 * rem <= G) { tail = rem; tail_waves = 2; }
+    else if (2 * rem <= G) { tail = rem; tail_waves = 4; }
+  }
+  const int nfull = nblk - tail;
+  int rc = use_interleaved(p) ? launch<8, 3, false, true>(p, stream, 0, nfull) : launch<8, 3, false, false>(p, stream, 0, nfull);
+  if (rc != FK_OK || !tail) return rc;
+  return tail_waves == 2 ? launch<2, 3, false, false>(p, stream, nfull, tail) : launch<4, 3, false, false>(p, stream, nfull, tail);
 }
 
 }  // namespace
+
+extern "C" int fk_attention_set_tail(int32_t mode) {
+  FK_CHECK_ARG(mode == 0 || mode == 1, "fk_attention_set_tail: %d is not 0 (plain grid) or 1 (light workgroups for the last round)", mode);
+  g_attn_tail = mode;
+  return FK_OK;
+}
 
 extern "C" int fk_attention_fwd_bf16(const void* q, const void* k, const void* v, void* o, int32_t B,
                                      int32_t H, int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld,

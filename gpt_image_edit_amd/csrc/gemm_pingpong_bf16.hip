@@ -27,6 +27,8 @@
 // applied where the tile is written (DMA source address) and again on the ds_read_b128 side.
 // Up to FK_MAX_GROUP problems with identical (N, K, epilogue) share one launch ("grouped GEMM"): the
 // text- and image-stream linears of a double block become one grid.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "fk_common.h"
@@ -46,8 +48,17 @@ constexpr int GROUP_M = FK_GROUP_M;
 
 struct GroupArgs {
   fk_gemm_args p[FK_MAX_GROUP];
-  int tiles_before[FK_MAX_GROUP + 1];  // prefix sums of tile counts
+  int tiles_before[FK_MAX_GROUP + 1];  // prefix sums of tile counts (mixed launch: of the 256 x 256 tiles)
   int n;
+  // mixed launch (gemm_mix_kernel): column tiles [0, big_cols) of width 256 are 256 x 256 tiles, the columns from
+  // big_cols * 256 on are 256 x 128 tiles; per XCD (blockIdx % 8) the chunk of each class it works off
+  int big_cols;
+  int small_before[FK_MAX_GROUP + 1];
+  int xcd_big_start[8], xcd_big_cnt[8], xcd_small_start[8];
+  // split-K launch (gemm8_kernel<.., SPLITK>): two workgroups per 256 x 256 tile, each over half of K; fp32 partial
+  // tiles (256 KiB apiece) and one (ticket, flag) word pair per tile in a caller-owned workspace
+  float* sk_partials;
+  unsigned* sk_ctl;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -121,30 +132,36 @@ FK_DEV float row16_sum(float v) {
   return v;
 }
 
-// tile selection: XCD chunking over the whole grid, then problem, then grouped (GROUP_M deep) order
+// tile selection: XCD chunking over the whole grid (workgroup b runs on XCD b % 8: consecutive tiles of the order
+// below -- which share A rows and W columns -- stay on one XCD's L2), then problem, then grouped (GROUP_M deep) order
+FK_DEV int xcd_chunk_index() {
+  const int nwg = gridDim.x;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+// tile t of a class of tiles that covers the column tiles [col0 / BN, col0 / BN + nbn) of every problem
 template <int BN>
-FK_DEV void select_tile(const GroupArgs& ga, int& pi, int& m0, int& n0) {
-  int t;
-  {
-    const int nwg = gridDim.x;
-    const int q = nwg >> 3, r = nwg & 7;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
+FK_DEV void tile_of(const GroupArgs& ga, const int (&before)[FK_MAX_GROUP + 1], int t, int nbn, int col0, int& pi, int& m0,
+                    int& n0) {
   pi = 0;
 #pragma unroll
   for (int i = 1; i < FK_MAX_GROUP; ++i)
-    if (i < ga.n && t >= ga.tiles_before[i]) pi = i;
+    if (i < ga.n && t >= before[i]) pi = i;
   const fk_gemm_args& p = ga.p[pi];
-  t -= ga.tiles_before[pi];
-  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  t -= before[pi];
+  const int nbm = (p.M + BM - 1) / BM;
   const int per_group = GROUP_M * nbn;
   const int g = t / per_group;
   const int first_m = g * GROUP_M;
   const int gm = min(nbm - first_m, GROUP_M);
   const int rem = t - g * per_group;
   m0 = (first_m + rem % gm) * BM;
-  n0 = (rem / gm) * BN;
+  n0 = col0 + (rem / gm) * BN;
+}
+template <int BN>
+FK_DEV void select_tile(const GroupArgs& ga, int t, int& pi, int& m0, int& n0) {
+  tile_of<BN>(ga, ga.tiles_before, t, (ga.p[0].N + BN - 1) / BN, 0, pi, m0, n0);
 }
 
 // epilogue (as gemm_bf16.hip): bias/activation -> bf16 -> LDS tile -> coalesced 16-byte rows.
@@ -370,18 +387,18 @@ struct Cfg8 {
   static FK_DEV int tile_col(int wn, int nf) { return nf * 128 + wn * 32; }
 };
 
+// sk_half < 0: the whole K range.  sk_half = 0 / 1 (split-K launch): this workgroup multiplies K-tiles
+// [sk_half * nk, (sk_half + 1) * nk), nk = K / 128, and meets its partner through workspace slot sk_slot (below).
 template <int EPI, int BN>
-__global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
+FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, int sk_half, int sk_slot) {
   using C = Cfg8<BN>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;   // group = wm; waves w and w + 4 share a SIMD
-  int pi, m0, n0;
-  select_tile<BN>(ga, pi, m0, n0);
   const fk_gemm_args& p = ga.p[pi];
-  const int nk = p.K / C::BK;
+  const int nk = sk_half < 0 ? p.K / C::BK : p.K / (2 * C::BK);
+  const int kbase = sk_half > 0 ? nk * (C::BK * 2) : 0;   // byte offset of this workgroup's first K-tile in a row
 
   // ---- LDS-DMA sources: piece = 8 rows x 128 B, lane -> (row, slot), source chunk = slot ^ swz(row).
   // Wave w requests pieces 2w and 2w + 1 of every half-tile.
@@ -406,7 +423,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
   }
   // which: 0 = A0, 1 = A1, 2 = W0, 3 = W1; kt is clamped (surplus requests are never read)
   auto dma_half = [&](int which, int buf, int kt) {
-    const int koff = min(kt, nk - 1) * (C::BK * 2);
+    const int koff = kbase + min(kt, nk - 1) * (C::BK * 2);
     char* dst = smem + buf * C::BUF_BYTES + which * C::HALF_BYTES + wave * 2048;
     if (which < 2) {
       buffer_lds16(rs_a, dst, a_voff[which][0], koff);
@@ -498,20 +515,99 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
   if (wm == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus (clamped) requests must not land in the C tile
 
+  if (sk_half >= 0) {
+    // ---- split-K rendezvous ---------------------------------------------------------------------------------------
+    // The two workgroups of a tile each hold the fp32 partial sums of half the K range.  Whoever finishes FIRST
+    // (ticket = an agent-scope fetch-add on the tile's counter word: even -> first) writes its accumulators to the
+    // tile's workspace slot with write-through stores, drains them, publishes flag = ticket + 1 and exits; the
+    // SECOND (odd ticket) waits for flag == its ticket, acquires, adds the stored partials to its own and runs the
+    // epilogue.  fp32 addition commutes, so own + other is the same bits whichever half arrives first: the result
+    // is deterministic.  The wait cannot deadlock under any dispatch order: it is only ever for a workgroup that has
+    // already drawn its ticket, i.e. is resident and a few microseconds from publishing.  Counter and flag are
+    // monotonic (every launch adds exactly two tickets per slot it uses), so nothing is reset between launches.
+    // Recipe: cdna_hip_programming.md Guideline 16 R1 (sc1 payload -> per-wave vmcnt(0) -> barrier -> one-lane
+    // relaxed agent flag store; consumer: one-lane relaxed poll -> ONE agent acquire -> barrier -> loads).
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    gu32* const ctl = (gu32*)(ga.sk_ctl + 2 * (size_t)sk_slot);
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(ga.sk_partials + (size_t)sk_slot * (BM * BN)), 0, BM * BN * 4, 0x00020000);
+    __syncthreads();   // every wave is done with the operand ring: its first word now carries the ticket
+    if (tid == 0) *(volatile unsigned*)smem = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = __builtin_amdgcn_readfirstlane(*(volatile unsigned*)smem);
+    constexpr int NV = C::NF * C::MF * 4;   // 16-byte pieces of the accumulators per thread: piece r of thread t at (r * 512 + t) * 16
+    if ((ticket & 1u) == 0) {
+#pragma unroll
+      for (int r = 0; r < NV; ++r) {
+        const f32x16_t& a = acc[r / (C::MF * 4)][(r / 4) % C::MF];
+        const int q = r & 3;
+        const u32x4_t v = {__float_as_uint(a[4 * q]), __float_as_uint(a[4 * q + 1]), __float_as_uint(a[4 * q + 2]),
+                           __float_as_uint(a[4 * q + 3])};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs_p, tid * 16, r * (C::NTHREADS * 16), /*sc1: write through*/ 16);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its own stores
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(ctl + 1, ticket + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (tid == 0) {
+      while (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket) __builtin_amdgcn_s_sleep(4);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r0 = 0; r0 < NV; r0 += 4) {
+      u32x4_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, tid * 16, (r0 + u) * (C::NTHREADS * 16), /*sc1*/ 16);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u;
+        f32x16_t& a = acc[r / (C::MF * 4)][(r / 4) % C::MF];
+        const int q = r & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[4 * q + j] += __uint_as_float(v[u][j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the batches apart: all 32 loads in flight at once would need 128 more VGPRs
+      // (hipcc still moves one or two accumulator tiles through scratch around this block: <= 8 stores + 8 loads per
+      //  workgroup, outside the K loop; tests/test_kernel_resources.py budgets exactly that for this instantiation)
+    }
+  }
   store_tile<EPI, BN, C>(acc, p, smem, m0, n0, wm, wn);
 }
 
-template <int EPI, int BN>
-int launch8(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) {
+template <int EPI, int BN, bool SPLITK>
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int pi, m0, n0;
+  const int t = xcd_chunk_index();
+  if constexpr (SPLITK) {
+    select_tile<BN>(ga, t >> 1, pi, m0, n0);
+    gemm8_body<EPI, BN>(ga, smem, pi, m0, n0, t & 1, t >> 1);
+  } else {
+    select_tile<BN>(ga, t, pi, m0, n0);
+    gemm8_body<EPI, BN>(ga, smem, pi, m0, n0, -1, 0);
+  }
+}
+
+template <int BN>
+int count_tiles(GroupArgs& ga, const fk_gemm_args* probs, int n) {
   int total = 0;
   for (int i = 0; i < FK_MAX_GROUP; ++i) {
     ga.tiles_before[i] = total;
     if (i < n) total += ((probs[i].M + BM - 1) / BM) * ((probs[i].N + BN - 1) / BN);
   }
   ga.tiles_before[FK_MAX_GROUP] = total;
-  auto kern = gemm8_kernel<EPI, BN>;
+  return total;
+}
+
+template <int EPI, int BN, bool SPLITK>
+int launch8(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) {
+  const int total = count_tiles<BN>(ga, probs, n);
+  auto kern = gemm8_kernel<EPI, BN, SPLITK>;
   FK_ENSURE_MAX_LDS(kern, Cfg8<BN>::SMEM_BYTES, "fk_gemm_bf16 (256 x 256 tile, 8 waves ping-pong)");
-  hipLaunchKernelGGL(kern, dim3(total), dim3(512), Cfg8<BN>::SMEM_BYTES, stream, ga);
+  hipLaunchKernelGGL(kern, dim3(SPLITK ? 2 * total : total), dim3(512), Cfg8<BN>::SMEM_BYTES, stream, ga);
   FK_CHECK_LAUNCH("fk_gemm_bf16 (256 x 256 tile, 8 waves ping-pong)");
   return FK_OK;
 }
@@ -547,15 +643,12 @@ struct Cfg9 {
 };
 
 template <int EPI, int BN>
-__global__ __launch_bounds__(512, 2) void gemm9_kernel(const GroupArgs ga) {
+FK_DEV void gemm9_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0) {
   using C = Cfg9<BN>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 3, wn = wave >> 2;   // group = wn
-  int pi, m0, n0;
-  select_tile<BN>(ga, pi, m0, n0);
   const fk_gemm_args& p = ga.p[pi];
   const int nk = p.K / C::BK;
 
@@ -679,13 +772,16 @@ __global__ __launch_bounds__(512, 2) void gemm9_kernel(const GroupArgs ga) {
 }
 
 template <int EPI, int BN>
+__global__ __launch_bounds__(512, 2) void gemm9_kernel(const GroupArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int pi, m0, n0;
+  select_tile<BN>(ga, xcd_chunk_index(), pi, m0, n0);
+  gemm9_body<EPI, BN>(ga, smem, pi, m0, n0);
+}
+
+template <int EPI, int BN>
 int launch9(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) {
-  int total = 0;
-  for (int i = 0; i < FK_MAX_GROUP; ++i) {
-    ga.tiles_before[i] = total;
-    if (i < n) total += ((probs[i].M + BM - 1) / BM) * ((probs[i].N + BN - 1) / BN);
-  }
-  ga.tiles_before[FK_MAX_GROUP] = total;
+  const int total = count_tiles<BN>(ga, probs, n);
   auto kern = gemm9_kernel<EPI, BN>;
   FK_ENSURE_MAX_LDS(kern, Cfg9<BN>::SMEM_BYTES, "fk_gemm_bf16 (256 x 128 tile, 8 waves ping-pong)");
   hipLaunchKernelGGL(kern, dim3(total), dim3(512), Cfg9<BN>::SMEM_BYTES, stream, ga);
@@ -693,10 +789,74 @@ int launch9(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream)
   return FK_OK;
 }
 
-// variant = tile width: 128 -> gemm9_kernel (256 x 128), 256 -> gemm8_kernel (256 x 256)
+// ---- mixed launch: 256 x 256 tiles for the first big_cols column tiles, 256 x 128 tiles for the rest -----------------
+// One workgroup per CU means a grid runs in rounds of #CUs tiles.  At M = 2560 the fused QKV projection (N = 9216) is
+// 360 tiles of 256 x 256 (1.41 rounds -> 2) or 720 of 256 x 128 (2.81 -> 3 rounds of 0.61): ONE round of 256 x 256
+// tiles followed by the remaining columns as 256 x 128 tiles takes 1 + 0.61 -- 12 % less than the better pure grid.
+// Both bodies accumulate over K in the same order, so WHICH tile shape computes an output element does not change its
+// bits: the split of the columns is free to follow the grid.  Workgroups are dispatched in blockIdx order, XCD = b % 8:
+// each XCD's list is its chunk of the big tiles first, then its chunk of the small ones.
 template <int EPI>
-int launch_bn(GroupArgs& ga, const fk_gemm_args* probs, int n, int bn, hipStream_t stream) {
-  return bn == 256 ? launch8<EPI, 256>(ga, probs, n, stream) : launch9<EPI, 128>(ga, probs, n, stream);
+__global__ __launch_bounds__(512, 2) void gemm_mix_kernel(const GroupArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int nbig = ga.xcd_big_cnt[xcd];
+  int pi, m0, n0;
+  if (idx < nbig) {
+    tile_of<256>(ga, ga.tiles_before, ga.xcd_big_start[xcd] + idx, ga.big_cols, 0, pi, m0, n0);
+    gemm8_body<EPI, 256>(ga, smem, pi, m0, n0, -1, 0);
+  } else {
+    tile_of<128>(ga, ga.small_before, ga.xcd_small_start[xcd] + idx - nbig, (ga.p[0].N - ga.big_cols * 256 + 127) / 128,
+                 ga.big_cols * 256, pi, m0, n0);
+    gemm9_body<EPI, 128>(ga, smem, pi, m0, n0);
+  }
+}
+
+constexpr int MIX_SMEM = Cfg8<256>::SMEM_BYTES > Cfg9<128>::SMEM_BYTES ? Cfg8<256>::SMEM_BYTES : Cfg9<128>::SMEM_BYTES;
+
+template <int EPI>
+int launch_mix(GroupArgs& ga, const fk_gemm_args* probs, int n, int big_cols, hipStream_t stream) {
+  const int ncols128 = (probs[0].N - big_cols * 256 + 127) / 128;
+  int tb = 0, ts = 0;
+  for (int i = 0; i < FK_MAX_GROUP; ++i) {
+    ga.tiles_before[i] = tb;
+    ga.small_before[i] = ts;
+    if (i < n) {
+      const int nbm = (probs[i].M + BM - 1) / BM;
+      tb += nbm * big_cols;
+      ts += nbm * ncols128;
+    }
+  }
+  ga.tiles_before[FK_MAX_GROUP] = tb;
+  ga.small_before[FK_MAX_GROUP] = ts;
+  ga.big_cols = big_cols;
+  const int W = tb + ts;
+  int bs = 0, ss = 0;
+  for (int x = 0; x < 8; ++x) {
+    const int wx = W / 8 + (x < W % 8 ? 1 : 0), bx = tb / 8 + (x < tb % 8 ? 1 : 0);
+    if (wx < bx) return FK_E2BIG_STRIDES;   // cannot happen for the grids the planner proposes (ts >= 8); caller falls back
+    ga.xcd_big_start[x] = bs;
+    ga.xcd_big_cnt[x] = bx;
+    ga.xcd_small_start[x] = ss;
+    bs += bx;
+    ss += wx - bx;
+  }
+  auto kern = gemm_mix_kernel<EPI>;
+  FK_ENSURE_MAX_LDS(kern, MIX_SMEM, "fk_gemm_bf16 (mixed 256 x 256 / 256 x 128 tiles)");
+  hipLaunchKernelGGL(kern, dim3(W), dim3(512), MIX_SMEM, stream, ga);
+  FK_CHECK_LAUNCH("fk_gemm_bf16 (mixed 256 x 256 / 256 x 128 tiles)");
+  return FK_OK;
+}
+
+// variant: 128 -> gemm9_kernel (256 x 128), 256 -> gemm8_kernel (256 x 256), 384 -> mixed, 512 -> split-K pairs of 256 x 256
+template <int EPI>
+int launch_variant(GroupArgs& ga, const fk_gemm_args* probs, int n, int variant, int big_cols, hipStream_t stream) {
+  switch (variant) {
+    case 256: return launch8<EPI, 256, false>(ga, probs, n, stream);
+    case 384: return launch_mix<EPI>(ga, probs, n, big_cols, stream);
+    case 512: return launch8<EPI, 256, true>(ga, probs, n, stream);
+    default: return launch9<EPI, 128>(ga, probs, n, stream);
+  }
 }
 
 int cu_count() {
@@ -709,28 +869,98 @@ int cu_count() {
   }
   return cus;
 }
+
+// ---- launch plan ----------------------------------------------------------------------------------------------------
+// Time of a grid in units of one 256 x 256 tile, workgroups handed to G CUs in launch order (list scheduling):
+// `nb` tiles of cost 1 first, then `ns` tiles of cost cs.
+double makespan(long nb, long ns, double cs, int G) {
+  const long full = nb / G, rem = nb % G;
+  // group A: G - rem CUs free at `full`; group B: rem CUs free at full + 1 (absent when rem == 0)
+  double ta = (double)full, tb = (double)full + 1.0, end = rem ? tb : ta;
+  const long na = G - rem;
+  if (nb == 0) end = 0.0;
+  while (ns > 0) {
+    if (rem == 0 || ta <= tb) {
+      const long k = ns < na ? ns : na;
+      ta += cs; ns -= k;
+      if (ta > end) end = ta;
+    } else {
+      const long k = ns < rem ? ns : rem;
+      tb += cs; ns -= k;
+      if (tb > end) end = tb;
+    }
+  }
+  return end;
+}
+
+struct Plan { int variant, big_cols; };
+
+// nbm: row tiles summed over the problems of the launch; N, K shared.  allow: bit 0 mixed, bit 1 split-K.
+Plan plan_launch(long nbm, int N, int K, int G, int allow, bool have_ws, int ws_slots) {
+  const double c128 = 0.5 * FK_RATE_256;   // a 256 x 128 tile in units of a 256 x 256 tile (measured rate ratio)
+  const long t128 = nbm * ((N + 127) / 128), t256 = nbm * ((N + 255) / 256);
+  Plan best = {128, 0};
+  double tbest = makespan(0, t128, c128, G);
+  if (N % 256 != 0) return best;
+  const double t_256 = makespan(t256, 0, c128, G);
+  if (t_256 < tbest) { tbest = t_256; best = {256, 0}; }
+  if (allow & 1) {
+    const int nb256 = N / 256;
+    for (int cb = 1; cb < nb256; ++cb) {
+      const long ts = nbm * 2 * (nb256 - cb);
+      if (ts < 8) continue;
+      const double t = makespan(nbm * cb, ts, c128, G);
+      if (t < tbest * 0.97) { tbest = t; best = {384, cb}; }   // a mixed grid must pay for its larger kernel image
+    }
+  }
+  if ((allow & 2) && have_ws && K >= 6144 && (K / 64) % 4 == 0 && 2 * t256 <= G && t256 <= ws_slots) {
+    // two half-K workgroups per tile in ONE round; the exchange costs ~17 us (256 KiB written through, read back, two
+    // barriers and a fence) against K x 25.8 ns for a whole tile
+    const double t = 0.5 + 17.0e-6 / (K * 25.8e-9);
+    if (t < tbest * 0.97) { tbest = t; best = {512, 0}; }
+  }
+  return best;
+}
 }  // namespace
 
 static thread_local int g_last_variant = 0;
-// 128 / 256: the 256 x 128 / 256 x 256 kernel, 0: none of the large-tile kernels yet
+// 128 / 256: the 256 x 128 / 256 x 256 kernel, 384: mixed grid, 512: split-K pairs, 0: none of the large-tile kernels yet
 int fk_gemm_last_variant(void) { return g_last_variant; }
 
+// bit 0: mixed grids, bit 1: split-K pairs (needs fk_gemm_args.splitk_ws); FK_GEMM_PLAN=0..3 (default 3) or
+// fk_gemm_set_plan().  Without bit 1 the result of a GEMM does not depend on the grid it runs in ("batch-invariant").
+static int g_plan_allow = -1;
+static int plan_allow() {
+  if (g_plan_allow < 0) {
+    const char* e = getenv("FK_GEMM_PLAN");
+    g_plan_allow = e ? (atoi(e) & 3) : 3;
+  }
+  return g_plan_allow;
+}
+extern "C" int fk_gemm_set_plan(int32_t allow) {
+  FK_CHECK_ARG(allow >= 0 && allow <= 3, "fk_gemm_set_plan: %d is not in 0..3 (bit 0 mixed grids, bit 1 split-K)", allow);
+  g_plan_allow = allow;
+  return FK_OK;
+}
+
 // Used by fk_gemm_bf16 / fk_gemm_bf16_grouped after argument validation.
-// bn_hint: 128 / 256 force the N tile; 0 = choose per problem.  The 256 x 256 kernel has the higher steady-state
-// rate (measured 1.1-1.2x for large grids), but one workgroup per CU means the grid runs in rounds of #CUs tiles:
-// pick the tile with the better (quantisation efficiency) x (rate).  (A stream-K form of the 256 x 256 kernel that
-// shares the last round's K-iterations among all CUs was built in round 1 and measured 2x slower: DESIGN.md section 4b; git history.)
-int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t stream) {
+// variant_hint: 128 / 256 / 384 / 512 force a launch form where it is applicable; 0 = choose per problem.  The 256 x 256
+// kernel has the higher steady-state rate (measured 1.1-1.2x for large grids), but one workgroup per CU means the grid
+// runs in rounds of #CUs tiles: plan_launch picks the form with the shortest list-scheduling makespan.  (A stream-K form
+// of the 256 x 256 kernel that shares the last round's K-iterations among all CUs was built in round 1 and measured 2x
+// slower: DESIGN.md section 4b; git history.)
+int fk_gemm2_launch(const fk_gemm_args* probs, int n, int variant_hint, hipStream_t stream) {
   GroupArgs ga;
   ga.n = n;
-  long t128 = 0, t256 = 0;
+  ga.big_cols = 0;
+  ga.sk_partials = nullptr;
+  ga.sk_ctl = nullptr;
+  long nbm_total = 0;
   bool ok256 = probs[0].N % 256 == 0, ok32 = true;   // ok32: a tile's rows are addressable with 32-bit byte offsets
   for (int i = 0; i < FK_MAX_GROUP; ++i) {
     ga.p[i] = probs[i < n ? i : 0];
     if (i < n) {
-      const long nbm = (probs[i].M + BM - 1) / BM;
-      t128 += nbm * ((probs[i].N + 127) / 128);
-      t256 += nbm * ((probs[i].N + 255) / 256);
+      nbm_total += (probs[i].M + BM - 1) / BM;
       // both kernels address a tile's rows with 32-bit byte offsets from the tile's first row
       auto span = [](const fk_rows& r) {
         const long long ld = r.ld < 0 ? -r.ld : r.ld, bs = r.batch_stride < 0 ? -r.batch_stride : r.batch_stride;
@@ -749,22 +979,53 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t s
   }
   if (!ok32) return FK_E2BIG_STRIDES;   // caller falls back to the 128 x 128 kernel (64-bit addressing)
 
+  // split-K workspace (optional, caller-owned): slots x 256 KiB of fp32 partial tiles, then slots x 2 control words
+  const int ws_slots = probs[0].splitk_ws ? probs[0].splitk_slots : 0;
+  const int N = probs[0].N, K = probs[0].K;
   const int G = cu_count();
-  int bn = bn_hint;
-  if (bn == 256 && !ok256) bn = 128;
-  if (bn != 128 && bn != 256) {
-    auto eff = [G](long tiles) { return (double)tiles / (double)(((tiles + G - 1) / G) * G); };
-    bn = (ok256 && FK_RATE_256 * eff(t256) > eff(t128)) ? 256 : 128;
+  const long t256 = nbm_total * ((N + 255) / 256);
+  const bool sk_ok = ws_slots > 0 && ok256 && (K / 64) % 4 == 0 && t256 <= ws_slots;
+  Plan plan;
+  switch (variant_hint) {
+    case 128: plan = {128, 0}; break;
+    case 256: plan = {ok256 ? 256 : 128, 0}; break;
+    case 384: {
+      plan = plan_launch(nbm_total, N, K, G, 1, false, 0);
+      if (plan.variant != 384) {   // forced: the best split of the columns even where it does not pay
+        plan = {128, 0};
+        if (ok256 && N >= 512) {
+          double tb = 1e30;
+          for (int cb = 1; cb < N / 256; ++cb) {
+            if (nbm_total * 2 * (N / 256 - cb) < 8) continue;
+            const double t = makespan(nbm_total * cb, nbm_total * 2 * (N / 256 - cb), 0.5 * FK_RATE_256, G);
+            if (t < tb) { tb = t; plan = {384, cb}; }
+          }
+        }
+      }
+      break;
+    }
+    case 512: plan = {sk_ok ? 512 : (ok256 ? 256 : 128), 0}; break;
+    default: plan = plan_launch(nbm_total, N, K, G, plan_allow(), sk_ok, ws_slots); break;
   }
-  g_last_variant = bn;
+  if (plan.variant == 512) {
+    ga.sk_partials = (float*)probs[0].splitk_ws;
+    ga.sk_ctl = (unsigned*)((char*)probs[0].splitk_ws + (size_t)ws_slots * (BM * 256 * 4));
+  }
+  g_last_variant = plan.variant;
+  int rc;
   switch (probs[0].epilogue) {
-    case FK_EPI_NONE: return launch_bn<FK_EPI_NONE>(ga, probs, n, bn, stream);
-    case FK_EPI_GELU_TANH: return launch_bn<FK_EPI_GELU_TANH>(ga, probs, n, bn, stream);
-    case FK_EPI_SILU: return launch_bn<FK_EPI_SILU>(ga, probs, n, bn, stream);
-    case FK_EPI_GATE_RES: return launch_bn<FK_EPI_GATE_RES>(ga, probs, n, bn, stream);
-    case FK_EPI_RES: return launch_bn<FK_EPI_RES>(ga, probs, n, bn, stream);
-    case FK_EPI_SCALE: return launch_bn<FK_EPI_SCALE>(ga, probs, n, bn, stream);
-    case FK_EPI_QKV: return launch_bn<FK_EPI_QKV>(ga, probs, n, bn, stream);
+    case FK_EPI_NONE: rc = launch_variant<FK_EPI_NONE>(ga, probs, n, plan.variant, plan.big_cols, stream); break;
+    case FK_EPI_GELU_TANH: rc = launch_variant<FK_EPI_GELU_TANH>(ga, probs, n, plan.variant, plan.big_cols, stream); break;
+    case FK_EPI_SILU: rc = launch_variant<FK_EPI_SILU>(ga, probs, n, plan.variant, plan.big_cols, stream); break;
+    case FK_EPI_GATE_RES: rc = launch_variant<FK_EPI_GATE_RES>(ga, probs, n, plan.variant, plan.big_cols, stream); break;
+    case FK_EPI_RES: rc = launch_variant<FK_EPI_RES>(ga, probs, n, plan.variant, plan.big_cols, stream); break;
+    case FK_EPI_SCALE: rc = launch_variant<FK_EPI_SCALE>(ga, probs, n, plan.variant, plan.big_cols, stream); break;
+    case FK_EPI_QKV: rc = launch_variant<FK_EPI_QKV>(ga, probs, n, plan.variant, plan.big_cols, stream); break;
     default: fk_set_error("fk_gemm_bf16: unknown epilogue %d", probs[0].epilogue); return FK_EUNSUPPORTED;
   }
+  if (rc == FK_E2BIG_STRIDES && plan.variant == 384) {   // degenerate XCD split of a mixed grid: plain 256 x 128 grid
+    g_last_variant = 128;
+    return fk_gemm2_launch(probs, n, 128, stream);
+  }
+  return rc;
 }

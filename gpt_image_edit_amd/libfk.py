@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("FK_LIB_PATH") or os.path.join(_HERE, "libfk_gfx950.so
 
 c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
+FK_SPLITK_SLOT_BYTES = 256 * 256 * 4 + 8   # include/fk.h: one fp32 partial tile + its (ticket, flag) words
 FK_EPI_NONE, FK_EPI_GELU_TANH, FK_EPI_SILU, FK_EPI_GATE_RES, FK_EPI_RES, FK_EPI_SCALE, FK_EPI_QKV = range(7)
 
 
@@ -30,8 +31,8 @@ class GemmArgs(ctypes.Structure):
         ("gate", c_vp), ("gate_batch_stride", c_i64), ("gate_rows_per_batch", c_i64),
         ("M", c_i32), ("N", c_i32), ("K", c_i32),
         ("epilogue", c_i32), ("out_fp32", c_i32), ("alpha", c_f32),
-        ("q_out", c_vp), ("k_out", c_vp), ("wq", c_vp), ("wk", c_vp), ("rope_cs", c_vp), ("reserved_ptr_", c_vp),
-        ("qkv_s_offset", c_i32), ("qkv_s_total", c_i32), ("qkv_heads", c_i32), ("reserved_", c_i32),
+        ("q_out", c_vp), ("k_out", c_vp), ("wq", c_vp), ("wk", c_vp), ("rope_cs", c_vp), ("splitk_ws", c_vp),
+        ("qkv_s_offset", c_i32), ("qkv_s_total", c_i32), ("qkv_heads", c_i32), ("splitk_slots", c_i32),
     ]
 
 
@@ -54,10 +55,12 @@ SIGNATURES = {
     "fk_gemm_bf16_grouped": (c_i32, [ctypes.POINTER(GemmArgs), c_i32, c_vp]),
     "fk_gemm_last_variant": (c_i32, []),
     "fk_gemm_set_variant": (c_i32, [c_i32]),
+    "fk_gemm_set_plan": (c_i32, [c_i32]),
     "fk_ln_modulate_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "fk_ln_modulate2_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "fk_qkv_post_bf16": (c_i32, [c_vp] * 9 + [c_i32] * 4 + [c_f32, c_vp]),
     "fk_attention_fwd_bf16": (c_i32, [c_vp] * 4 + [c_i32] * 3 + [c_i64] * 4 + [c_f32, c_vp]),
+    "fk_attention_set_tail": (c_i32, [c_i32]),
     "fk_attention_fwd_f32_debug": (c_i32, [c_vp] * 4 + [c_i32] * 3 + [c_i64] * 4 + [c_f32, c_vp]),
     "fk_attention_fwd_lse_bf16": (c_i32, [c_vp] * 5 + [c_i32] * 3 + [c_i64] * 4 + [c_f32, c_vp]),
     "fk_attention_bwd_bf16": (c_i32, [ctypes.POINTER(AttnView)] * 4 + [c_vp, c_vp] + [ctypes.POINTER(AttnView)] * 3 + [c_i32] * 3 + [c_f32, c_vp]),

@@ -51,6 +51,22 @@ def rows_of(t):
     raise ValueError(f"expected a 2-D or 3-D tensor, got {t.dim()}-D")
 
 
+# Split-K workspace (fk.h: fk_gemm_args.splitk_ws): one per (device, stream) -- launches that share one must be ordered.
+# 128 slots cover every grid the planner splits (two half-K workgroups per tile on at most all 256 CUs); 32 MiB each.
+SPLITK_SLOTS = 128
+_SPLITK_WS = {}
+
+
+def splitk_workspace(device):
+    """(uint8 buffer, slots) for the current stream of ``device``; control words zeroed once (monotonic tickets after)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    ws = _SPLITK_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(SPLITK_SLOTS * libfk.FK_SPLITK_SLOT_BYTES, device=device, dtype=torch.uint8)
+        _SPLITK_WS[key] = ws
+    return ws, SPLITK_SLOTS
+
+
 def _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv=None):
     _need_cuda(a, w, bias, out, res, gate)
     M, ra = rows_of(a)
@@ -83,6 +99,9 @@ def _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv=None):
         args.gate_rows_per_batch = a.shape[1]
     args.M, args.N, args.K = M, N, K
     args.epilogue, args.out_fp32, args.alpha = epilogue, int(out_fp32), float(alpha)
+    if K >= 6144 and N % 256 == 0 and M <= 256 * SPLITK_SLOTS and not out_fp32:   # the only shapes the planner may split
+        ws, slots = splitk_workspace(a.device)
+        args.splitk_ws, args.splitk_slots = ws.data_ptr(), slots
     if epilogue == FK_EPI_QKV:
         cs = qkv["cs"] if "cs" in qkv else pack_rope(qkv["cos"], qkv["sin"])
         _need_cuda(qkv["q_out"], qkv["k_out"], qkv["wq"], qkv["wk"], cs)
@@ -106,6 +125,12 @@ def gemm(a, w, bias=None, out=None, epilogue=FK_EPI_NONE, res=None, gate=None, o
     args, out = _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv)
     libfk.check(libfk.load().fk_gemm_bf16(ctypes.byref(args), _stream()), "fk_gemm_bf16")
     return out
+
+
+def gemm_set_plan(allow):
+    """fk_gemm_set_plan: bit 0 = mixed grids (bit-identical results), bit 1 = split-K pairs (last-bit differences against
+    the unsplit sum, so a sample's result then depends on how full the grid is).  ``gemm_set_plan(1)`` = batch-invariant."""
+    libfk.check(libfk.load().fk_gemm_set_plan(int(allow)), "fk_gemm_set_plan")
 
 
 def gemm_grouped(problems, epilogue=FK_EPI_NONE):

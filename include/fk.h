@@ -92,19 +92,30 @@ typedef struct fk_gemm_args {
   const float* rope_cs;          /* fp32 [S_total, 64, 2]: (cos, sin) of every rotary pair (FluxPosEmbed repeats each
                                   * value over the two columns of its pair, so the [S,128] cos / sin tables hold
                                   * every number twice; the epilogue reads 512 B per token row instead of 1 KiB) */
-  const void* reserved_ptr_;
+  /* Optional split-K workspace (caller-owned, one per stream that issues GEMMs): splitk_slots x 256 KiB of fp32 partial
+   * tiles followed by splitk_slots x 2 uint32 control words, the control words zeroed ONCE at allocation (they are
+   * monotonic tickets afterwards).  With it, a K >= 6144 GEMM whose 256 x 256 tiling fills at most half the CUs runs
+   * as two half-K workgroups per tile (deterministic: the two fp32 partials are added once, and fp32 addition
+   * commutes).  NULL: never split.  Launches that share a workspace must be ordered (same stream). */
+  void* splitk_ws;
   int32_t qkv_s_offset, qkv_s_total, qkv_heads;
-  int32_t reserved_;
+  int32_t splitk_slots;
 } fk_gemm_args;
+#define FK_SPLITK_SLOT_BYTES (256 * 256 * 4 + 8)
 
 int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream);
-/* Which large tile the calling thread's last fk_gemm_bf16[_grouped] used: 128 = 256 x 128, 256 = 256 x 256,
- * 0 = neither so far (tests, profiling). */
+/* Which large-tile launch the calling thread's last fk_gemm_bf16[_grouped] used: 128 = 256 x 128 tiles, 256 = 256 x 256,
+ * 384 = mixed grid, 512 = split-K pairs of 256 x 256 tiles, 0 = none so far (tests, profiling). */
 int fk_gemm_last_variant(void);
-/* Tuning / measurement hook: force the large-tile kernel of every later fk_gemm_bf16[_grouped] call of the process:
- * 128 = 256 x 128 tile, 256 = 256 x 256 tile; 0 = back to the per-problem choice.  Same results bit for bit
- * whichever is used. */
+/* Tuning / measurement hook: force the launch form of every later fk_gemm_bf16[_grouped] call of the process where
+ * it applies: 128 = 256 x 128 tiles, 256 = 256 x 256 tiles, 384 = mixed grid, 512 = split-K pairs; 0 = back to the
+ * per-problem choice.  128 / 256 / 384 give the same results bit for bit. */
 int fk_gemm_set_variant(int32_t variant);
+/* Which launch forms the per-problem choice may use: bit 0 = mixed grids (one round of 256 x 256 tiles, the remaining
+ * columns as 256 x 128 tiles; bit-identical results), bit 1 = split-K pairs (results differ in the last bits from the
+ * unsplit sum).  Default 3 (FK_GEMM_PLAN overrides).  With bit 1 clear a GEMM's result does not depend on the grid it
+ * runs in, i.e. a sample computed inside a batch equals the same sample computed alone bit for bit. */
+int fk_gemm_set_plan(int32_t allow);
 
 /* n (<= FK_MAX_GROUP) independent problems that share N, K and the epilogue in ONE launch: the text- and
  * image-stream linears of a FluxTransformerBlock (different weights, different row counts) fill the GPU
@@ -146,6 +157,11 @@ int fk_qkv_post_bf16(const void* qkv, void* q_out, void* k_out, const void* wq_i
 int fk_attention_fwd_bf16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H,
                           int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld,
                           int64_t o_batch_stride, float scale, fk_stream_t stream);
+/* Measurement hook: 1 (default; FK_ATTN_TAIL overrides) = the blocks of a grid's last, partly filled round of CUs run
+ * as 2- or 4-wave workgroups of 64 / 128 query rows so that they spread over the idle CUs; 0 = plain grid.  Same
+ * results bit for bit: a query row's arithmetic does not depend on the workgroup shape that carries it. */
+int fk_attention_set_tail(int32_t mode);
+
 /* Parity / debug build of the SAME kernel (same tiling, LDS layouts, softmax, key <-> MFMA k-slot binding): the output
  * is fp32 (o_ld / o_batch_stride in fp32 elements, 16-byte aligned) and every probability enters the PV product as
  * two bf16 terms (hi + lo), so the result can be compared with an fp32 reference at the tolerance BASELINE.json

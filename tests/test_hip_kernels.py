@@ -129,10 +129,12 @@ def _last_variant():
     return libfk.load().fk_gemm_last_variant()
 
 
-@pytest.mark.parametrize("B,S,N,K,want", [(1, 2560, 12288, 3072, 256), (1, 2560, 9216, 3072, 128),
-                                          (3, 100, 512, 128, 128), (2, 1200, 3072, 1024, 128)])
+@pytest.mark.parametrize("B,S,N,K,want", [(1, 2560, 12288, 3072, 256), (1, 2560, 9216, 3072, 384),
+                                          (3, 100, 512, 128, 128), (2, 1200, 3072, 1024, 128), (1, 2560, 3072, 12288, 512)])
 def test_gemm_tile_choice_and_batched_epilogue(ops, B, S, N, K, want):
-    # the launcher picks the 256 x 256 (4-wave) kernel only where its higher rate survives the round quantisation;
+    # the launcher picks the launch form with the shortest makespan over 256 CUs: 256 x 256 tiles where their higher rate
+    # survives the round quantisation, one round of them + 256 x 128 tiles for the rest (384) where that beats both pure
+    # grids, two half-K workgroups per 256 x 256 tile (512) for a long-K GEMM that fills at most half the chip;
     # both kernels address batched [B, S, :] operands per tile (one division per tile, a compare per row; batches
     # shorter than a tile take the reciprocal path) -- gated residual in place, like the blocks use it
     x = randn(B, S, K, seed=64)
@@ -145,8 +147,15 @@ def test_gemm_tile_choice_and_batched_epilogue(ops, B, S, N, K, want):
     y = (x.float() @ w.float().T + bias.float()).to(BF)
     ref = res + mod[:, None, N:2 * N] * y
     assert_bf16_close(f"gate_res B{B} S{S} N{N}", rd, ref, max_ulp=1, max_bad_frac=2e-3)
-    got = ops.gemm(xd, w.cuda(), bias.cuda(), epilogue=ops.FK_EPI_GELU_TANH)
-    assert_bf16_close(f"gelu B{B} S{S} N{N}", got, F.gelu(y, approximate="tanh"), max_ulp=1, max_bad_frac=1e-4)
+    if K <= 3072:   # (at K = 12288 the pre-activations reach -8: GELU outputs of 1e-14, where one ulp means nothing)
+        got = ops.gemm(xd, w.cuda(), bias.cuda(), epilogue=ops.FK_EPI_GELU_TANH)
+        assert_bf16_close(f"gelu B{B} S{S} N{N}", got, F.gelu(y, approximate="tanh"), max_ulp=1, max_bad_frac=1e-4)
+    else:           # the split-K pair is deterministic: fp32 addition of the two partial tiles commutes
+        first = rd.clone()
+        for _ in range(3):
+            rd2 = res.cuda()
+            ops.gemm(xd, w.cuda(), bias.cuda(), out=rd2, epilogue=ops.FK_EPI_GATE_RES, res=rd2, gate=md[:, N:2 * N])
+            assert torch.equal(rd2, first)
 
 
 def test_gemm_grouped(ops):

@@ -19,8 +19,11 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 BUDGET = {
     "attention_fwd.hip": [("attention_fwd_kernel", 64)],
     "attention_bwd.hip": [("attention_bwd_kernel", 64)],
-    "gemm_pingpong_bf16.hip": [("gemm8_kernel", 0), ("gemm9_kernel", 0)],
+    # the split-K instantiation (..., true) moves one accumulator tile through scratch around its rendezvous, outside the
+    # K loop (at most 8 stores + 8 loads per workgroup); every other instantiation keeps everything in registers
+    "gemm_pingpong_bf16.hip": [("gemm8_kernelILi", 0), ("gemm9_kernel", 0), ("gemm_mix_kernel", 0)],
 }
+EXCEPTIONS = {"gemm8_kernelILi": ("Lb1EEE", 136, 32)}   # key -> (name fragment, max scratch bytes, max spilled VGPRs)
 
 
 @pytest.mark.parametrize("src", sorted(BUDGET))
@@ -40,7 +43,15 @@ def test_hot_kernels_keep_their_accumulators_in_registers(src, tmp_path):
         for key, max_scratch in BUDGET[src]:
             if key in name:
                 seen += 1
-                assert int(vgprs) <= 256, f"{name}: {vgprs} VGPRs"
+                # two waves per SIMD -> 256 registers each; the light attention workgroups (2 / 4 waves = one wave per
+                # SIMD, launched for the last partial round only) may take the whole 512-entry file
+                light = "attention_fwd_kernelILi2E" in name or "attention_fwd_kernelILi4E" in name
+                assert int(vgprs) <= (512 if light else 256), f"{name}: {vgprs} VGPRs"
+                frag, relaxed, max_spills = EXCEPTIONS.get(key, (None, 0, 16))
+                if frag and frag in name:
+                    max_scratch = relaxed
+                else:
+                    max_spills = 16
                 assert int(scratch) <= max_scratch, f"{name}: {scratch} B of scratch per lane (arrays in private memory?)"
-                assert int(spills) <= 16, f"{name}: {spills} spilled VGPRs"
+                assert int(spills) <= max_spills, f"{name}: {spills} spilled VGPRs"
     assert seen >= len(BUDGET[src]), f"expected kernels {BUDGET[src]} in {src}"
