@@ -55,7 +55,9 @@ WORKLOADS = {
     "cfg4_slice4_1024x1024_28step": (4, 1024, 1024, 1024, 1024, 512),
 }
 EXTRA_WORKLOAD = "single_1024x1024_28step"
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+if not os.path.exists(TRAFFIC_FILE):
+    TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
 def build_pipeline(device, n_double=19, n_single=38):
@@ -147,17 +149,18 @@ def instrumented_edit(pipe, inp):
 def roofline_of(fam, workload):
     """`roofline` object of the bench line from the instrumented edit's family sums (+ the committed PMC traffic)."""
     gm = fam["gemm"]
-    traffic, traffic_note = None, None
+    traffic, traffic_note, traffic_classes = None, None, None
     if os.path.exists(TRAFFIC_FILE):
         try:
             tr = json.load(open(TRAFFIC_FILE))
             ent = tr.get("gemm", {}).get(workload) or tr.get("gemm", {}).get("default")
             if ent:
                 traffic, traffic_note = ent["hbm_bytes_per_launch"], ent.get("note")
+                traffic_classes = ent.get("classes")
         except Exception as e:  # a malformed side file must not cost the bench line
             traffic_note = f"unreadable {TRAFFIC_FILE}: {e}"
     rl = {
-        "kernel": "gemm8_kernel<*> + gemm9_kernel<*> + gemm_bf16_kernel<*> (bf16 MFMA GEMM family: all MMDiT / VAE linears)",
+        "kernel": "gemm8_kernel<*> + gemm_mix_kernel<*> + gemm9_kernel<*> + gemm_bf16_kernel<*> (bf16 MFMA GEMM family: all MMDiT / VAE linears)",
         "bound": "mfma", "achieved": gm["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": gm["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
         "launches_per_edit": gm["launches"], "ms_per_edit": gm["ms"], "algorithmic_tflop_per_edit": gm["flops"] / 1e12,
@@ -166,6 +169,9 @@ def roofline_of(fam, workload):
     }
     if traffic_note:
         rl["traffic_note"] = traffic_note
+    if traffic_classes:   # counted bytes beyond the XCD L2s per launch of EVERY GEMM launch class of the workload
+        rl["traffic_by_launch_class"] = {k: {"bytes": v["hbm_bytes_per_launch"], "x_algorithmic": v["ratio"], "l2_hit": v["l2_hit"]}
+                                         for k, v in traffic_classes.items()}
     return rl
 
 
@@ -282,7 +288,7 @@ def train_step_bench(device, steps=3, warmup=1, world=1):
         return nb * 24 * D * D * S + nb * 4 * S * S * D + 2 * (n_double * 12 + n_single * 3 + 2) * D * D
     model = HipFluxTransformer2DModel(dict(flux_spec.FLUX_KONTEXT_CONFIG), device=device, init="synthetic", seed=0)
     projector = HipDenoiseProjector(device=device, init="synthetic", seed=1)
-    ts = DenoiserTrainStep(model, sharded=True, projector=projector)
+    ts = DenoiserTrainStep(model, sharded=True, projector=projector, keep_grads=False)   # gradients live in the ZeRO buckets only
     g = torch.Generator(device=device).manual_seed(7)
     B, h, w, L_vlm, L_t5 = 1, 128, 128, 256, 256
     S_txt = L_vlm + L_t5
@@ -311,6 +317,8 @@ def train_step_bench(device, steps=3, warmup=1, world=1):
     fwd = flops_forward(S)
     return {"value": B * world / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "n_gpus": world, "steps": steps, "warmup": warmup,
             "loss": float(out["loss"].item()), "trainable_params": n_train, "seq_len": S,
+            "peak_memory_gb": torch.cuda.max_memory_allocated(device) / 1e9,
+            "zero2_buckets": len(ts.opt.layout.buckets),
             "forward_tflop": fwd / 1e12,
             "model_tflops_3x_forward": 3 * fwd / dt / 1e12,
             "frac_of_mfma_peak_3x_forward": 3 * fwd / dt / 1e12 / PEAK_BF16_TFLOPS,

@@ -258,9 +258,12 @@ class FluxBackward:
 
     # ---- backward ----------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def backward(self, dsample):
+    def backward(self, dsample, sink=None, keep=True):
         """dsample: gradient of the loss w.r.t. the forward's output [B, S_img, 64] (bf16).
-        Returns (grads: dict name -> tensor, d_encoder_hidden_states [B, S_txt, joint_dim] bf16)."""
+        Returns (grads: dict name -> tensor, d_encoder_hidden_states [B, S_txt, joint_dim] bf16).
+        ``sink``: called with every block's trainable gradients as soon as that block's backward has been enqueued
+        (``zero.ShardedAdamW.accumulate``: the bucket's reduce-scatter then overlaps the earlier blocks' backward);
+        ``keep=False`` drops them from the returned dict afterwards (they live on in the sink)."""
         sv = self._saved
         if sv is None:
             raise RuntimeError("FluxBackward.backward() needs the forward() of the same step first")
@@ -277,19 +280,30 @@ class FluxBackward:
         ops.gemm(dsample.to(BF16).contiguous(), self.wT("proj_out.weight"), out=dn[:, S_txt:])
         ops.ln_modulate_bwd(sv.ckpt[nd + ns][:, S_txt:], dn[:, S_txt:], mod[:, pk.mod_out: pk.mod_out + D], g[:, S_txt:], dmod_out)
         s = ws.s
+
+        def emit(block_grads):
+            bg = {k: v for k, v in block_grads.items() if k in self.trainable}
+            if sink is not None:
+                sink(bg)
+            if keep or sink is None:
+                grads.update(bg)
         for j in reversed(range(ns)):
             if not sv.store:
                 s.copy_(sv.ckpt[nd + j])
                 self._single_forward(j, sv, s, save=True)
-            self._single_backward(j, sv, g, grads)
+            bg = {}
+            self._single_backward(j, sv, g, bg)
+            emit(bg)
         for i in reversed(range(nd)):
             if not sv.store:
                 s.copy_(sv.ckpt[i])
                 self._double_forward(i, sv, s, save=True)
-            self._double_backward(i, sv, g, grads)
+            bg = {}
+            self._double_backward(i, sv, g, bg)
+            emit(bg)
         d_enc = ops.gemm(g[:, :S_txt], self.wT("context_embedder.weight"))
         self._saved = None
-        return {k: v for k, v in grads.items() if k in self.trainable}, d_enc
+        return grads, d_enc
 
     def _double_backward(self, i, sv, g, grads):
         m, P, ws, pk = self.m, self.m.p, sv.ws, sv.pk

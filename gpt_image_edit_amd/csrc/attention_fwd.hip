@@ -42,9 +42,10 @@ struct AttnParams {
   int64_t o_ld, o_bs;
   float scale_log2;    // scale * log2(e)
   float* lse;          // optional [B, H, S]: log2-domain log-sum-exp of every row (saved for the backward pass)
-  // which query rows this launch covers: the (b, h, 256-row block) list is cut into `subs` workgroups per block (subs x
-  // NW x 32 = 256 rows); workgroup t of the launch works on block t0 + t / subs, rows [sub * NW * 32, (sub + 1) * NW * 32)
-  int t0, subs;
+  // The (b, h, 256-row block) list: blocks [0, n_full) are one workgroup each (8 waves x 32 rows); every later block is
+  // cut into `light_subs` (4 / 2) "light" workgroups in which all 8 waves keep loading K / V tiles but only the first
+  // 8 / light_subs waves own query rows (see attention_entry).  light_subs = 0: no light workgroups.
+  int n_full, light_subs;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -103,12 +104,19 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   }
-  const int tb = p.t0 + t / p.subs, sub = t % p.subs;
+  int tb = t, sub = 0, nact = NW;           // nact: waves of this workgroup that own query rows
+  if (t >= p.n_full) {
+    const int l = t - p.n_full;
+    tb = p.n_full + l / p.light_subs;
+    sub = l - (l / p.light_subs) * p.light_subs;
+    nact = NW / p.light_subs;
+  }
   const int qb = tb % nqb;
   const int bh = tb / nqb;
   const int b = bh / p.H, h = bh - b * p.H;
-  const int q_row0 = qb * QSPAN + sub * QBLK;
-  if (q_row0 >= p.S) return;                // ragged last block of a light launch: nothing for this workgroup
+  const int q_row0 = qb * QSPAN + sub * nact * 32;
+  if (q_row0 >= p.S) return;                // ragged last block: nothing for this light workgroup
+  const bool active = wave < nact;          // wave-uniform; the other waves only feed the K / V ring and keep the barriers
 
   const bf16_t* Kg = p.k + (int64_t)bh * p.S * HD;
   const bf16_t* Vg = p.v + (int64_t)b * p.v_bs + h * HD;
@@ -253,6 +261,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
     if constexpr (!ILV) {
       constexpr bool FIRST = decltype(first_tag)::value;
       const char* sb = acquire_tile(kt);
+      if (!active) { release_tile(); return; }
       float psum = 0.f;
   #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -308,6 +317,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
       constexpr bool FIRST = decltype(first_tag)::value;
       constexpr bool MASK = decltype(mask_tag)::value;
       const char* sb = acquire_tile(kt);
+      if (!active) { release_tile(); return; }
       float psum = 0.f;
       f32x16_t s0 = scores(sb, 0, kt, mask_tag);
       if constexpr (FIRST) m_ref = block_max(s0) + REF_BIAS;   // reference = row maximum over the first 32 keys + bias
@@ -414,10 +424,12 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
       m_ref = -3.0e38f;
       for (int kt = 0; kt < nkt; ++kt) {
         const char* sb = acquire_tile(kt);
+        if (active) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          if (ragged && kt == nkt - 1) m_ref = fmaxf(m_ref, block_max(scores(sb, kb, kt, TT{})));
-          else m_ref = fmaxf(m_ref, block_max(scores(sb, kb, kt, FF{})));
+          for (int kb = 0; kb < 2; ++kb) {
+            if (ragged && kt == nkt - 1) m_ref = fmaxf(m_ref, block_max(scores(sb, kb, kt, TT{})));
+            else m_ref = fmaxf(m_ref, block_max(scores(sb, kb, kt, FF{})));
+          }
         }
         release_tile();
       }
@@ -466,6 +478,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
     }
   }
 
+  if (!active) return;
   // ---- finalize: O = O^T / l ; lane (q = ql) holds d = 32 df + 8 g + 4 hh + (0..3), g = r >> 2 -------------
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
@@ -533,27 +546,26 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
 // barrier (timing probe): +1..6 %.  Counters at B = 4, S = 8704: matrix pipe 52 % busy at 1.86 GHz, waves 37 % parked,
 // 32 % issue-stalled, LDS array ~26 % busy, no bank conflicts.
 
-// blocks [t0, t0 + nblocks) of the (b, h, 256-row block) list, 256 / (NW * 32) workgroups per block
 template <int NW, int STAGES, bool F32OUT, bool ILV>
-int launch(AttnParams p, hipStream_t stream, int t0, int nblocks) {
+int launch(AttnParams p, hipStream_t stream, int n_full, int n_light_blocks, int light_subs) {
   constexpr int SMEM = STAGES * STAGE_BYTES + 16;   // ring + the restart flag word
   auto kern = attention_fwd_kernel<NW, STAGES, F32OUT, ILV>;
   FK_ENSURE_MAX_LDS(kern, SMEM, "fk_attention_fwd_bf16");
-  p.t0 = t0;
-  p.subs = 8 / NW;
-  if (nblocks <= 0) return FK_OK;
-  hipLaunchKernelGGL(kern, dim3(nblocks * p.subs), dim3(NW * 64), SMEM, stream, p);
+  p.n_full = n_full;
+  p.light_subs = light_subs;
+  hipLaunchKernelGGL(kern, dim3(n_full + n_light_blocks * light_subs), dim3(NW * 64), SMEM, stream, p);
   FK_CHECK_LAUNCH("fk_attention_fwd_bf16");
   return FK_OK;
 }
 
 // The last, partly filled round of a grid.  One workgroup (8 waves x 32 query rows) per CU means the grid runs in
 // rounds of #CUs blocks; at batch 1 and S = 8704 that is 816 blocks = 3 full rounds + 48 blocks that hold 48 CUs for a
-// whole fourth round while 208 idle.  Those tail blocks are launched as FOUR (or two) workgroups of 2 (4) waves each --
-// 64 (128) query rows against the same K / V stream, one wave per SIMD -- so the tail spreads over 192 CUs and ends
-// early (a lone wave on its SIMD runs ~1.4x faster than two sharing one).  Every query row's arithmetic is the same
-// whichever workgroup shape carries it, so the output is bit-identical to the plain grid (and a sample still equals
-// itself inside any batch).  FK_ATTN_TAIL=0 disables (A/B).
+// whole fourth round while 208 idle.  Those tail blocks can be run as FOUR (or two) "light" workgroups each, at the end
+// of the same launch: all 8 waves of a light workgroup keep issuing their share of the K / V LDS-DMA requests (the
+// request issue, ~60 cycles apiece, is what a wave cannot afford to do alone: a 2-wave workgroup that loads for itself
+// measured SLOWER in the edit), but only 2 (4) waves own query rows -- one computing wave per SIMD instead of two, so
+// each runs faster and the tail spreads over 192 CUs.  Every query row's arithmetic is the same whichever workgroup
+// shape carries it: bit-identical output.  fk_attention_set_tail / FK_ATTN_TAIL select it.
 static int g_attn_tail = -2;
 static int attn_tail_mode() {
   if (g_attn_tail == -2) {
@@ -610,18 +622,16 @@ int attention_entry(const void* q, const void* k, const void* v, void* o, int32_
   p.scale_log2 = scale * 1.4426950408889634f;
   p.lse = lse;
   const int nblk = ((S + 255) / 256) * H * B;
-  if (f32out) return launch<8, 3, true, false>(p, stream, 0, nblk);
+  if (f32out) return launch<8, 3, true, false>(p, stream, nblk, 0, 0);
   const int G = attn_cu_count();
-  int tail = 0, tail_waves = 0;                     // blocks handed to light workgroups, waves per light workgroup
+  int tail = 0, subs = 0;                          // blocks handed to light workgroups, light workgroups per block
   if (attn_tail_mode() && nblk > G && nblk % G != 0) {
     const int rem = nblk % G;
-    if (4 * rem <= G) { tail = rem; tail_waves = 2; }
-    else if (2 * rem <= G) { tail = rem; tail_waves = 4; }
+    if (4 * rem <= G) { tail = rem; subs = 4; }
+    else if (2 * rem <= G) { tail = rem; subs = 2; }
   }
-  const int nfull = nblk - tail;
-  int rc = use_interleaved(p) ? launch<8, 3, false, true>(p, stream, 0, nfull) : launch<8, 3, false, false>(p, stream, 0, nfull);
-  if (rc != FK_OK || !tail) return rc;
-  return tail_waves == 2 ? launch<2, 3, false, false>(p, stream, nfull, tail) : launch<4, 3, false, false>(p, stream, nfull, tail);
+  return use_interleaved(p) ? launch<8, 3, false, true>(p, stream, nblk - tail, tail, subs)
+                            : launch<8, 3, false, false>(p, stream, nblk - tail, tail, subs);
 }
 
 }  // namespace

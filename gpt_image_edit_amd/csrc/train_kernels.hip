@@ -95,12 +95,14 @@ __global__ __launch_bounds__(RED_THREADS) void finish_sum_kernel(const double* p
 //   v = b2*v + (1-b2)*g*g;  p -= step_size (= lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps);  bf16 copy of p
 __global__ __launch_bounds__(256) void adamw_kernel(float* master, bf16_t* param_bf16, const void* grad, int g_is_bf16,
                                                     float* m, float* v, const double* grad_sumsq, float max_norm,
-                                                    float decay, float b1, float b2, float eps, float step_size,
-                                                    float bc2_sqrt, int64_t n) {
-  float coef = 1.0f;
+                                                    float grad_scale, float decay, float b1, float b2, float eps,
+                                                    float step_size, float bc2_sqrt, int64_t n) {
+  // grad_scale: the stored gradients are grad_scale^-1 times the gradient to apply (sums over the data-parallel ranks:
+  // grad_scale = 1 / world) -- folded into the clipping coefficient, so no separate pass divides them
+  float coef = grad_scale;
   if (grad_sumsq) {
-    const float total = (float)sqrt(grad_sumsq[0]);
-    coef = fminf(max_norm / (total + 1e-6f), 1.0f);
+    const float total = __fmul_rn((float)sqrt(grad_sumsq[0]), grad_scale);
+    coef = __fmul_rn(fminf(max_norm / (total + 1e-6f), 1.0f), grad_scale);
   }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float g = g_is_bf16 ? bf2f(((const bf16_t*)grad)[i]) : ((const float*)grad)[i];
@@ -166,17 +168,26 @@ extern "C" int fk_sumsq(const void* g, int32_t g_is_bf16, int64_t n, int32_t acc
   return FK_OK;
 }
 
-extern "C" int fk_adamw_step(float* master, void* param_bf16, const void* grad, int32_t grad_is_bf16, float* exp_avg,
-                             float* exp_avg_sq, const double* grad_sumsq, float max_grad_norm, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, int32_t step, int64_t n, fk_stream_t stream) {
-  FK_CHECK_ARG(master && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "fk_adamw_step: bad arguments");
+extern "C" int fk_adamw_step_scaled(float* master, void* param_bf16, const void* grad, int32_t grad_is_bf16, float* exp_avg,
+                                    float* exp_avg_sq, const double* grad_sumsq, float max_grad_norm, float grad_scale,
+                                    float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                                    int64_t n, fk_stream_t stream) {
+  FK_CHECK_ARG(master && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1 && grad_scale > 0.f,
+               "fk_adamw_step: bad arguments");
   // the scalar factors in double on the host, like torch's python-side arithmetic, then fp32 into the kernel
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
   const float decay = (float)(1.0 - (double)lr * (double)weight_decay);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, master, (bf16_t*)param_bf16,
-                     grad, grad_is_bf16, exp_avg, exp_avg_sq, grad_sumsq, max_grad_norm, decay, beta1, beta2, eps,
-                     step_size, bc2_sqrt, n);
+                     grad, grad_is_bf16, exp_avg, exp_avg_sq, grad_sumsq, max_grad_norm, grad_scale, decay, beta1, beta2,
+                     eps, step_size, bc2_sqrt, n);
   FK_CHECK_LAUNCH("fk_adamw_step");
   return FK_OK;
+}
+
+extern "C" int fk_adamw_step(float* master, void* param_bf16, const void* grad, int32_t grad_is_bf16, float* exp_avg,
+                             float* exp_avg_sq, const double* grad_sumsq, float max_grad_norm, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int32_t step, int64_t n, fk_stream_t stream) {
+  return fk_adamw_step_scaled(master, param_bf16, grad, grad_is_bf16, exp_avg, exp_avg_sq, grad_sumsq, max_grad_norm, 1.0f,
+                              lr, beta1, beta2, eps, weight_decay, step, n, stream);
 }

@@ -84,6 +84,7 @@ SIGNATURES = {
     "fk_flow_loss_bf16": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp] + [c_i32] * 4 + [c_vp]),
     "fk_sumsq": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "fk_adamw_step": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp] + [c_f32] * 6 + [c_i32, c_i64, c_vp]),
+    "fk_adamw_step_scaled": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp] + [c_f32] * 7 + [c_i32, c_i64, c_vp]),
     "fk_euler_step_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "fk_transpose_bf16": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "fk_softmax_rows": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp]),

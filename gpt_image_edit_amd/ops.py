@@ -644,15 +644,16 @@ def sumsq(tensors, out=None):
 
 
 def adamw_step(master, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
-               grad_sumsq=None, max_grad_norm=1.0, param_bf16=None):
-    """In-place AdamW update of the fp32 ``master`` (and the bf16 copy); ``grad_sumsq`` (fp64 [1]) enables clipping."""
+               grad_sumsq=None, max_grad_norm=1.0, param_bf16=None, grad_scale=1.0):
+    """In-place AdamW update of the fp32 ``master`` (and the bf16 copy); ``grad_sumsq`` (fp64 [1]) enables clipping.
+    ``grad_scale``: ``grad`` holds sums that still have to be multiplied by it (1 / world after a reduce-scatter)."""
     _need_cuda(master, grad, exp_avg, exp_avg_sq, grad_sumsq, param_bf16)
     for t, what in ((master, "master"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         _f32c(t, what)
     if grad.dtype not in (torch.float32, BF16) or not grad.is_contiguous() or grad.numel() != master.numel():
         raise TypeError("grad must be a contiguous fp32 / bf16 tensor of the parameter's size")
-    libfk.check(libfk.load().fk_adamw_step(_ptr(master), _ptr(param_bf16), _ptr(grad), int(grad.dtype == BF16),
-                                           _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(grad_sumsq), float(max_grad_norm),
-                                           float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
-                                           int(step), master.numel(), _stream()), "fk_adamw_step")
+    libfk.check(libfk.load().fk_adamw_step_scaled(_ptr(master), _ptr(param_bf16), _ptr(grad), int(grad.dtype == BF16),
+                                                  _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(grad_sumsq), float(max_grad_norm),
+                                                  float(grad_scale), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                                  float(weight_decay), int(step), master.numel(), _stream()), "fk_adamw_step")
     return master

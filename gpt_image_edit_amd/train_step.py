@@ -28,10 +28,12 @@ BF16 = torch.bfloat16
 
 class DenoiserTrainStep:
     def __init__(self, model, lr=1e-6, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, trainable=None,
-                 sharded=False, group=None, store_activations="auto", projector=None):
+                 sharded=False, group=None, store_activations="auto", projector=None, keep_grads=True, bucket_numel=None):
         """sharded=True: the optimiser state lives in ``zero.ShardedAdamW`` (ZeRO-2: one flat bf16 parameter buffer the
         model's trainable tensors become views of, fp32 gradients reduce-scattered over the data-parallel ranks, this
-        rank's slice of master + moments updated, parameters all-gathered); works unchanged with one process."""
+        rank's slice of master + moments updated, parameters all-gathered); works unchanged with one process.
+        keep_grads=False (sharded only): ``forward_backward`` hands every block's gradients to the optimiser's buckets and
+        does not keep them (saves the 8 GB of bf16 gradients; ``step()['grads']`` is then empty)."""
         self.model = model
         self.projector = projector
         self.bw = FluxBackward(model, trainable, store_activations=store_activations)
@@ -39,11 +41,16 @@ class DenoiserTrainStep:
         self.step_count = 0
         self.state = {}     # name -> (fp32 master, exp_avg, exp_avg_sq)
         self.opt = None
+        self.keep_grads = keep_grads
+        self._sunk = set()
         if sharded:
-            from .zero import ShardedAdamW
+            from .zero import DEFAULT_BUCKET, ShardedAdamW, backward_order
             names = sorted(self.trainable_names())
+            # buckets in the order the backward pass finishes the gradients: a bucket's reduce-scatter is issued the moment
+            # its last block is done and runs under the backward of the earlier blocks (zero2.json: overlap_comm)
             self.opt = ShardedAdamW({k: self._param(k).data for k in names}, lr=lr, betas=betas, eps=eps,
-                                    weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group)
+                                    weight_decay=weight_decay, max_grad_norm=max_grad_norm, group=group,
+                                    order=backward_order(names), bucket_numel=bucket_numel or DEFAULT_BUCKET)
             for k in names:
                 self._param(k).data = self.opt.params[k]     # the forward now reads views of the flat buffer
             model._packed = None
@@ -117,10 +124,19 @@ class DenoiserTrainStep:
         loss, grad = ops.flow_loss(pred[:, :S_tgt], model_input.contiguous(), noise.contiguous())
         dsample = torch.zeros_like(pred)
         dsample[:, :S_tgt].copy_(grad)
-        grads, d_enc = self.bw.backward(dsample)
+        self._sunk = set()
+        sink = None
+        if self.opt is not None:
+            def sink(block_grads):
+                self.opt.accumulate(block_grads)
+                self._sunk.update(block_grads)
+        grads, d_enc = self.bw.backward(dsample, sink=sink, keep=self.keep_grads or self.opt is None)
         if n_proj:
-            for k, g in self.projector.backward(d_enc[:, :n_proj]).items():
-                grads[self.PROJ + k] = g
+            pg = {self.PROJ + k: g for k, g in self.projector.backward(d_enc[:, :n_proj]).items()}
+            if sink is not None:
+                sink(pg)
+            if self.keep_grads or self.opt is None:
+                grads.update(pg)
         return loss, grads, d_enc
 
     @torch.no_grad()
@@ -128,11 +144,12 @@ class DenoiserTrainStep:
         """Global-norm clipping + AdamW on fp32 masters; the bf16 parameters of the model are rewritten in the same pass."""
         names = sorted(grads)
         if self.opt is not None:
-            for k, flat in self.opt.grads.items():       # bf16 / fp32 -> the flat fp32 gradient buffer (a cast, no arithmetic)
-                if k in grads:
-                    flat.copy_(grads[k])
-                else:
-                    flat.zero_()                         # e.g. the projector on a batch that came with ready prompt_embeds
+            # whatever forward_backward has not already handed to the buckets (gradients from another source); tensors
+            # without a gradient this step -- e.g. the projector on a batch that came with ready prompt_embeds -- count as 0
+            rest = {k: g for k, g in grads.items() if k not in self._sunk}
+            if rest:
+                self.opt.accumulate(rest)
+            self._sunk = set()
             norm = self.opt.step()
             self.step_count = self.opt.step_count
             self.bw.refresh()

@@ -31,13 +31,15 @@ from .param_tree import ParamTreeMixin, build_param_tree
 BF16 = torch.bfloat16
 # FK_FUSE_QKV=0 keeps RMSNorm+RoPE as the separate fk_qkv_post_bf16 pass (A/B measurement, identical results)
 FUSE_QKV = os.environ.get("FK_FUSE_QKV", "1") != "0"
-# FK_OVERLAP_MLP=0 / 1: never / always run the single blocks' MLP-up GEMM on a second stream (A/B measurement, identical
-# results); default "auto": by the attention grid's last-round waste (HipFluxTransformer2DModel._overlap_pays)
+# FK_OVERLAP_MLP=0 / 1 / auto: never / always / by the attention grid's last-round waste (HipFluxTransformer2DModel.
+# _overlap_pays) run the single blocks' MLP-up GEMM on a second stream (identical results).  Default 0 since round 3: with
+# the mixed / split-K GEMM grids the second stream no longer pays (1024^2 edit, one box, interleaved: 4033.5 ms on one
+# stream, 4039.6 ms with it; round 2 measured +2.6 % for it)
 # single-stream order of a single block's two projections of n (A/B, FK_MLP_FIRST=1: MLP-up before the QKV GEMM; default:
 # after the attention, which then reads q / k / v while they are cache-warm -- cfg 2 on one box, three interleaved runs
 # each: 1.0149 / 1.0156 / 1.0150 images/s against 1.0145 / 0.9909 / 0.9646)
 MLP_FIRST = os.environ.get("FK_MLP_FIRST", "0") == "1"
-OVERLAP_MLP = {"0": False, "1": True}.get(os.environ.get("FK_OVERLAP_MLP", "auto"), "auto")
+OVERLAP_MLP = {"0": False, "1": True, "auto": "auto"}.get(os.environ.get("FK_OVERLAP_MLP", "0"), False)
 
 
 def rope_tables(ids, axes_dim=(16, 56, 56), theta=10000.0):

@@ -2,61 +2,110 @@
 
 The reference trains under DeepSpeed ZeRO stage 2 (``scripts/accelerate_configs/zero2.json`` via accelerate,
 ``train_denoiser.py:707-760``): every rank holds the full bf16 weights, the fp32 master copy and the two Adam moments
-of the trainable subset are partitioned over the ranks, gradients are reduce-scattered in fp32 and the updated
-parameters all-gathered in bf16 -- 16.2 GB + 8.1 GB per step for the 4.04 B trainable parameters.
+of the trainable subset are partitioned over the ranks, gradients are reduce-scattered in fp32 in buckets of 5.4e8
+elements WHILE the backward pass runs (``overlap_comm``) and the updated parameters all-gathered in bf16 -- 16.2 GB +
+8.1 GB per step for the 4.04 B trainable parameters.
 
 This module is that exchange written for one process per GPU over ``torch.distributed`` (``nccl`` = RCCL on the GPUs,
 ``gloo`` in the CPU tests), around the HIP kernels of ``csrc/train_kernels.hip``:
 
-    flat fp32 gradients  --reduce_scatter_tensor(SUM)/world-->  this rank's slice
-    fk_sumsq(slice) --all_reduce(SUM)--> global ||g||^2        (accelerator.clip_grad_norm_, train_denoiser.py:1171-1177)
-    fk_adamw_step(master slice, moments, clip coefficient, bf16 slice)
-    bf16 slice  --all_gather_into_tensor-->  flat bf16 parameters (the tensors the forward pass reads are views of it)
+  * The trainable tensors are laid out in the ORDER THE BACKWARD PASS PRODUCES THEIR GRADIENTS (last block first) and cut
+    into buckets (default 5.4e8 elements like the reference; xGMI rings are per-link bound, so buckets stay large).
+    A bucket is ``world`` equal chunks; rank r owns chunk r of every bucket (fp32 master + both moments).
+  * ``accumulate(grads)`` -- called by the backward pass after every block -- casts the block's gradients into the
+    bucket's fp32 staging buffer; the moment a bucket is complete its ``reduce_scatter_tensor(SUM)`` is issued
+    asynchronously, so it runs under the backward of the earlier blocks.  Two staging buffers alternate; a rank keeps
+    only ITS chunk of every reduced bucket (gradient memory: 2 buckets + total / world, not the whole set).
+  * ``step()``: wait for the outstanding reductions; ``fk_sumsq`` of the local chunks + one scalar all-reduce = the global
+    norm (``accelerator.clip_grad_norm_``, ``train_denoiser.py:1171-1177``); ``fk_adamw_step_scaled`` per bucket chunk
+    -- the 1 / world of the gradient MEAN is folded into the clipping coefficient, no pass divides the sums -- writing
+    the bf16 chunk straight into its place in the flat parameter buffer; ``all_gather_into_tensor`` per bucket, IN
+    PLACE (the send buffer is the rank's chunk of the receive buffer; nothing is cloned).
 
-Two collectives per step, each ONE call on a contiguous buffer, so RCCL can drive every xGMI link; xGMI rings are
-per-link bound, so the buffers are not cut into small buckets.  The arithmetic is injected (``kernels``): the default is
-``gpt_image_edit_amd.ops`` (HIP, no fallback); the world-size-2 CPU test passes a torch stand-in of its own.
+The tensors the forward pass reads are views of the flat bf16 buffer.  The arithmetic is injected (``kernels``): the
+default is ``gpt_image_edit_amd.ops`` (HIP, no fallback); the world-size-2 CPU tests pass a torch stand-in of their own.
+Unmeasured on hardware so far: no multi-GPU node was available to the builder.
 """
 import torch
 import torch.distributed as dist
 
-__all__ = ["FlatLayout", "ShardedAdamW"]
+__all__ = ["FlatLayout", "ShardedAdamW", "backward_order"]
 
-ALIGN = 64   # elements: every slice starts on a 256-byte (fp32) boundary
+ALIGN = 64                      # elements: every chunk starts on a 256-byte (fp32) boundary
+DEFAULT_BUCKET = 540_000_000    # zero2.json: reduce_bucket_size 5.4e8
+
+
+def backward_order(names):
+    """Names sorted by when ``backward.FluxBackward.backward`` finishes their gradients: single blocks 37 .. 0, double
+    blocks 18 .. 0, then everything else (the ``denoise_projector``, fed by the gradient of ``prompt_embeds``)."""
+    def key(n):
+        parts = n.split(".")
+        if parts[0] == "single_transformer_blocks":
+            return (0, -int(parts[1]), n)
+        if parts[0] == "transformer_blocks":
+            return (1, -int(parts[1]), n)
+        return (2, 0, n)
+    return sorted(names, key=key)
 
 
 class FlatLayout:
-    """Name-ordered packing of a set of tensors into one flat buffer padded to ``world`` equal, aligned slices."""
+    """Packing of a set of tensors into one flat buffer of buckets, each bucket ``world`` equal aligned chunks."""
 
-    def __init__(self, shapes, world):
-        self.names = sorted(shapes)
-        self.offsets, off = {}, 0
+    def __init__(self, shapes, world, order=None, bucket_numel=None):
+        self.names = list(order) if order is not None else sorted(shapes)
+        if sorted(self.names) != sorted(shapes):
+            raise ValueError("order must be a permutation of the tensor names")
+        self.world = world
+        limit = bucket_numel if bucket_numel else float("inf")
+        groups, cur, cur_n = [], [], 0
         for n in self.names:
             numel = 1
             for d in shapes[n]:
                 numel *= int(d)
-            self.offsets[n] = (off, numel, tuple(shapes[n]))
-            off += numel
-        self.used = off
-        per = -(-off // world)                       # ceil
-        self.slice_numel = -(-per // ALIGN) * ALIGN
-        self.total = self.slice_numel * world
-        self.world = world
+            if cur and cur_n + numel > limit:
+                groups.append(cur)
+                cur, cur_n = [], 0
+            cur.append((n, numel, tuple(shapes[n])))
+            cur_n += numel
+        if cur:
+            groups.append(cur)
+        self.offsets, self.bucket_of, self.buckets = {}, {}, []
+        off = state_off = used = 0
+        for b, grp in enumerate(groups):
+            raw = sum(k for _, k, _ in grp)
+            chunk = -(-(-(-raw // world)) // ALIGN) * ALIGN              # ceil(raw / world) rounded up to ALIGN
+            o = off
+            for n, k, shape in grp:
+                self.offsets[n] = (o, k, shape)
+                self.bucket_of[n] = b
+                o += k
+            self.buckets.append(dict(offset=off, size=chunk * world, chunk=chunk, state_offset=state_off,
+                                     names=[n for n, _, _ in grp], used=raw))
+            off += chunk * world
+            state_off += chunk
+            used += raw
+        self.used, self.total, self.slice_numel = used, off, state_off
+        self.max_bucket = max(b["size"] for b in self.buckets)
 
     def views(self, flat):
         """dict name -> view of ``flat`` with the tensor's shape."""
         return {n: flat[o:o + k].view(shape) for n, (o, k, shape) in self.offsets.items()}
 
-    def slice_of(self, flat, rank):
-        return flat[rank * self.slice_numel:(rank + 1) * self.slice_numel]
+    def chunk_of(self, flat, b, rank):
+        bk = self.buckets[b]
+        return flat[bk["offset"] + rank * bk["chunk"]: bk["offset"] + (rank + 1) * bk["chunk"]]
+
+    def bucket_view(self, flat, b):
+        bk = self.buckets[b]
+        return flat[bk["offset"]: bk["offset"] + bk["size"]]
 
 
 class ShardedAdamW:
     def __init__(self, params, lr=1e-6, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, kernels=None,
-                 group=None):
+                 group=None, order=None, bucket_numel=DEFAULT_BUCKET):
         """``params``: dict name -> bf16 tensor (the trainable subset, e.g. ``training.trainable_names``).  After
-        construction ``self.params`` holds views of ONE flat bf16 buffer that replace them in the model, and
-        ``self.grads`` fp32 views of the flat gradient buffer the backward pass accumulates into."""
+        construction ``self.params`` holds views of ONE flat bf16 buffer that replace them in the model.  ``order``:
+        the names in the order their gradients become available (``backward_order``); default: sorted."""
         self.group = group
         on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if on else 1
@@ -67,45 +116,119 @@ class ShardedAdamW:
         self.hp = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.max_grad_norm = max_grad_norm
         dev = next(iter(params.values())).device
-        self.layout = FlatLayout({n: p.shape for n, p in params.items()}, self.world)
-        L = self.layout
+        self.layout = L = FlatLayout({n: p.shape for n, p in params.items()}, self.world, order=order, bucket_numel=bucket_numel)
         self.flat_param = torch.zeros(L.total, dtype=torch.bfloat16, device=dev)
-        self.flat_grad = torch.zeros(L.total, dtype=torch.float32, device=dev)
-        self.params, self.grads = L.views(self.flat_param), L.views(self.flat_grad)
+        self.params = L.views(self.flat_param)
         for n, p in params.items():
             self.params[n].copy_(p)
-        # this rank's slice of the optimiser state: fp32 master + both moments
-        self.master = L.slice_of(self.flat_param, self.rank).float().contiguous()
+        # this rank's chunk of every bucket: fp32 master + both moments + the reduced gradient
+        self.master = torch.cat([L.chunk_of(self.flat_param, b, self.rank).float() for b in range(len(L.buckets))]).contiguous()
         self.exp_avg = torch.zeros_like(self.master)
         self.exp_avg_sq = torch.zeros_like(self.master)
-        self.grad_slice = torch.empty_like(self.master)
+        self.grad_slice = torch.zeros_like(self.master)
+        # two alternating fp32 staging buffers: bucket b fills while bucket b - 1 is on the wire
+        n_stage = min(2, len(L.buckets))
+        self.staging = [torch.zeros(L.max_bucket, dtype=torch.float32, device=dev) for _ in range(n_stage)]
         self.step_count = 0
         self.last_grad_norm = None
+        self._begin()
+
+    # ---- gradient intake ---------------------------------------------------------------------------------------------
+    def _begin(self):
+        self._seen = [set() for _ in self.layout.buckets]
+        self._launched = [False] * len(self.layout.buckets)
+        self._work = {}            # bucket -> async work handle of its reduce-scatter
+        self._stage_owner = [None] * len(self.staging)
+
+    def _stage_for(self, b):
+        """Staging buffer of bucket b (waits for the reduction of the bucket that used it before)."""
+        slot = b % len(self.staging)
+        owner = self._stage_owner[slot]
+        if owner != b:
+            if owner is not None:
+                if not self._launched[owner]:
+                    raise RuntimeError(f"bucket {b} needs the staging buffer of bucket {owner}, which is still incomplete: "
+                                       "gradients must arrive in the layout's order (order=backward_order(names))")
+                w = self._work.pop(owner, None)
+                if w is not None:
+                    w.wait()
+            self._stage_owner[slot] = b
+            self.staging[slot][: self.layout.buckets[b]["size"]].zero_()       # padding and absent tensors count as zero
+        return self.staging[slot]
+
+    def grad_view(self, name):
+        """fp32 view (the tensor's shape) inside the staging buffer of the tensor's bucket."""
+        L = self.layout
+        b = L.bucket_of[name]
+        o, k, shape = L.offsets[name]
+        lo = o - L.buckets[b]["offset"]
+        return self._stage_for(b)[lo: lo + k].view(shape)
+
+    def accumulate(self, grads):
+        """Take a block's gradients (dict name -> bf16 / fp32 tensor; a cast, no arithmetic) and start the reduction of
+        every bucket they complete."""
+        L = self.layout
+        for n in sorted((n for n in grads if n in L.offsets), key=lambda n: L.offsets[n][0]):
+            b = L.bucket_of[n]
+            if self._launched[b]:
+                raise RuntimeError(f"gradient of {n} arrived after its bucket was reduced (order= does not match the backward pass)")
+            self.grad_view(n).copy_(grads[n])
+            self._seen[b].add(n)
+            if len(self._seen[b]) == len(L.buckets[b]["names"]):
+                self._reduce(b)
+
+    def _reduce(self, b):
+        bk = self.layout.buckets[b]
+        stage = self._stage_for(b)[: bk["size"]]
+        dst = self.grad_slice[bk["state_offset"]: bk["state_offset"] + bk["chunk"]]
+        if self.world > 1:
+            self._work[b] = dist.reduce_scatter_tensor(dst, stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            dst.copy_(stage[: bk["chunk"]])
+        self._launched[b] = True
+
+    # ---- compatibility: whole-gradient views (tests, small models) ------------------------------------------------------
+    @property
+    def grads(self):
+        """dict name -> fp32 staging view; writing all of them and calling ``step()`` is the unbucketed use.  Only valid
+        when everything fits the staging buffers (at most two buckets)."""
+        if len(self.layout.buckets) > len(self.staging):
+            raise RuntimeError("grads views need <= 2 buckets; feed gradients through accumulate()")
+        return {n: self.grad_view(n) for n in self.layout.names}
 
     def state_bytes(self):
-        """(replicated, sharded) bytes this rank holds for the optimiser: flat bf16 params + fp32 grads | 4 fp32 slices."""
-        return self.layout.total * (2 + 4), self.layout.slice_numel * 4 * 4
+        """(replicated, sharded) bytes this rank holds for the optimiser: flat bf16 params + fp32 staging | 4 fp32 chunks."""
+        return self.layout.total * 2 + sum(s.numel() for s in self.staging) * 4, self.layout.slice_numel * 4 * 4
 
     @torch.no_grad()
     def step(self):
-        """Consume ``self.grads`` (this rank's local fp32 gradients), update, refresh ``self.params`` on every rank."""
+        """Finish the gradient exchange, update this rank's chunks, refresh ``self.params`` on every rank."""
         L = self.layout
-        if self.world > 1:
-            dist.reduce_scatter_tensor(self.grad_slice, self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
-            self.grad_slice.mul_(1.0 / self.world)   # mean over the data-parallel ranks, like DDP / DeepSpeed
-        else:
-            self.grad_slice.copy_(L.slice_of(self.flat_grad, 0))
-        sumsq = self.k.sumsq(self.grad_slice)            # fp64 [1]; padding elements are zero
+        for b in range(len(L.buckets)):        # buckets with tensors that received no gradient this step (zeros)
+            if not self._launched[b]:
+                self._stage_for(b)
+                self._reduce(b)
+        for b in sorted(self._work):
+            self._work[b].wait()
+        self._work = {}
+        sumsq = self.k.sumsq(self.grad_slice)            # fp64 [1] over the SUMS; padding elements are zero
         if self.world > 1:
             dist.all_reduce(sumsq, op=dist.ReduceOp.SUM, group=self.group)
-        self.last_grad_norm = sumsq.sqrt()
+        scale = 1.0 / self.world                          # mean over the data-parallel ranks, like DDP / DeepSpeed
+        self.last_grad_norm = sumsq.sqrt() * scale
         self.step_count += 1
-        mine = L.slice_of(self.flat_param, self.rank)
-        self.k.adamw_step(self.master, self.grad_slice, self.exp_avg, self.exp_avg_sq, self.step_count,
-                          grad_sumsq=sumsq if self.max_grad_norm is not None else None,
-                          max_grad_norm=self.max_grad_norm if self.max_grad_norm is not None else 0.0,
-                          param_bf16=mine, **self.hp)
-        if self.world > 1:
-            dist.all_gather_into_tensor(self.flat_param, mine.clone(), group=self.group)
-        self.flat_grad.zero_()
+        works = []
+        for b, bk in enumerate(L.buckets):
+            so, ch = bk["state_offset"], bk["chunk"]
+            mine = L.chunk_of(self.flat_param, b, self.rank)
+            self.k.adamw_step(self.master[so:so + ch], self.grad_slice[so:so + ch], self.exp_avg[so:so + ch],
+                              self.exp_avg_sq[so:so + ch], self.step_count,
+                              grad_sumsq=sumsq if self.max_grad_norm is not None else None,
+                              max_grad_norm=self.max_grad_norm if self.max_grad_norm is not None else 0.0,
+                              param_bf16=mine, grad_scale=scale, **self.hp)
+            if self.world > 1:   # in place: `mine` IS the rank's chunk of the bucket being gathered
+                works.append(dist.all_gather_into_tensor(L.bucket_view(self.flat_param, b), mine, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        self._begin()
         return self.last_grad_norm

@@ -267,6 +267,15 @@ int fk_sumsq(const void* g, int32_t g_is_bf16, int64_t n, int32_t accumulate, do
 int fk_adamw_step(float* master, void* param_bf16, const void* grad, int32_t grad_is_bf16, float* exp_avg,
                   float* exp_avg_sq, const double* grad_sumsq, float max_grad_norm, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int32_t step, int64_t n, fk_stream_t stream);
+/* The same with gradients that are stored UNSCALED sums: the gradient applied is grad_scale * grad (grad_scale = 1 / world
+ * for the sums a ZeRO-2 reduce-scatter leaves), grad_sumsq is the squared norm of the stored sums, and the clipping
+ * coefficient becomes grad_scale * min(1, max_grad_norm / (grad_scale * sqrt(grad_sumsq[0]) + 1e-6)) -- one multiply per
+ * element either way, no pass of its own for the mean.  grad_scale = 1 is fk_adamw_step bit for bit. */
+int fk_adamw_step_scaled(float* master, void* param_bf16, const void* grad, int32_t grad_is_bf16, float* exp_avg,
+                         float* exp_avg_sq, const double* grad_sumsq, float max_grad_norm, float grad_scale, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int32_t step, int64_t n,
+                         fk_stream_t stream);
+
 /* FlowMatchEulerDiscreteScheduler.step fused with the pipeline's `noise_pred[:, :S_tgt]` slice:
  *   x[b, s, :] = bf16(float(x) + float(bf16(bf16(dsigma) * v[b, s, :])))   for s < S_tgt
  * x rows at x + b*x_batch_stride + s*C, v rows at v + b*v_batch_stride + s*C.

@@ -24,10 +24,11 @@ class TorchKernels:
 
     @staticmethod
     def adamw_step(master, grad, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay, grad_sumsq=None,
-                   max_grad_norm=1.0, param_bf16=None):
-        g = grad.float()
-        if grad_sumsq is not None:
-            g = g * torch.clamp(max_grad_norm / (grad_sumsq.sqrt().float() + 1e-6), max=1.0)
+                   max_grad_norm=1.0, param_bf16=None, grad_scale=1.0):
+        coef = torch.tensor(grad_scale, dtype=torch.float32)
+        if grad_sumsq is not None:     # csrc/train_kernels.hip::adamw_kernel: the 1 / world sits inside the coefficient
+            coef = torch.clamp(max_grad_norm / (grad_sumsq.sqrt().float() * grad_scale + 1e-6), max=1.0) * grad_scale
+        g = grad.float() * coef
         master.mul_(1 - lr * weight_decay)
         exp_avg.lerp_(g, 1 - betas[0])
         exp_avg_sq.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
@@ -58,13 +59,25 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gpt_image_edit_amd.zero import ShardedAdamW
+    from gpt_image_edit_amd.zero import backward_order
     opt = ShardedAdamW(_params(), max_grad_norm=1.0, kernels=TorchKernels, **HP)
+    # the same run with the gradients fed block by block into buckets of <= 400 elements (4 buckets, two staging buffers
+    # in rotation, reduce-scatters in flight while later gradients arrive): must give the same bits
+    order = backward_order(list(SHAPES))
+    bopt = ShardedAdamW(_params(), max_grad_norm=1.0, kernels=TorchKernels, order=order, bucket_numel=400, **HP)
+    assert len(bopt.layout.buckets) == 4 and len(bopt.staging) == 2
     norms = []
     for step in range(3):
-        for n, g in _grads(rank, step).items():
+        gs = _grads(rank, step)
+        for n, g in gs.items():
             opt.grads[n].copy_(g)
         norms.append(float(opt.step()))
-    q.put((rank, {n: p.clone() for n, p in opt.params.items()}, norms, opt.state_bytes(), opt.layout.slice_numel))
+        for n in order:                                   # one tensor at a time, in production order
+            bopt.accumulate({n: gs[n]})
+        bn = float(bopt.step())                           # the norm is summed chunk by chunk in fp64: other chunks, other order
+        assert abs(bn - norms[-1]) <= 1e-12 * norms[-1]
+    same = all(torch.equal(opt.params[n], bopt.params[n]) for n in SHAPES)
+    q.put((rank, {n: p.clone() for n, p in opt.params.items()}, norms, opt.state_bytes(), opt.layout.slice_numel, same))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -91,8 +104,10 @@ def test_sharded_adamw_gloo_world2_matches_single_process():
             p.grad = sum(g[n] for g in gs) / world
         ref_norms.append(float(torch.nn.utils.clip_grad_norm_(ref.values(), 1.0)))
         opt.step()
-    (_, p0, n0, bytes0, slice0), (_, p1, n1, _, _) = res
+    (_, p0, n0, bytes0, slice0, same0), (_, p1, n1, _, _, same1) = res
+    assert same0 and same1, "bucketed, overlapped reduce-scatter changed the result"
     total = sum(torch.tensor(s).prod().item() for s in SHAPES.values())
+    # one bucket: bf16 parameters + ONE fp32 staging buffer replicated, 4 fp32 chunks (master, 2 moments, gradient) sharded
     assert slice0 % 64 == 0 and slice0 * world >= total and bytes0 == (slice0 * world * 6, slice0 * 16)
     for a, b, c in zip(n0, n1, ref_norms):
         assert a == b and abs(a - c) <= 1e-5 * c
@@ -106,7 +121,7 @@ def test_sharded_adamw_gloo_world2_matches_single_process():
 def test_flat_layout_single_process():
     from gpt_image_edit_amd.zero import FlatLayout, ShardedAdamW
     L = FlatLayout(SHAPES, 8)
-    assert L.slice_numel % 64 == 0 and L.total == 8 * L.slice_numel >= L.used
+    assert L.slice_numel % 64 == 0 and L.total == 8 * L.slice_numel >= L.used and len(L.buckets) == 1
     flat = torch.arange(L.total, dtype=torch.float32)
     v = L.views(flat)
     assert sorted(v) == L.names and all(v[n].shape == tuple(SHAPES[n]) for n in SHAPES)
@@ -118,4 +133,23 @@ def test_flat_layout_single_process():
     for n in SHAPES:
         opt.grads[n].fill_(0.5)
     opt.step()
-    assert all(not torch.equal(before[n], opt.params[n]) for n in SHAPES) and float(opt.flat_grad.abs().sum()) == 0
+    assert all(not torch.equal(before[n], opt.params[n]) for n in SHAPES)
+    # buckets in backward order: chunks of every bucket are equal and aligned, every tensor lives in exactly one bucket
+    from gpt_image_edit_amd.zero import backward_order
+    names = ["transformer_blocks.0.a", "single_transformer_blocks.2.a", "single_transformer_blocks.10.a", "denoise_projector.0.weight",
+             "transformer_blocks.3.a"]
+    assert backward_order(names) == ["single_transformer_blocks.10.a", "single_transformer_blocks.2.a", "transformer_blocks.3.a",
+                                     "transformer_blocks.0.a", "denoise_projector.0.weight"]
+    Lb = FlatLayout({n: (100, 7) for n in names}, 4, order=backward_order(names), bucket_numel=1500)
+    assert [b["names"] for b in Lb.buckets] == [names_ for names_ in ([backward_order(names)[0:2]] + [backward_order(names)[2:4]] + [backward_order(names)[4:]])]
+    assert all(b["chunk"] % 64 == 0 and b["size"] == 4 * b["chunk"] >= b["used"] for b in Lb.buckets)
+    assert Lb.slice_numel == sum(b["chunk"] for b in Lb.buckets) and Lb.total == 4 * Lb.slice_numel
+    # feeding gradients out of order is an error, not a silent mix-up
+    order = backward_order(names)
+    o2 = ShardedAdamW({n: torch.zeros(100, 7, dtype=BF) for n in names}, kernels=TorchKernels, order=order, bucket_numel=1500, **HP)
+    assert len(o2.layout.buckets) == 3 and len(o2.staging) == 2
+    import pytest
+    o2.accumulate({order[0]: torch.ones(100, 7)})          # half of bucket 0
+    o2.accumulate({order[2]: torch.ones(100, 7), order[3]: torch.ones(100, 7)})   # all of bucket 1: reduced
+    with pytest.raises(RuntimeError, match="incomplete"):
+        o2.accumulate({order[4]: torch.ones(100, 7)})      # bucket 2 wants bucket 0's staging buffer

@@ -1,8 +1,11 @@
-"""Within-process interleaved A/B of whole edits under different GEMM launch plans (fk_gemm_set_plan) and other
-process-level switches: the pipeline is built once, every arm runs once per round (1 warm-up + `edits` timed edits),
-medians over the rounds are printed, then one instrumented edit per arm (per-family HIP-event sums, as bench.py).
+"""Within-process interleaved A/B of whole edits under process-level switches: the pipeline is built once, every arm runs
+once per round (1 warm-up + `edits` timed edits), medians over the rounds are printed, then one instrumented edit per arm
+(per-family HIP-event sums, as bench.py).  An arm = comma-separated switches:
+    plan=<0..3>   fk_gemm_set_plan (bit 0 mixed grids, bit 1 split-K pairs)
+    tail=<0|1>    fk_attention_set_tail (light workgroups for the attention grid's last round)
+    side=<0|1|auto>  transformer.OVERLAP_MLP (single blocks' MLP-up GEMM on a second stream)
 
-    python tools/ab_edit_plans.py [workload] [rounds] [edits]         AB_PLANS="0,1,3" (default)
+    AB_ARMS="plan=0;plan=1;plan=3" python tools/ab_edit_plans.py [workload] [rounds] [edits]
 """
 import os
 import statistics
@@ -14,31 +17,51 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
-from gpt_image_edit_amd import ops  # noqa: E402
+from gpt_image_edit_amd import libfk, ops, transformer  # noqa: E402
 
 workload = sys.argv[1] if len(sys.argv) > 1 else "cfg2_single_512x512_28step"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 edits = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-plans = [int(v) for v in os.environ.get("AB_PLANS", "0,1,3").split(",")]
+arms = [a.strip() for a in os.environ.get("AB_ARMS", "plan=0;plan=1;plan=3").split(";") if a.strip()]
+lib = libfk.load()
+DEFAULT_SIDE = transformer.OVERLAP_MLP
+
+
+def apply(arm):
+    ops.gemm_set_plan(3)
+    lib.fk_attention_set_tail(1)
+    transformer.OVERLAP_MLP = DEFAULT_SIDE
+    for kv in arm.split(","):
+        k, v = kv.split("=")
+        if k == "plan":
+            ops.gemm_set_plan(int(v))
+        elif k == "tail":
+            lib.fk_attention_set_tail(int(v))
+        elif k == "side":
+            transformer.OVERLAP_MLP = {"0": False, "1": True}.get(v, "auto")
+        else:
+            raise SystemExit(f"unknown switch {k}")
+
+
 dev = torch.device("cuda:0")
 pipe = bench.build_pipeline(dev)
 inp = bench.make_inputs(workload, dev, seed=42)
-res = {p: [] for p in plans}
+res = {a: [] for a in arms}
 for r in range(rounds):
-    for p in plans:
-        ops.gemm_set_plan(p)
+    for a in arms:
+        apply(a)
         bench.run_edit(pipe, inp)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(edits):
             bench.run_edit(pipe, inp)
         torch.cuda.synchronize()
-        res[p].append((time.perf_counter() - t0) / edits * 1e3)
-for p in plans:
-    print(f"{workload} plan {p}: ms/edit median {statistics.median(res[p]):.1f}  all {[round(x, 1) for x in res[p]]}", flush=True)
-for p in plans:
-    ops.gemm_set_plan(p)
+        res[a].append((time.perf_counter() - t0) / edits * 1e3)
+for a in arms:
+    print(f"{workload} [{a}]: ms/edit median {statistics.median(res[a]):.1f}  all {[round(x, 1) for x in res[a]]}", flush=True)
+for a in arms:
+    apply(a)
     fam = bench.instrumented_edit(pipe, inp)
-    print(f"{workload} plan {p}: " + "  ".join(f"{k} {v['ms']:.1f} ms {v['tflops']:.0f} TF/s ({v['launches']})" for k, v in fam.items()),
+    print(f"{workload} [{a}]: " + "  ".join(f"{k} {v['ms']:.1f} ms {v['tflops']:.0f} TF/s ({v['launches']})" for k, v in fam.items()),
           flush=True)
-ops.gemm_set_plan(3)
+apply("plan=3")

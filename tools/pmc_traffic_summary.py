@@ -79,7 +79,7 @@ def main(d, out_stem):
     kf = cal["alg_read_bytes"] / f_cal          # bytes per FETCH_SIZE unit
     kw = cal["alg_write_bytes"] / w_cal
     rq = passes["req"][0]["ctr"]
-    lines = ["# HBM traffic of the path's kernels from rocprofv3 PMC passes (round 2)", "",
+    lines = ["# HBM traffic of the path's kernels from rocprofv3 PMC passes", "",
              "Command: `bash tools/pmc_traffic.sh` (one TCC counter group per pass, `--kernel-trace` only; target "
              "`tools/traffic_target.py`: every item launched 3x back to back, separated by a one-wave kernel). Raw "
              "per-dispatch rows: `gpurun_out/traffic/*.txt` on the build box.", "",

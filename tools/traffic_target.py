@@ -55,8 +55,12 @@ def main():
              B * S * D * 2, B * S * D * 2, note="one read + one write of the [B,S,3072] stream")
         del x, o
     # ---- GEMMs (bf16 in / out; algorithmic = A + W read once, C written once) -------------------------------------
-    for M, N, K, epi, tag in ((2560, 9216, 3072, 0, "qkv-shaped 512^2"), (8704, 12288, 3072, 1, "mlp-up 1024^2 (GELU)"),
-                              (32768, 3072, 12288, 0, "mlp-down 4 x 1024^2"), (278528, 3072, 3072, 0, "out-proj cfg3 (B=32)")):
+    # one item per launch class of the 512^2 and the 1024^2 edit (the launcher picks the form: mixed grid, split-K pair ...)
+    for M, N, K, epi, tag in ((2560, 9216, 3072, 0, "qkv 512^2"), (2560, 12288, 3072, 1, "mlp-up 512^2 (GELU)"),
+                              (2560, 3072, 15360, 0, "proj_out 512^2 (K-long)"), (2560, 3072, 3072, 0, "out-proj 512^2"),
+                              (8704, 9216, 3072, 0, "qkv 1024^2"), (8704, 12288, 3072, 1, "mlp-up 1024^2 (GELU)"),
+                              (8704, 3072, 15360, 0, "proj_out 1024^2 (K-long)"),
+                              (278528, 3072, 3072, 0, "out-proj cfg3 (B=32)")):
         a, w, b = rnd(M, K), rnd(N, K, scale=0.05), rnd(N)
         c = torch.empty(M, N, device="cuda", dtype=BF)
         item(f"gemm {M}x{N}x{K} {tag}", "gemm", lambda: ops.gemm(a, w, b, out=c, epilogue=epi),
