@@ -286,6 +286,8 @@ def train_step_bench(device, steps=3, warmup=1, world=1):
     def flops_forward(S, D=3072, n_double=19, n_single=38):   # BASELINE.md section 2 (embedders omitted)
         nb = n_double + n_single
         return nb * 24 * D * D * S + nb * 4 * S * S * D + 2 * (n_double * 12 + n_single * 3 + 2) * D * D
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(device)
     model = HipFluxTransformer2DModel(dict(flux_spec.FLUX_KONTEXT_CONFIG), device=device, init="synthetic", seed=0)
     projector = HipDenoiseProjector(device=device, init="synthetic", seed=1)
     ts = DenoiserTrainStep(model, sharded=True, projector=projector, keep_grads=False)   # gradients live in the ZeRO buckets only

@@ -196,6 +196,9 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
 #pragma unroll
   for (int s = 0; s < PF; ++s)
     if (s < nt) issue_tile(s, s);
+  // waves w and w + 4 share a SIMD; the later-dispatched half loses the VALU arbitration at the head of every segment:
+  // one static priority raise for it (MI355X_MICROARCH.md, "Two waves per SIMD", item 4); the condition is wave-uniform
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 
   for (int t = 0; t < nt; ++t) {
     if (t + PF - 1 < nt) wait_vmcnt<(PF - 1) * LOADS>();
@@ -206,15 +209,25 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
     const bool mask = ragged && t == nt - 1;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      // Operand fragments are read two MFMAs ahead of their use and the order is pinned (one DS read, then one MFMA), as
+      // in attention_fwd.hip: left alone, hipcc issues every ds_read right in front of its MFMA and the wave sits out an
+      // LDS round trip 48 times per tile.  Same products in the same order: results are unchanged bit for bit.
       f32x16_t s, dp;
+      auto product = [&](f32x16_t& out, int img, const bf16x8_t (&xf)[8]) {
+        bf16x8_t kf[3];
+        kf[0] = rowfrag(sb, img, kb, 0);
+        kf[1] = rowfrag(sb, img, kb, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk)
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(sb, 0, kb, kk), x1f[kk], kk == 0 ? f32x16_t{} : s, 0, 0, 0);
-      if constexpr (HAS_C) {
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk)
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(sb, 2, kb, kk), x2f[kk], kk == 0 ? f32x16_t{} : dp, 0, 0, 0);
-      }
+        for (int kk = 0; kk < 8; ++kk) {
+          if (kk + 2 < 8) kf[(kk + 2) % 3] = rowfrag(sb, img, kb, kk + 2);
+          out = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk % 3], xf[kk], kk == 0 ? f32x16_t{} : out, 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+      };
+      product(s, 0, x1f);
+      if constexpr (HAS_C) product(dp, 2, x2f);
       // ---- elementwise: w = p (DV) or p (dp - D) scale (DQ, DK), p = exp2(s c' - lse) <= 1 -------------------------
       float w[16];
 #pragma unroll
@@ -235,15 +248,27 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
         }
       }
       // ---- acc^T[d][row] += Bt^T w for the two 16-column steps of this half ------------------------------------------
+      bf16x8_t pfs[2];
 #pragma unroll
       for (int step = 0; step < 2; ++step) {
         u32x4_t pw;
 #pragma unroll
         for (int e = 0; e < 4; ++e) pw[e] = pack_bf2(w[8 * step + 2 * e], w[8 * step + 2 * e + 1]);
-        const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
+        pfs[step] = __builtin_bit_cast(bf16x8_t, pw);
+      }
+      {
+        bf16x8_t tf[3];
+        tf[0] = trfrag(sb, 2 * kb, 0);
+        tf[1] = trfrag(sb, 2 * kb, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // two transpose reads per fragment
 #pragma unroll
-        for (int df = 0; df < 4; ++df)
-          acc[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(sb, 2 * kb + step, df), pf, acc[df], 0, 0, 0);
+        for (int i = 0; i < 8; ++i) {
+          const int df = i & 3;
+          if (i + 2 < 8) tf[(i + 2) % 3] = trfrag(sb, 2 * kb + ((i + 2) >> 2), (i + 2) & 3);
+          acc[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[i % 3], pfs[i >> 2], acc[df], 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
       }
     }
     st_cur = (st_cur == STAGES - 1) ? 0 : st_cur + 1;

@@ -565,12 +565,17 @@ int launch(AttnParams p, hipStream_t stream, int n_full, int n_light_blocks, int
 // request issue, ~60 cycles apiece, is what a wave cannot afford to do alone: a 2-wave workgroup that loads for itself
 // measured SLOWER in the edit), but only 2 (4) waves own query rows -- one computing wave per SIMD instead of two, so
 // each runs faster and the tail spreads over 192 CUs.  Every query row's arithmetic is the same whichever workgroup
-// shape carries it: bit-identical output.  fk_attention_set_tail / FK_ATTN_TAIL select it.
+// shape carries it: bit-identical output (tests/test_hip_cfg3.py).  MEASURED, BOTH FORMS, AND OFF BY DEFAULT
+// (profiles/r03_attention_tail.txt): isolated the light workgroups gain 1.5-3 % at S = 8704 / 5632 as a second launch of
+// 2-wave workgroups and lose 2 % inside the launch; inside the 1024^2 edit both forms LOSE (1492 -> 1524 ms and
+// 1634 -> 1695 ms of attention per edit): a lone wave per SIMD does not run enough faster than two sharing one to pay
+// for the extra workgroups' prologues, and the idle CUs of the plain grid's last round are not wasted -- they hand
+// their power budget to the busy ones.  fk_attention_set_tail(1) / FK_ATTN_TAIL=1 select it for measurements.
 static int g_attn_tail = -2;
 static int attn_tail_mode() {
   if (g_attn_tail == -2) {
     const char* e = getenv("FK_ATTN_TAIL");
-    g_attn_tail = e ? atoi(e) : 1;
+    g_attn_tail = e ? atoi(e) : 0;
   }
   return g_attn_tail;
 }

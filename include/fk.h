@@ -157,8 +157,9 @@ int fk_qkv_post_bf16(const void* qkv, void* q_out, void* k_out, const void* wq_i
 int fk_attention_fwd_bf16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H,
                           int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld,
                           int64_t o_batch_stride, float scale, fk_stream_t stream);
-/* Measurement hook: 1 (default; FK_ATTN_TAIL overrides) = the blocks of a grid's last, partly filled round of CUs run
- * as 2- or 4-wave workgroups of 64 / 128 query rows so that they spread over the idle CUs; 0 = plain grid.  Same
+/* Measurement hook: 1 = the blocks of a grid's last, partly filled round of CUs run as four / two "light" workgroups
+ * (all 8 waves load K / V, 2 / 4 own query rows) so that they spread over the idle CUs; 0 (default; FK_ATTN_TAIL
+ * overrides) = plain grid -- the light form measured slower inside an edit (profiles/r03_attention_tail.txt).  Same
  * results bit for bit: a query row's arithmetic does not depend on the workgroup shape that carries it. */
 int fk_attention_set_tail(int32_t mode);
 
