@@ -229,20 +229,42 @@ def cpu_baseline(workload, mode="full"):
         for pre in ("context_embedder.", "time_text_embed.", "norm_out.", "proj_out.", "transformer_blocks.0.",
                     "single_transformer_blocks.0."):
             sd.update(block_state(pre))
-        t0 = time.perf_counter()
-        h = mmdit.linear(sd, "x_embedder", tokens)
-        c = mmdit.linear(sd, "context_embedder", enc)
-        temb = mmdit.time_text_embed(sd, torch.full((B,), 500.0), torch.full((B,), 3500.0), pooled)
-        for i in range(19):
-            c, h = mmdit.double_block(sd, "transformer_blocks.0.", h, c, temb, rope)
-        s = torch.cat([c, h], dim=1)
-        for i in range(38):
-            s = mmdit.single_block(sd, "single_transformer_blocks.0.", s, temb, rope)
-        e = mmdit.linear(sd, "norm_out.linear", torch.nn.functional.silu(temb))
-        scale, shift = e.chunk(2, dim=1)
-        hh = mmdit.layer_norm(s[:, S_txt:]) * (1 + scale)[:, None, :] + shift[:, None, :]
-        v = mmdit.linear(sd, "proj_out", hh)
-        t_step = time.perf_counter() - t0
+        # a SECOND, distinct weight set for one double + one single block (block index 1): run in the middle of the
+        # stack and timed by itself, so that the line shows whether sharing one set flatters the CPU (cache-warm weights)
+        for pre in ("transformer_blocks.1.", "single_transformer_blocks.1."):
+            sd.update(block_state(pre, seed=6))
+        n_steps = 4 if mode == "cfg1" else 1
+        t_steps, t_shared, t_distinct = [], {}, {}
+
+        def timed(fn, store, key):
+            t = time.perf_counter()
+            out = fn()
+            store.setdefault(key, []).append(time.perf_counter() - t)
+            return out
+        for step in range(n_steps):
+            t0 = time.perf_counter()
+            h = mmdit.linear(sd, "x_embedder", tokens)
+            c = mmdit.linear(sd, "context_embedder", enc)
+            temb = mmdit.time_text_embed(sd, torch.full((B,), 500.0), torch.full((B,), 3500.0), pooled)
+            for i in range(19):
+                if i == 9:
+                    c, h = timed(lambda: mmdit.double_block(sd, "transformer_blocks.1.", h, c, temb, rope), t_distinct, "double")
+                else:
+                    c, h = timed(lambda: mmdit.double_block(sd, "transformer_blocks.0.", h, c, temb, rope), t_shared, "double")
+            s = torch.cat([c, h], dim=1)
+            for i in range(38):
+                if i == 19:
+                    s = timed(lambda: mmdit.single_block(sd, "single_transformer_blocks.1.", s, temb, rope), t_distinct, "single")
+                else:
+                    s = timed(lambda: mmdit.single_block(sd, "single_transformer_blocks.0.", s, temb, rope), t_shared, "single")
+            e = mmdit.linear(sd, "norm_out.linear", torch.nn.functional.silu(temb))
+            scale, shift = e.chunk(2, dim=1)
+            hh = mmdit.layer_norm(s[:, S_txt:]) * (1 + scale)[:, None, :] + shift[:, None, :]
+            v = mmdit.linear(sd, "proj_out", hh)
+            t_steps.append(time.perf_counter() - t0)
+        t_step = sum(t_steps) / len(t_steps)
+        med = lambda xs: sorted(xs)[len(xs) // 2]  # noqa: E731
+        weights_note = {k: dict(shared_set_median_s=med(t_shared[k]), distinct_set_s=med(t_distinct[k])) for k in ("double", "single")}
         # ---- VAE either side (weights generated outside the timed spans: "model load excluded") ------------------
         sd_v = flux_spec.synthetic_state(flux_spec.vae_param_shapes(), seed=1)
         img = torch.rand(B, 3, Hc, Wc, generator=g) * 2 - 1
@@ -256,12 +278,21 @@ def cpu_baseline(workload, mode="full"):
     assert torch.isfinite(v).all()
     t4, t28 = t_enc + 4 * t_step + t_dec, t_enc + 28 * t_step + t_dec
     flops_step = mmdit.flops_forward(S_txt + S_img)
-    return dict(common, value=1.0 / t28, cfg1_4step_images_per_s=1.0 / t4,
-                t_step_s=t_step, t_vae_encode_s=t_enc, t_vae_decode_s=t_dec, gflops_step=flops_step / t_step / 1e9,
-                sample=f"fp32 oracle through the cli-equivalent plumbing at S={S_txt + S_img} (B=1): ONE full-depth denoise "
-                       f"step (embedders + 19 double + 38 single blocks + head) {t_step:.1f}s + VAE encode {t_enc:.1f}s + VAE decode {t_dec:.1f}s executed; "
-                       f"`value` = 1 / (enc + 28 x step + dec) = 1 / {t28:.0f}s is an EXTRAPOLATION of that one step "
-                       f"(cfg 1, 4 steps: 1 / {t4:.0f}s)")
+    if n_steps == 4:   # BASELINE.json configs[0] as defined: all four steps executed
+        t4 = t_enc + sum(t_steps) + t_dec
+        what = (f"cfg 1 AS DEFINED: all 4 denoise steps executed ({', '.join(f'{t:.1f}' for t in t_steps)} s) + VAE encode {t_enc:.1f}s + "
+                f"VAE decode {t_dec:.1f}s = {t4:.0f}s per image; `value` = 1 / (enc + 28 x mean step + dec) = 1 / {t28:.0f}s is the 28-step extrapolation")
+    else:
+        what = (f"ONE full-depth denoise step (embedders + 19 double + 38 single blocks + head) {t_step:.1f}s + VAE encode {t_enc:.1f}s + "
+                f"VAE decode {t_dec:.1f}s executed; steps 2-4 of cfg 1 and steps 2-28 of cfg 2 NOT executed: `value` = 1 / (enc + 28 x step + dec) "
+                f"= 1 / {t28:.0f}s and cfg 1 = 1 / {t4:.0f}s are EXTRAPOLATIONS of that one step (all four executed: `--cpu-baseline cfg1`, "
+                f"profiles/r03_cpu_baseline_cfg1.json)")
+    return dict(common, value=1.0 / t28, cfg1_4step_images_per_s=1.0 / t4, steps_executed=n_steps,
+                steps_not_executed=[] if n_steps == 4 else [2, 3, 4],
+                t_step_s=t_step, t_steps_s=t_steps, t_vae_encode_s=t_enc, t_vae_decode_s=t_dec, gflops_step=flops_step / t_step / 1e9,
+                block_time_shared_vs_distinct_weights=weights_note,
+                sample=f"fp32 oracle through the cli-equivalent plumbing at S={S_txt + S_img} (B=1): {what}; 18 + 37 of the blocks "
+                       f"share one seeded weight set, block 9 / 19 of each kind has its own (timed apart: `block_time_shared_vs_distinct_weights`)")
 
 
 def prompt_encode_time(device, batch=1):
@@ -368,7 +399,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the workload's batch per GPU; strong: --global-batch fixed, sharded items[rank::world]")
     ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: total edits per step (default 8 x batch)")
-    ap.add_argument("--cpu-baseline", default="full", choices=["full", "blocks", "none"])
+    ap.add_argument("--cpu-baseline", default="full", choices=["full", "cfg1", "blocks", "none"],
+                    help="full: one full-depth CPU step + VAE (default); cfg1: all four steps of BASELINE.json configs[0]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the 1024^2 and prompt-encode extras")

@@ -180,20 +180,33 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
   bool overflow = false;         // wave-uniform
 
   const int nkt = (p.S + KVBLK - 1) / KVBLK;
+  // STAGES == 3: one barrier per tile, tile kt + 2 requested when tile kt is published.
+  // STAGES == 4 ("pairs"): ONE barrier per TWO tiles -- at every even tile the wave waits for the pair (kt, kt + 1),
+  // passes the barrier and requests the pair (kt + 2, kt + 3) into the two stages the previous pair has just left.
+  constexpr bool PAIRS = STAGES == 4;
   int st_cur = 0, st_pf = PF;
   auto fill = [&]() {
 #pragma unroll
-    for (int s = 0; s < PF; ++s)
+    for (int s = 0; s < (PAIRS ? 2 : PF); ++s)
       if (s < nkt) issue_tile(s, s);
     st_cur = 0;
-    st_pf = PF;
+    st_pf = PAIRS ? 2 : PF;
   };
-  // ring bookkeeping shared by the main loop and the pre-pass: wait for tile kt, publish it, request tile kt+PF
+  // ring bookkeeping shared by the main loop and the pre-pass: wait for tile kt, publish it, request the tile(s) ahead
   auto acquire_tile = [&](int kt) {
-    if (kt + PF - 1 < nkt) wait_vmcnt<(PF - 1) * LOADS>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (kt + PF < nkt) issue_tile(kt + PF, st_pf);
+    if constexpr (PAIRS) {
+      if ((kt & 1) == 0) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nkt) issue_tile(kt + 2, st_pf);
+        if (kt + 3 < nkt) issue_tile(kt + 3, st_pf == STAGES - 1 ? 0 : st_pf + 1);
+      }
+    } else {
+      if (kt + PF - 1 < nkt) wait_vmcnt<(PF - 1) * LOADS>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (kt + PF < nkt) issue_tile(kt + PF, st_pf);
+    }
     return smem + st_cur * STAGE_BYTES;
   };
   auto release_tile = [&]() {
@@ -572,6 +585,7 @@ int launch(AttnParams p, hipStream_t stream, int n_full, int n_light_blocks, int
 // for the extra workgroups' prologues, and the idle CUs of the plain grid's last round are not wasted -- they hand
 // their power budget to the busy ones.  fk_attention_set_tail(1) / FK_ATTN_TAIL=1 select it for measurements.
 static int g_attn_tail = -2;
+static int g_attn_ring = -1;
 static int attn_tail_mode() {
   if (g_attn_tail == -2) {
     const char* e = getenv("FK_ATTN_TAIL");
@@ -635,11 +649,24 @@ int attention_entry(const void* q, const void* k, const void* v, void* o, int32_
     if (4 * rem <= G) { tail = rem; subs = 4; }
     else if (2 * rem <= G) { tail = rem; subs = 2; }
   }
+  if (g_attn_ring < 0) {                            // FK_ATTN_RING=4: 4-stage ring, one barrier per two KV tiles
+    const char* e = getenv("FK_ATTN_RING");
+    g_attn_ring = e ? atoi(e) : 3;
+  }
+  if (g_attn_ring == 4)
+    return use_interleaved(p) ? launch<8, 4, false, true>(p, stream, nblk - tail, tail, subs)
+                              : launch<8, 4, false, false>(p, stream, nblk - tail, tail, subs);
   return use_interleaved(p) ? launch<8, 3, false, true>(p, stream, nblk - tail, tail, subs)
                             : launch<8, 3, false, false>(p, stream, nblk - tail, tail, subs);
 }
 
 }  // namespace
+
+extern "C" int fk_attention_set_ring(int32_t stages) {
+  FK_CHECK_ARG(stages == 3 || stages == 4, "fk_attention_set_ring: %d is not 3 (a barrier per KV tile) or 4 (a barrier per two)", stages);
+  g_attn_ring = stages;
+  return FK_OK;
+}
 
 extern "C" int fk_attention_set_tail(int32_t mode) {
   FK_CHECK_ARG(mode == 0 || mode == 1, "fk_attention_set_tail: %d is not 0 (plain grid) or 1 (light workgroups for the last round)", mode);

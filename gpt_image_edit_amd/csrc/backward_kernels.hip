@@ -33,8 +33,20 @@ __global__ __launch_bounds__(256) void finalize_partials_kernel(const float* par
   const int b = blockIdx.y;
   float s = 0.f;
   if (c < n) {
+    // eight independent running sums per thread (parts grp + 4 (8 j + u)): the loads of one trip are in flight together
+    // instead of one memory latency per part (measured 53 us per launch as a serial chain, 2.4 % of a training step);
+    // combined in a fixed order, so the result stays bit-identical from run to run
     const float* p = part + ((int64_t)b * nparts) * n + c;
-    for (int i = grp; i < nparts; i += 4) s += p[(int64_t)i * n];
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = grp; i < nparts; i += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = i + 4 * u;
+        const float v = p[(int64_t)min(j, nparts - 1) * n];
+        a[u] += j < nparts ? v : 0.f;
+      }
+    }
+    s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
   red[grp][cl] = s;
   __syncthreads();

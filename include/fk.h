@@ -162,6 +162,9 @@ int fk_attention_fwd_bf16(const void* q, const void* k, const void* v, void* o, 
  * overrides) = plain grid -- the light form measured slower inside an edit (profiles/r03_attention_tail.txt).  Same
  * results bit for bit: a query row's arithmetic does not depend on the workgroup shape that carries it. */
 int fk_attention_set_tail(int32_t mode);
+/* Measurement hook: K / V ring of the forward kernel: 3 stages = one workgroup barrier per 64-key tile (default;
+ * FK_ATTN_RING overrides), 4 stages = one barrier per two tiles.  Same results bit for bit. */
+int fk_attention_set_ring(int32_t stages);
 
 /* Parity / debug build of the SAME kernel (same tiling, LDS layouts, softmax, key <-> MFMA k-slot binding): the output
  * is fp32 (o_ld / o_batch_stride in fp32 elements, 16-byte aligned) and every probability enters the PV product as

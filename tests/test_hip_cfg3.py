@@ -189,3 +189,25 @@ def test_attention_tail_workgroups_give_the_same_bits(B, H, S):
     ref = F.scaled_dot_product_attention(q[:, h].float().cpu()[:, None], k[:, h].float().cpu()[:, None], v[:, None])[:, 0]
     d = report(f"attention tail B{B} H{H} S{S} (last head)", outs[1][0][:, :, h * 128:(h + 1) * 128], ref)
     assert d.max().item() <= 1e-2 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("B,H,S", [(1, 3, 8704), (2, 2, 2500), (1, 2, 64), (1, 2, 100)])
+def test_attention_ring_of_four_gives_the_same_bits(B, H, S):
+    """fk_attention_set_ring(4): one workgroup barrier per TWO KV tiles (4-stage ring) instead of one per tile -- the same
+    arithmetic behind other synchronisation; odd / even / single tile counts and a ragged last tile."""
+    _skip()
+    from gpt_image_edit_amd import libfk, ops
+    q, k = _randn(B, H, S, 128, seed=150).cuda(), _randn(B, H, S, 128, seed=151).cuda()
+    qkv = _randn(B, S, 3 * H * 128, seed=152).cuda()
+    lib = libfk.load()
+    outs = []
+    try:
+        for ring in (3, 4, 4):
+            libfk.check(lib.fk_attention_set_ring(ring), "fk_attention_set_ring")
+            o = torch.full((B, S, H * 128), 7.0, dtype=BF, device="cuda")
+            ops.attention(q, k, qkv[:, :, 2 * H * 128:], o)
+            outs.append(o)
+    finally:
+        lib.fk_attention_set_ring(3)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
