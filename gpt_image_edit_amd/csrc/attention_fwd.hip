@@ -183,6 +183,9 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
   // STAGES == 3: one barrier per tile, tile kt + 2 requested when tile kt is published.
   // STAGES == 4 ("pairs"): ONE barrier per TWO tiles -- at every even tile the wave waits for the pair (kt, kt + 1),
   // passes the barrier and requests the pair (kt + 2, kt + 3) into the two stages the previous pair has just left.
+  // Measured (profiles/r03_attention_variants.txt): 1-3 % SLOWER at every shape, isolated and inside the edits -- the
+  // per-tile barrier is not the cost the parked-wave counter suggests; it keeps the eight waves' K / V reads together.
+  // Kept as a switch (fk_attention_set_ring), not the default.
   constexpr bool PAIRS = STAGES == 4;
   int st_cur = 0, st_pf = PF;
   auto fill = [&]() {
@@ -579,7 +582,7 @@ int launch(AttnParams p, hipStream_t stream, int n_full, int n_light_blocks, int
 // measured SLOWER in the edit), but only 2 (4) waves own query rows -- one computing wave per SIMD instead of two, so
 // each runs faster and the tail spreads over 192 CUs.  Every query row's arithmetic is the same whichever workgroup
 // shape carries it: bit-identical output (tests/test_hip_cfg3.py).  MEASURED, BOTH FORMS, AND OFF BY DEFAULT
-// (profiles/r03_attention_tail.txt): isolated the light workgroups gain 1.5-3 % at S = 8704 / 5632 as a second launch of
+// (profiles/r03_attention_variants.txt): isolated the light workgroups gain 1.5-3 % at S = 8704 / 5632 as a second launch of
 // 2-wave workgroups and lose 2 % inside the launch; inside the 1024^2 edit both forms LOSE (1492 -> 1524 ms and
 // 1634 -> 1695 ms of attention per edit): a lone wave per SIMD does not run enough faster than two sharing one to pay
 // for the extra workgroups' prologues, and the idle CUs of the plain grid's last round are not wasted -- they hand

@@ -159,7 +159,7 @@ int fk_attention_fwd_bf16(const void* q, const void* k, const void* v, void* o, 
                           int64_t o_batch_stride, float scale, fk_stream_t stream);
 /* Measurement hook: 1 = the blocks of a grid's last, partly filled round of CUs run as four / two "light" workgroups
  * (all 8 waves load K / V, 2 / 4 own query rows) so that they spread over the idle CUs; 0 (default; FK_ATTN_TAIL
- * overrides) = plain grid -- the light form measured slower inside an edit (profiles/r03_attention_tail.txt).  Same
+ * overrides) = plain grid -- the light form measured slower inside an edit (profiles/r03_attention_variants.txt).  Same
  * results bit for bit: a query row's arithmetic does not depend on the workgroup shape that carries it. */
 int fk_attention_set_tail(int32_t mode);
 /* Measurement hook: K / V ring of the forward kernel: 3 stages = one workgroup barrier per 64-key tile (default;
