@@ -521,15 +521,50 @@ def _gn_workspace(lib, B, HW, C, device):
     return hit
 
 
-def group_norm_nhwc(x, gamma, beta, silu, eps=1e-6, out=None):
-    """GroupNorm(32) (+SiLU) over [B, ..., C] NHWC bf16."""
-    _need_cuda(x, gamma, beta)
+def group_norm_stats(x, eps=1e-6):
+    """(mean, rstd) fp32 [B, 32, 2] of GroupNorm(32) over [B, ..., C] NHWC bf16.  The buffer is shared by every call of
+    one shape on the device: consume it (``group_norm_nhwc`` / ``conv3x3_halo(gn=...)``) before the next call."""
+    _need_cuda(x)
     B, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C)
     lib = libfk.load()
     ws, stats = _gn_workspace(lib, B, HW, C, x.device)
     libfk.check(lib.fk_groupnorm_stats_nhwc_bf16(_ptr(x), _ptr(stats), _ptr(ws), B, HW, C, 32, eps, _stream()),
                 "fk_groupnorm_stats_nhwc_bf16")
+    return stats
+
+
+def conv3x3_halo(x, w_packed, bias, cout, upsample2x=False, res=None, gn=None, out=None):
+    """3 x 3 / stride 1 / pad 1 convolution over NHWC bf16 by the LDS halo-tiled kernel (csrc/conv_halo.hip), optionally
+    with GroupNorm(32) (+ SiLU) of the INPUT applied while the halo tile is staged: ``gn = (stats, gamma, beta, silu)``
+    with ``stats`` from :func:`group_norm_stats`.  Cin % 64 == 0."""
+    _need_cuda(x, w_packed, bias, res)
+    B, Hin, Win, Cin = x.shape
+    Hout, Wout = (Hin * 2, Win * 2) if upsample2x else (Hin, Win)
+    if out is None:
+        out = torch.empty((B, Hout, Wout, cout), device=x.device, dtype=BF16)
+    if not x.is_contiguous() or (res is not None and not res.is_contiguous()):
+        raise ValueError("conv3x3_halo needs contiguous NHWC tensors")
+    a = libfk.ConvArgs()
+    a.x, a.w, a.bias, a.y = x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), out.data_ptr()
+    a.res = res.data_ptr() if res is not None else None
+    a.B, a.Hin, a.Win, a.Cin, a.Cout = B, Hin, Win, Cin, cout
+    a.ksize, a.stride, a.pad, a.upsample2x = 3, 1, 1, int(upsample2x)
+    a.Hout, a.Wout = Hout, Wout
+    stats, gamma, beta, silu = gn if gn is not None else (None, None, None, False)
+    _need_cuda(stats, gamma, beta)
+    libfk.check(libfk.load().fk_conv3x3_halo_bf16(ctypes.byref(a), _ptr(stats), _ptr(gamma), _ptr(beta), 32, int(bool(silu)),
+                                                  _stream()), "fk_conv3x3_halo_bf16")
+    return out
+
+
+def group_norm_nhwc(x, gamma, beta, silu, eps=1e-6, out=None):
+    """GroupNorm(32) (+SiLU) over [B, ..., C] NHWC bf16."""
+    _need_cuda(x, gamma, beta)
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    lib = libfk.load()
+    stats = group_norm_stats(x, eps)
     if out is None:
         out = torch.empty_like(x)
     libfk.check(lib.fk_groupnorm_apply_nhwc_bf16(_ptr(x), _ptr(out), _ptr(stats), _ptr(gamma), _ptr(beta), B, HW,

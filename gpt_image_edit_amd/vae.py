@@ -10,6 +10,7 @@ add fused into the epilogue); GroupNorm is a two-pass stats + fused apply/SiLU; 
 mid-block attention is QK^T (fp32 scores) -> row softmax -> PV on the same GEMM kernel.
 No torch math runs on the data path; there is no CPU fallback.
 """
+import os
 from types import SimpleNamespace
 
 import torch
@@ -17,6 +18,8 @@ from torch import nn
 
 from . import flux_spec, ops
 from .param_tree import ParamTreeMixin, build_param_tree
+
+HALO = os.environ.get("FK_VAE_HALO", "1") != "0"
 
 BF16 = torch.bfloat16
 
@@ -118,17 +121,32 @@ class HipAutoencoderKL(ParamTreeMixin, nn.Module):
     def _conv(self, name, x, stride=1, pad=1, upsample=False, res=None):
         w, b, cout = self._packed()[name]
         ks = 3 if self.p(name + ".weight").shape[-1] == 3 else 1
+        if pad == 1 and self._halo_ok(name, x, stride):
+            return ops.conv3x3_halo(x, w, b, cout, upsample2x=upsample, res=res)
         return ops.conv2d_nhwc(x, w, b, cout, ksize=ks, stride=stride, pad=pad if ks == 3 else 0,
                                upsample2x=upsample, res=res)
 
     def _gn(self, name, x, silu):
         return ops.group_norm_nhwc(x, self.p(name + ".weight"), self.p(name + ".bias"), silu)
 
+    def _halo_ok(self, name, x, stride=1):
+        """3 x 3 / stride 1 convolutions with Cin % 64 == 0 and >= 64 output channels run on the LDS halo-tiled kernel
+        (csrc/conv_halo.hip); FK_VAE_HALO=0 keeps everything on the implicit-GEMM kernel (A/B, same rounding points)."""
+        w = self.p(name + ".weight")
+        return HALO and stride == 1 and w.shape[-1] == 3 and x.shape[-1] % 64 == 0 and w.shape[0] >= 64
+
+    def _gn_conv(self, norm, conv, x, res=None):
+        """conv(silu(group_norm(x))) (+ res): GroupNorm-apply + SiLU as the convolution's operand prologue."""
+        if not self._halo_ok(conv, x):
+            return self._conv(conv, self._gn(norm, x, True), res=res)
+        w, b, cout = self._packed()[conv]
+        stats = ops.group_norm_stats(x)
+        return ops.conv3x3_halo(x, w, b, cout, res=res, gn=(stats, self.p(norm + ".weight"), self.p(norm + ".bias"), True))
+
     def _resnet(self, p, x):
-        t = self._conv(p + "conv1", self._gn(p + "norm1", x, True))
-        t = self._gn(p + "norm2", t, True)
+        t = self._gn_conv(p + "norm1", p + "conv1", x)
         xs = self._conv(p + "conv_shortcut", x) if self.has(p + "conv_shortcut.weight") else x
-        return self._conv(p + "conv2", t, res=xs)
+        return self._gn_conv(p + "norm2", p + "conv2", t, res=xs)
 
     def _mid_attention(self, p, x):
         B, H, W, C = x.shape

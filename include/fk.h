@@ -311,6 +311,14 @@ typedef struct fk_conv_args {
   int32_t Hout, Wout;
 } fk_conv_args;
 int fk_conv2d_nhwc_bf16(const fk_conv_args* args, fk_stream_t stream);
+/* The 3 x 3 / stride 1 / pad 1 convolutions of ResnetBlock2D / Upsample2D (Cin % 64 == 0) as an LDS halo-tiled MFMA kernel:
+ * a workgroup stages the 18 x 18 x 64-channel halo of its 16 x 16 output pixels ONCE per channel chunk and reads the nine
+ * taps from LDS.  With gn_stats != NULL (fk_groupnorm_stats_nhwc_bf16 of x) the GroupNorm(gn_groups) + optional SiLU that
+ * precedes the convolution in the reference graph (conv(act(norm(x)))) is applied while the halo is staged -- same
+ * arithmetic and rounding points as fk_groupnorm_apply_nhwc_bf16, zero padding outside the image AFTER the normalisation --
+ * so the normalised activation is never written to memory.  args->res: y = bf16(res + y).  args->upsample2x as above. */
+int fk_conv3x3_halo_bf16(const fk_conv_args* args, const float* gn_stats, const void* gn_gamma, const void* gn_beta,
+                         int32_t gn_groups, int32_t gn_silu, fk_stream_t stream);
 
 /* GroupNorm(32 groups, eps) statistics: stats[b, g] = (mean, rstd) fp32; ws: fp32 workspace of
  * fk_groupnorm_ws_floats(B, HW, C) floats. */

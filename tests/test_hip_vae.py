@@ -61,6 +61,52 @@ def test_conv_nhwc(cin, cout, h, w, mode):
     assert (ulp > 1).float().mean().item() < 2e-3
 
 
+@pytest.mark.parametrize("cin,cout,h,w,mode", [(128, 128, 9, 7, "gn"), (256, 128, 20, 33, "gn+res"), (512, 256, 6, 10, "up"),
+                                               (64, 64, 16, 16, "plain"), (128, 512, 32, 16, "gn+res"), (256, 256, 17, 40, "up+res")])
+def test_conv3x3_halo(cin, cout, h, w, mode):
+    """The LDS halo-tiled 3 x 3 convolution (csrc/conv_halo.hip) with GroupNorm(32) + SiLU as its operand prologue:
+    against conv2d(silu(group_norm(x))) in fp32 on the host, and bit for bit against the un-fused HIP route's
+    normalised activation (same rounding points) convolved by the implicit-GEMM kernel up to the accumulation order.
+    Sizes off the 16-pixel tile, several channel chunks, two batch entries, upsampled input, residual."""
+    _skip()
+    from gpt_image_edit_amd import ops
+    from gpt_image_edit_amd.vae import _pack_conv
+    B = 2
+    x = (randn(B, cin, h, w, seed=11, scale=1.3).float() + torch.linspace(-1, 1, cin)[None, :, None, None]).to(BF)
+    wt = randn(cout, cin, 3, 3, seed=12, scale=0.03)
+    bias = randn(cout, seed=13, scale=0.1)
+    gamma, beta = (1 + randn(cin, seed=14, scale=0.1).float()).to(BF), randn(cin, seed=15, scale=0.1)
+    gn, up, with_res = "gn" in mode, "up" in mode, "res" in mode
+    xin = x.float()
+    if gn:   # the reference graph in bf16: GroupNorm output rounded, SiLU output rounded
+        xin = F.silu(F.group_norm(x.float(), 32, gamma.float(), beta.float(), 1e-6).to(BF).float()).to(BF).float()
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, wt.float(), bias.float(), padding=1)
+    res = randn(*ref.shape, seed=16)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = _pack_conv(wt.cuda())
+    res_d = res.permute(0, 2, 3, 1).contiguous().cuda() if with_res else None
+    gn_arg = (ops.group_norm_stats(x_nhwc), gamma.cuda(), beta.cuda(), True) if gn else None
+    got = ops.conv3x3_halo(x_nhwc, wp, bias.cuda(), cout, upsample2x=up, res=res_d, gn=gn_arg)
+    got2 = ops.conv3x3_halo(x_nhwc, wp, bias.cuda(), cout, upsample2x=up, res=res_d,
+                            gn=(ops.group_norm_stats(x_nhwc), gamma.cuda(), beta.cuda(), True) if gn else None)
+    # the un-fused HIP route on the same operands
+    xn = ops.group_norm_nhwc(x_nhwc, gamma.cuda(), beta.cuda(), True) if gn else x_nhwc
+    old = ops.conv2d_nhwc(xn, wp, bias.cuda(), cout, ksize=3, stride=1, pad=1, upsample2x=up, res=res_d)
+    torch.cuda.synchronize()
+    assert torch.equal(got, got2), "halo convolution is not deterministic"
+    want = (res + ref.to(BF)) if with_res else ref.to(BF)
+    g = got.permute(0, 3, 1, 2).cpu()
+    report(f"conv3x3_halo {mode} {cin}->{cout} {h}x{w}", g, want)
+    ulp = bf16_ulp_diff(g, want)
+    assert (ulp > 1).float().mean().item() < 4e-3
+    assert (g.float() - want.float()).abs().max().item() <= 2e-2 * want.float().abs().max().item()
+    # same operands, other accumulation order: the two HIP kernels agree to the last bit almost everywhere
+    u2 = bf16_ulp_diff(got.cpu(), old.cpu())
+    assert (u2 > 1).float().mean().item() < 1e-3 and (u2 == 0).float().mean().item() > 0.9
+
+
 @pytest.mark.parametrize("C,hw,silu", [(128, 33 * 17, True), (512, 64, False), (256, 4096, True)])
 def test_group_norm(C, hw, silu):
     _skip()
