@@ -128,15 +128,19 @@ def instrumented_edit(pipe, inp):
     def grouped_flops(a, k, out):
         return sum(2.0 * (pr["a"].numel() // pr["a"].shape[-1]) * pr["w"].shape[0] * pr["w"].shape[1] for pr in a[0])
 
-    orig = (ops.gemm, ops.gemm_grouped, ops.attention, ops.conv2d_nhwc)
-    ops.gemm, ops.gemm_grouped, ops.attention, ops.conv2d_nhwc = (
+    def halo_flops(a, k, out):   # conv3x3_halo(x, w_packed, bias, cout, ...): the GroupNorm-stats launch in front of it is not in the bracket
+        return 2.0 * out.numel() // out.shape[-1] * a[3] * 9 * a[0].shape[-1]
+
+    orig = (ops.gemm, ops.gemm_grouped, ops.attention, ops.conv2d_nhwc, ops.conv3x3_halo)
+    ops.gemm, ops.gemm_grouped, ops.attention, ops.conv2d_nhwc, ops.conv3x3_halo = (
         wrap(ops.gemm, "gemm", gemm_flops), wrap(ops.gemm_grouped, "gemm", grouped_flops),
-        wrap(ops.attention, "attention", attn_flops), wrap(ops.conv2d_nhwc, "conv", conv_flops))
+        wrap(ops.attention, "attention", attn_flops), wrap(ops.conv2d_nhwc, "conv", conv_flops),
+        wrap(ops.conv3x3_halo, "conv", halo_flops))
     try:
         run_edit(pipe, inp)
         torch.cuda.synchronize()
     finally:
-        ops.gemm, ops.gemm_grouped, ops.attention, ops.conv2d_nhwc = orig
+        ops.gemm, ops.gemm_grouped, ops.attention, ops.conv2d_nhwc, ops.conv3x3_halo = orig
         transformer.OVERLAP_MLP = overlap
     out = {}
     for fam, lst in rec.items():
