@@ -4,17 +4,29 @@
 //   P = softmax(Q K^T c),  O = P V             D_q = sum_d dO O  (fk_rowdot_bf16),  lse_q from the forward (log2 domain)
 //   dV = P^T dO          dP = dO V^T          dS = P o (dP - D) c          dQ = dS K          dK = dS^T Q
 //
-// Three passes of ONE kernel skeleton, each the shape of the forward kernel -- a "row" operand held in registers (32
-// rows per wave, 256 per workgroup), the "column" operand streamed through LDS in tiles of 64 by LDS-DMA, two MFMA
-// products that land transposed so that every lane owns one row, an elementwise stage, and one accumulating product
-// through the LDS transpose read:
+// The passes share ONE kernel skeleton, the shape of the forward kernel -- a "row" operand held in registers (32 rows
+// per wave), the "column" operand streamed through LDS in tiles of 64 by LDS-DMA, MFMA products that land transposed so
+// that every lane owns one row, an elementwise stage, and an accumulating product through the LDS transpose read:
 //   MODE_DQ  rows = queries (Q, dO in registers), columns = keys:     s = K Q^T, dp = V dO^T, w = p (dp - D) c, dQ^T += K^T w
 //   MODE_DV  rows = keys (K in registers),        columns = queries:  s = Q K^T,              w = p,            dV^T += dO^T w
 //   MODE_DK  rows = keys (K, V in registers),     columns = queries:  s = Q K^T, dp = dO V^T, w = p (dp - D) c, dK^T += Q^T w
-// with p = exp2(s c' - lse).  No atomics, no cross-workgroup reduction: gradients are deterministic; the price is that
-// S and dP are recomputed per pass (8 tile products instead of the 5 of a fused backward).  Every streamed tensor that
-// feeds both a row-fragment product and a transposed product is staged twice (two LDS images, two swizzles), as the
-// forward does for K (row fragments) and V (transpose read).
+// with p = exp2(s c' - lse).  No atomics, no cross-workgroup reduction: gradients are deterministic.
+//
+// Default since round 3: TWO passes, 7 tile products and 2 exponentials per score instead of 8 and 3.  dK and dV come out
+// of one launch (attention_bwd_dkv_kernel) in which the two waves that share a SIMD split the work on the same 32 keys:
+//   producer (waves 0-3)  s = Q K^T, p = exp2(s c' - lse), hands bf16(p) over through LDS,          dV^T += dO^T p
+//   consumer (waves 4-7)  dp = dO V^T, w = bf16(p) (dp - D) c,                                      dK^T += Q^T w
+// Both accumulators and both stationary operands do not fit 256 registers of one wave; split like this every wave is at
+// ~150, every product is computed once, and the hand-over is lane-to-same-lane (the producer's packed B-operand fragments
+// ARE the consumer's), one tile behind, ordered by the per-tile workgroup barrier -- no flags, no polling.
+// fk_attention_bwd_set_mode(0) / FK_ATTN_BWD=0 selects the three-pass form (dK then differs in the last bf16 bit: there
+// w is formed from the fp32 p).
+//
+// One LDS image per streamed tensor: the 16-byte slot c of tile row r sits at slot c ^ swz(r), swz(r) = the two bit pairs
+// of (r & 15) exchanged.  Row-fragment reads (ds_read_b128, 16 rows x one logical slot per lane group) see 16 distinct
+// slots because swz is a bijection of r & 15; transpose reads (ds_read_b64_tr_b16, 4 rows x the 4 slots of one 64-byte
+// block per 32-lane group) see 4 distinct blocks because the high pair of swz(r) is r & 3.  So K in the dQ pass and Q in
+// the dK pass are staged once, not twice (two DMA pieces per wave and tile less).
 #include <type_traits>
 
 #include "fk_common.h"
@@ -24,8 +36,9 @@ namespace {
 constexpr int HD = 128;
 constexpr int CBLK = 64;                        // columns per tile
 constexpr int IMG = CBLK * HD * 2;              // one LDS image of a tile: 16 KiB
-constexpr int STAGE_BYTES = 3 * IMG + 512;      // A | Bt | C | lse[64] dsum[64]
+constexpr int STAGE_BYTES = 2 * IMG + 512;      // image 0 | image 1 | lse[64] dsum[64]
 constexpr int STAGES = 3, PF = STAGES - 1;
+constexpr int PBUF_BYTES = 4 * 2 * 4096;        // dK+dV kernel: per wave pair, two tiles of packed p (2 halves x 2 steps x 64 lanes x 16 B)
 enum { MODE_DQ = 0, MODE_DV = 1, MODE_DK = 2 };
 
 struct TView {           // element (b, h, s, d) at p + b*bs + h*hs + s*ld + d
@@ -36,8 +49,10 @@ struct BwdParams {
   TView q, k, v, dout;
   const float* lse;      // [B, H, S] log2-domain log-sum-exp of the forward
   const float* dsum;     // [B, H, S] sum_d dO * O
-  bf16_t* out;           // gradient written by this pass
+  bf16_t* out;           // gradient written by this pass (dK of the dK+dV pass)
   int64_t o_ld, o_hs, o_bs;
+  bf16_t* out2;          // dV of the dK+dV pass
+  int64_t o2_ld, o2_hs, o2_bs;
   int B, H, S;
   float scale, scale_log2;
 };
@@ -62,12 +77,13 @@ template <int N>
 FK_DEV void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+FK_DEV int swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }   // slot XOR of LDS row r (header)
 
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p) {
   constexpr bool HAS_C = MODE != MODE_DV;          // second product (dp) and its streamed image
   constexpr bool COL_STATS = MODE != MODE_DQ;      // lse / D vary along the streamed dimension
-  constexpr int LOADS = 4 + (HAS_C ? 2 : 0) + (COL_STATS ? (MODE == MODE_DK ? 2 : 1) : 0);
+  constexpr int LOADS = 4 + (COL_STATS ? (MODE == MODE_DK ? 2 : 1) : 0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -86,12 +102,13 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
   const int bh = t0 / nrb;
   const int b = bh / p.H, h = bh - b * p.H;
 
-  // which tensors play which role
+  // which tensors play which role: image 0 feeds the s product (row fragments), image 1 the dp product (row fragments) or,
+  // in the dV pass, the accumulating product (transpose reads); the dQ / dK passes transpose-read image 0
   const TView& X1 = MODE == MODE_DQ ? p.q : p.k;
   const TView& X2 = MODE == MODE_DQ ? p.dout : p.v;
-  const TView& TA = MODE == MODE_DQ ? p.k : p.q;                            // row-fragment image A
-  const TView& TB = MODE == MODE_DQ ? p.k : (MODE == MODE_DV ? p.dout : p.q);   // transposed image Bt
-  const TView& TC = MODE == MODE_DQ ? p.v : p.dout;                         // row-fragment image C
+  const TView& T0 = MODE == MODE_DQ ? p.k : p.q;
+  const TView& T1 = MODE == MODE_DQ ? p.v : p.dout;
+  constexpr int TR_IMG = MODE == MODE_DV ? 1 : 0;
 
   // ---- stationary row operands (B operand of the swapped products): lane holds X[row][16 kk + 8 hh .. +8] ----------
   const int row = rb * 256 + wave * 32 + ql;
@@ -119,67 +136,58 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
     return __builtin_amdgcn_make_buffer_rsrc((void*)(t.p + (int64_t)b * t.bs + (int64_t)h * t.hs), 0,
                                              (int)(((int64_t)(p.S - 1) * t.ld + HD) * 2), 0x00020000);
   };
-  const __amdgpu_buffer_rsrc_t rs_a = rsrc_of(TA), rs_b = rsrc_of(TB), rs_c = rsrc_of(TC);
+  const __amdgpu_buffer_rsrc_t rs_0 = rsrc_of(T0), rs_1 = rsrc_of(T1);
   const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lse + (int64_t)bh * p.S), 0, p.S * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dsum + (int64_t)bh * p.S), 0, p.S * 4, 0x00020000);
   const int nt = (p.S + CBLK - 1) / CBLK;
   const bool ragged = p.S % CBLK != 0;
-  // byte offset of tile row r (clamped to the last valid row of the tensor: nothing beyond S is ever fetched)
-  auto voff_rowfrag = [&](const TView& t, int r) { return (int)((r * t.ld + ((pslot ^ (r & 15)) << 3)) * 2); };
-  auto voff_transp = [&](const TView& t, int r, int rs) {
-    const int vcol = ((((pslot >> 2) ^ (rs & 3)) << 5) + ((pslot & 3) << 3));
-    return (int)((r * t.ld + vcol) * 2);
-  };
-  int va[2], vb[2], vc[2];
+  // byte offset of source row q for LDS row r: the swizzle follows the LDS row
+  auto voff = [&](const TView& t, int q, int r) { return (int)((q * t.ld + ((pslot ^ swz(r)) << 3)) * 2); };
+  int v0[2], v1[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = (wave * 2 + i) * 4 + prow;
-    va[i] = voff_rowfrag(TA, r);
-    vb[i] = voff_transp(TB, r, r);
-    vc[i] = voff_rowfrag(TC, r);
+    v0[i] = voff(T0, r, r);
+    v1[i] = voff(T1, r, r);
   }
   auto issue_tile = [&](int t, int stage) {
     char* sb = smem + stage * STAGE_BYTES;
     const int base_row = t * CBLK;
-    int a0 = va[0], a1 = va[1], b0 = vb[0], b1 = vb[1], c0 = vc[0], c1 = vc[1], sl = lane * 4;
+    int a0 = v0[0], a1 = v0[1], c0 = v1[0], c1 = v1[1], sl = lane * 4;
     if (ragged && t == nt - 1) {   // rows beyond S: re-read the last valid row (its products are masked to zero)
       const int last = p.S - 1 - base_row;
       const int r0 = (wave * 2) * 4 + prow, r1 = r0 + 4;
       const int q0 = min(r0, last), q1 = min(r1, last);
-      // the swizzle follows the LDS row (r), the source row is clamped (q)
-      a0 = (int)((q0 * TA.ld + ((pslot ^ (r0 & 15)) << 3)) * 2);
-      a1 = (int)((q1 * TA.ld + ((pslot ^ (r1 & 15)) << 3)) * 2);
-      b0 = voff_transp(TB, q0, r0);
-      b1 = voff_transp(TB, q1, r1);
-      c0 = (int)((q0 * TC.ld + ((pslot ^ (r0 & 15)) << 3)) * 2);
-      c1 = (int)((q1 * TC.ld + ((pslot ^ (r1 & 15)) << 3)) * 2);
+      a0 = voff(T0, q0, r0);
+      a1 = voff(T0, q1, r1);
+      c0 = voff(T1, q0, r0);
+      c1 = voff(T1, q1, r1);
       sl = min(lane, last) * 4;
     }
-    buffer_lds<16>(rs_a, sb + (wave * 2) * 1024, a0, (int)(base_row * TA.ld * 2));
-    buffer_lds<16>(rs_a, sb + (wave * 2 + 1) * 1024, a1, (int)(base_row * TA.ld * 2));
-    buffer_lds<16>(rs_b, sb + IMG + (wave * 2) * 1024, b0, (int)(base_row * TB.ld * 2));
-    buffer_lds<16>(rs_b, sb + IMG + (wave * 2 + 1) * 1024, b1, (int)(base_row * TB.ld * 2));
-    if constexpr (HAS_C) {
-      buffer_lds<16>(rs_c, sb + 2 * IMG + (wave * 2) * 1024, c0, (int)(base_row * TC.ld * 2));
-      buffer_lds<16>(rs_c, sb + 2 * IMG + (wave * 2 + 1) * 1024, c1, (int)(base_row * TC.ld * 2));
-    }
+    buffer_lds<16>(rs_0, sb + (wave * 2) * 1024, a0, (int)(base_row * T0.ld * 2));
+    buffer_lds<16>(rs_0, sb + (wave * 2 + 1) * 1024, a1, (int)(base_row * T0.ld * 2));
+    buffer_lds<16>(rs_1, sb + IMG + (wave * 2) * 1024, c0, (int)(base_row * T1.ld * 2));
+    buffer_lds<16>(rs_1, sb + IMG + (wave * 2 + 1) * 1024, c1, (int)(base_row * T1.ld * 2));
     if constexpr (COL_STATS) {   // every wave writes the same 64 floats (identical values): uniform request counts
-      buffer_lds<4>(rs_l, sb + 3 * IMG, sl, base_row * 4);
-      if constexpr (MODE == MODE_DK) buffer_lds<4>(rs_d, sb + 3 * IMG + 256, sl, base_row * 4);
+      buffer_lds<4>(rs_l, sb + 2 * IMG, sl, base_row * 4);
+      if constexpr (MODE == MODE_DK) buffer_lds<4>(rs_d, sb + 2 * IMG + 256, sl, base_row * 4);
     }
   };
 
   // ---- operand reads -------------------------------------------------------------------------------------------------
-  const int k_rd = ql * 256, k_sw = ql & 15;
+  const int k_rd = ql * 256, k_sw = swz(ql);
   const int tj = (lane & 15) >> 2, tq = lane & 3, tdh = (lane >> 4) & 1;
-  const int v_rd = IMG + (4 * hh + tj) * 256 + tdh * 32 + tq * 8;
+  // transpose read of tile rows 16 st + 4 hh + tj (lo) and + 8 (hi): logical slot 4 df + 2 tdh + tq / 2, physical slot
+  // ^ swz(row) = 4 (df ^ tj) + ((2 tdh + tq / 2) ^ (hh + 2 hi))
+  const int t_lo = (4 * hh + tj) * 256 + (((2 * tdh + (tq >> 1)) ^ hh) << 4) + (tq & 1) * 8;
+  const int t_hi = (4 * hh + tj + 8) * 256 + (((2 * tdh + (tq >> 1)) ^ (hh + 2)) << 4) + (tq & 1) * 8;
   auto rowfrag = [&](const char* sb, int img, int kb, int kk) {
     return *(const bf16x8_t*)(sb + img * IMG + k_rd + kb * 8192 + (((2 * kk + hh) ^ k_sw) << 4));
   };
   auto trfrag = [&](const char* sb, int st, int df) {   // columns 16 st + {0, 8} + 4 hh + 0..3, d block df
-    const char* vp = sb + v_rd + st * 4096 + ((df ^ tj) << 6);
-    const s16x4_t lo = lds_tr16(vp);
-    const s16x4_t hi = lds_tr16(vp + 2048);
+    const char* vp = sb + TR_IMG * IMG + st * 4096 + ((df ^ tj) << 6);
+    const s16x4_t lo = lds_tr16(vp + t_lo);
+    const s16x4_t hi = lds_tr16(vp + t_hi);
     bf16x8_t f;
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -227,15 +235,15 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
         }
       };
       product(s, 0, x1f);
-      if constexpr (HAS_C) product(dp, 2, x2f);
+      if constexpr (HAS_C) product(dp, 1, x2f);
       // ---- elementwise: w = p (DV) or p (dp - D) scale (DQ, DK), p = exp2(s c' - lse) <= 1 -------------------------
       float w[16];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4_t lv = {lse_l, lse_l, lse_l, lse_l}, dv = {d_l, d_l, d_l, d_l};
         if constexpr (COL_STATS) {
-          lv = *(const f32x4_t*)(sb + 3 * IMG + (32 * kb + 8 * g + 4 * hh) * 4);
-          if constexpr (MODE == MODE_DK) dv = *(const f32x4_t*)(sb + 3 * IMG + 256 + (32 * kb + 8 * g + 4 * hh) * 4);
+          lv = *(const f32x4_t*)(sb + 2 * IMG + (32 * kb + 8 * g + 4 * hh) * 4);
+          if constexpr (MODE == MODE_DK) dv = *(const f32x4_t*)(sb + 2 * IMG + 256 + (32 * kb + 8 * g + 4 * hh) * 4);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -290,6 +298,234 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
   }
 }
 
+// ---- dK and dV in one launch: producer / consumer wave pairs (header) ---------------------------------------------------
+// Workgroup = 128 keys = 4 pairs of waves (w, w + 4), which the dispatcher places on the same SIMD.  Iteration i: the
+// producers work on query tile i, the consumers on tile i - 1 (whose p the producers stored in iteration i - 1), the DMA
+// fetches tile i + 1 into the stage the consumers left in iteration i - 1; one workgroup barrier per iteration orders all
+// three.  LDS: 3 stages x (Q | dO | lse, D) + 32 KiB of packed p = 132 608 B.
+__global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ql = lane & 31, hh = lane >> 5;
+  const int pair = wave & 3;
+  const bool producer = wave < 4;
+
+  const int nrb = (p.S + 127) / 128;
+  int t0;
+  {
+    const int nwg = gridDim.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    t0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
+  const int rb = t0 % nrb;
+  const int bh = t0 / nrb;
+  const int b = bh / p.H, h = bh - b * p.H;
+
+  // ---- stationary row operand: K rows for the producer, V rows for the consumer ----------------------------------------
+  const int row = rb * 128 + pair * 32 + ql;
+  const int rowc = min(row, p.S - 1);
+  bf16x8_t xf[8];
+  {
+    const bf16_t* xb = producer ? p.k.p + (int64_t)b * p.k.bs + (int64_t)h * p.k.hs + (int64_t)rowc * p.k.ld
+                                : p.v.p + (int64_t)b * p.v.bs + (int64_t)h * p.v.hs + (int64_t)rowc * p.v.ld;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) xf[kk] = *(const bf16x8_t*)(xb + 8 * hh + 16 * kk);
+  }
+
+  // ---- LDS-DMA of the query tiles: image 0 = Q, image 1 = dO, then lse and D of the 64 queries ------------------------
+  const int prow = lane >> 4, pslot = lane & 15;
+  auto rsrc_of = [&](const TView& t) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(t.p + (int64_t)b * t.bs + (int64_t)h * t.hs), 0,
+                                             (int)(((int64_t)(p.S - 1) * t.ld + HD) * 2), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rs_0 = rsrc_of(p.q), rs_1 = rsrc_of(p.dout);
+  const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lse + (int64_t)bh * p.S), 0, p.S * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dsum + (int64_t)bh * p.S), 0, p.S * 4, 0x00020000);
+  const int nt = (p.S + CBLK - 1) / CBLK;
+  const bool ragged = p.S % CBLK != 0;
+  auto voff = [&](const TView& t, int q, int r) { return (int)((q * t.ld + ((pslot ^ swz(r)) << 3)) * 2); };
+  int v0[2], v1[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave * 2 + i) * 4 + prow;
+    v0[i] = voff(p.q, r, r);
+    v1[i] = voff(p.dout, r, r);
+  }
+  auto issue_tile = [&](int t, int stage) {
+    char* sb = smem + stage * STAGE_BYTES;
+    const int base_row = t * CBLK;
+    int a0 = v0[0], a1 = v0[1], c0 = v1[0], c1 = v1[1], sl = lane * 4;
+    if (ragged && t == nt - 1) {   // queries beyond S: re-read the last valid one (the producer zeroes their p)
+      const int last = p.S - 1 - base_row;
+      const int r0 = (wave * 2) * 4 + prow, r1 = r0 + 4;
+      const int q0 = min(r0, last), q1 = min(r1, last);
+      a0 = voff(p.q, q0, r0);
+      a1 = voff(p.q, q1, r1);
+      c0 = voff(p.dout, q0, r0);
+      c1 = voff(p.dout, q1, r1);
+      sl = min(lane, last) * 4;
+    }
+    buffer_lds<16>(rs_0, sb + (wave * 2) * 1024, a0, (int)(base_row * p.q.ld * 2));
+    buffer_lds<16>(rs_0, sb + (wave * 2 + 1) * 1024, a1, (int)(base_row * p.q.ld * 2));
+    buffer_lds<16>(rs_1, sb + IMG + (wave * 2) * 1024, c0, (int)(base_row * p.dout.ld * 2));
+    buffer_lds<16>(rs_1, sb + IMG + (wave * 2 + 1) * 1024, c1, (int)(base_row * p.dout.ld * 2));
+    buffer_lds<4>(rs_l, sb + 2 * IMG, sl, base_row * 4);   // every wave writes the same 2 x 64 floats: uniform request counts
+    buffer_lds<4>(rs_d, sb + 2 * IMG + 256, sl, base_row * 4);
+  };
+
+  // ---- operand reads (as in attention_bwd_kernel) ------------------------------------------------------------------------
+  const int k_rd = ql * 256, k_sw = swz(ql);
+  const int tj = (lane & 15) >> 2, tq = lane & 3, tdh = (lane >> 4) & 1;
+  const int t_lo = (4 * hh + tj) * 256 + (((2 * tdh + (tq >> 1)) ^ hh) << 4) + (tq & 1) * 8;
+  const int t_hi = (4 * hh + tj + 8) * 256 + (((2 * tdh + (tq >> 1)) ^ (hh + 2)) << 4) + (tq & 1) * 8;
+  auto rowfrag = [&](const char* sb, int img, int kb, int kk) {
+    return *(const bf16x8_t*)(sb + img * IMG + k_rd + kb * 8192 + (((2 * kk + hh) ^ k_sw) << 4));
+  };
+  auto trfrag = [&](const char* sb, int img, int st, int df) {
+    const char* vp = sb + img * IMG + st * 4096 + ((df ^ tj) << 6);
+    const s16x4_t lo = lds_tr16(vp + t_lo);
+    const s16x4_t hi = lds_tr16(vp + t_hi);
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+  };
+
+  f32x16_t acc[4];
+#pragma unroll
+  for (int df = 0; df < 4; ++df)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[df][r] = 0.f;
+
+  // one 32 x 32 tile product against the stationary rows, operand reads pinned two MFMAs ahead (attention_bwd_kernel)
+  auto product = [&](f32x16_t& out, const char* sb, int img, int kb) {
+    bf16x8_t kf[3];
+    kf[0] = rowfrag(sb, img, kb, 0);
+    kf[1] = rowfrag(sb, img, kb, 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      if (kk + 2 < 8) kf[(kk + 2) % 3] = rowfrag(sb, img, kb, kk + 2);
+      out = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk % 3], xf[kk], kk == 0 ? f32x16_t{} : out, 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+  };
+  // acc^T[d][row] += image^T w for the two 16-query steps of half kb
+  auto accumulate = [&](const char* sb, int img, int kb, const bf16x8_t (&pf)[2]) {
+    bf16x8_t tf[3];
+    tf[0] = trfrag(sb, img, 2 * kb, 0);
+    tf[1] = trfrag(sb, img, 2 * kb, 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int df = i & 3;
+      if (i + 2 < 8) tf[(i + 2) % 3] = trfrag(sb, img, 2 * kb + ((i + 2) >> 2), (i + 2) & 3);
+      acc[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[i % 3], pf[i >> 2], acc[df], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+  };
+
+  char* const pbuf = smem + STAGES * STAGE_BYTES + pair * 8192 + lane * 16;
+  issue_tile(0, 0);
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // as in attention_bwd_kernel
+
+  int st_pro = 0, st_con = STAGES - 1, st_dma = 1;   // stages of tiles i, i - 1, i + 1
+  for (int i = 0; i <= nt; ++i) {
+    // own DMA pieces of tile i have landed, own p stores of tile i - 1 are in LDS; then everybody's
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (i + 1 < nt) issue_tile(i + 1, st_dma);
+    if (producer) {
+      if (i < nt) {
+        const char* sb = smem + st_pro * STAGE_BYTES;
+        char* pb = pbuf + (i & 1) * 4096;
+        const bool mask = ragged && i == nt - 1;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          f32x16_t s;
+          product(s, sb, 0, kb);
+          float w[16];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4_t lv = *(const f32x4_t*)(sb + 2 * IMG + (32 * kb + 8 * g + 4 * hh) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int r = 4 * g + j;
+              float pr = __builtin_amdgcn_exp2f(fminf(fmaf(s[r], p.scale_log2, -lv[j]), 0.f));
+              if (mask && i * CBLK + 32 * kb + 8 * g + 4 * hh + j >= p.S) pr = 0.f;
+              w[r] = pr;
+            }
+          }
+          bf16x8_t pfs[2];
+#pragma unroll
+          for (int step = 0; step < 2; ++step) {
+            u32x4_t pw;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pw[e] = pack_bf2(w[8 * step + 2 * e], w[8 * step + 2 * e + 1]);
+            pfs[step] = __builtin_bit_cast(bf16x8_t, pw);
+            *(bf16x8_t*)(pb + (2 * kb + step) * 1024) = pfs[step];
+          }
+          accumulate(sb, 1, kb, pfs);
+        }
+      }
+    } else {
+      if (i >= 1) {
+        const char* sb = smem + st_con * STAGE_BYTES;
+        const char* pb = pbuf + ((i - 1) & 1) * 4096;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          f32x16_t dp;
+          product(dp, sb, 1, kb);
+          bf16x8_t wfs[2];
+#pragma unroll
+          for (int step = 0; step < 2; ++step) {
+            const u32x4_t pp = __builtin_bit_cast(u32x4_t, *(const bf16x8_t*)(pb + (2 * kb + step) * 1024));
+            u32x4_t pw;
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {   // registers 8 step + 4 gg + (0..3) = queries 32 kb + 16 step + 8 gg + 4 hh + (0..3)
+              const f32x4_t dv = *(const f32x4_t*)(sb + 2 * IMG + 256 + (32 * kb + 16 * step + 8 * gg + 4 * hh) * 4);
+#pragma unroll
+              for (int e2 = 0; e2 < 2; ++e2) {
+                const int e = 2 * gg + e2, r = 8 * step + 2 * e;
+                const float w0 = bf_lo(pp[e]) * (dp[r] - dv[2 * e2]) * p.scale;
+                const float w1 = bf_hi(pp[e]) * (dp[r + 1] - dv[2 * e2 + 1]) * p.scale;
+                pw[e] = pack_bf2(w0, w1);
+              }
+            }
+            wfs[step] = __builtin_bit_cast(bf16x8_t, pw);
+          }
+          accumulate(sb, 0, kb, wfs);
+        }
+      }
+    }
+    st_con = st_pro;
+    st_pro = st_dma;
+    st_dma = (st_dma == STAGES - 1) ? 0 : st_dma + 1;
+  }
+
+  // ---- store: lane (row = ql) holds d = 32 df + 8 g + 4 hh + (0..3); producers hold dV, consumers dK -----------------
+  if (row < p.S) {
+    bf16_t* op = producer ? p.out2 + (int64_t)b * p.o2_bs + (int64_t)h * p.o2_hs + (int64_t)row * p.o2_ld
+                          : p.out + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs + (int64_t)row * p.o_ld;
+    op += 4 * hh;
+#pragma unroll
+    for (int df = 0; df < 4; ++df)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2_t pk;
+        pk[0] = pack_bf2(acc[df][4 * g + 0], acc[df][4 * g + 1]);
+        pk[1] = pack_bf2(acc[df][4 * g + 2], acc[df][4 * g + 3]);
+        *(u32x2_t*)(op + 32 * df + 8 * g) = pk;
+      }
+  }
+}
+
 template <int MODE>
 int launch_bwd(const BwdParams& p, hipStream_t stream) {
   constexpr int SMEM = STAGES * STAGE_BYTES;
@@ -299,6 +535,26 @@ int launch_bwd(const BwdParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3(nrb * p.H * p.B), dim3(512), SMEM, stream, p);
   FK_CHECK_LAUNCH("fk_attention_bwd_bf16");
   return FK_OK;
+}
+
+int launch_dkv(const BwdParams& p, hipStream_t stream) {
+  constexpr int SMEM = STAGES * STAGE_BYTES + PBUF_BYTES;
+  auto kern = attention_bwd_dkv_kernel;
+  FK_ENSURE_MAX_LDS(kern, SMEM, "fk_attention_bwd_bf16");
+  const int nrb = (p.S + 127) / 128;
+  hipLaunchKernelGGL(kern, dim3(nrb * p.H * p.B), dim3(512), SMEM, stream, p);
+  FK_CHECK_LAUNCH("fk_attention_bwd_bf16");
+  return FK_OK;
+}
+
+// 1 = dQ pass + paired dK/dV pass (default), 0 = three passes; FK_ATTN_BWD overrides, fk_attention_bwd_set_mode sets
+int g_bwd_mode = -1;
+int bwd_mode() {
+  if (g_bwd_mode < 0) {
+    const char* e = getenv("FK_ATTN_BWD");
+    g_bwd_mode = e ? (atoi(e) != 0) : 1;
+  }
+  return g_bwd_mode;
 }
 
 bool view_ok(const fk_attn_view& v, int64_t S) {
@@ -319,7 +575,7 @@ extern "C" int fk_attention_bwd_bf16(const fk_attn_view* q, const fk_attn_view* 
   for (const fk_attn_view* a : all)
     FK_CHECK_ARG(view_ok(*a, S), "fk_attention_bwd_bf16: every view needs a 16-byte aligned pointer, strides that are multiples "
                                  "of 8 elements and a (batch, head) extent below 2 GiB");
-  BwdParams p;
+  BwdParams p{};
   p.q = tv(*q); p.k = tv(*k); p.v = tv(*v); p.dout = tv(*dout);
   p.lse = lse; p.dsum = dsum;
   p.B = B; p.H = H; p.S = S;
@@ -331,9 +587,20 @@ extern "C" int fk_attention_bwd_bf16(const fk_attn_view* q, const fk_attn_view* 
   set_out(*dq);
   int rc = launch_bwd<MODE_DQ>(p, stream);
   if (rc != FK_OK) return rc;
+  if (bwd_mode() == 1) {
+    set_out(*dk);
+    p.out2 = (bf16_t*)dv->p; p.o2_ld = dv->ld; p.o2_hs = dv->head_stride; p.o2_bs = dv->batch_stride;
+    return launch_dkv(p, stream);
+  }
   set_out(*dv);
   rc = launch_bwd<MODE_DV>(p, stream);
   if (rc != FK_OK) return rc;
   set_out(*dk);
   return launch_bwd<MODE_DK>(p, stream);
+}
+
+extern "C" int fk_attention_bwd_set_mode(int32_t mode) {
+  FK_CHECK_ARG(mode == 0 || mode == 1, "fk_attention_bwd_set_mode: %d is not 0 (three passes) or 1 (dQ pass + paired dK / dV pass)", mode);
+  g_bwd_mode = mode;
+  return FK_OK;
 }

@@ -355,6 +355,11 @@ def rowdot(a, c, heads, out=None):
     return out
 
 
+def attention_bwd_set_mode(mode):
+    """fk_attention_bwd_set_mode: 1 = dQ pass + paired dK / dV pass (default), 0 = three passes."""
+    libfk.check(libfk.load().fk_attention_bwd_set_mode(int(mode)), "fk_attention_bwd_set_mode")
+
+
 def attention_bwd(q, k, v, dout, lse, dsum, dq, dk, dv, scale=None):
     """dq, dk [B,H,S,128] and dv ([B,S,H*128] view) of softmax(q k^T scale) v given dout ([B,S,H*128] view), lse, dsum."""
     _need_cuda(q, k, v, dout, lse, dsum, dq, dk, dv)

@@ -191,6 +191,12 @@ typedef struct fk_attn_view {
 int fk_attention_bwd_bf16(const fk_attn_view* q, const fk_attn_view* k, const fk_attn_view* v, const fk_attn_view* dout,
                           const float* lse, const float* dsum, const fk_attn_view* dq, const fk_attn_view* dk,
                           const fk_attn_view* dv, int32_t B, int32_t H, int32_t S, float scale, fk_stream_t stream);
+/* Measurement / parity hook for fk_attention_bwd_bf16: 1 = two launches, the dQ pass and one pass in which wave pairs
+ * produce dK and dV together (7 tile products, default; FK_ATTN_BWD overrides), 0 = three launches (dQ, dV, dK: 8 tile
+ * products).  dQ and dV are the same bit for bit in both; dK differs in the last bf16 bit (mode 1 forms
+ * p (dP - D) from the bf16 p that also enters dV, mode 0 from the fp32 p). */
+int fk_attention_bwd_set_mode(int32_t mode);
+
 /* fp32 elements of workspace `ws` the reductions below need (per-workgroup partial sums, fixed-order finalisation). */
 int64_t fk_bwd_ws_floats(void);
 /* Adjoint of fk_ln_modulate_bf16 for one stream (rows [b*rows_per_batch, (b+1)*rows_per_batch) use scale row b):

@@ -159,3 +159,16 @@ def test_attention_backward(ops, B, H, S):
     dq2, dk2, dqkv2 = torch.empty_like(dq), torch.empty_like(dk), torch.full_like(qkvd, 5.0)
     ops.attention_bwd(qd, kd, qkvd[:, :, 2 * D:], doutd[:, :, :D], lse, dsum, dq2, dk2, dqkv2[:, :, 2 * D:])
     assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dqkv, dqkv2)
+    # the three-pass form (fk_attention_bwd_set_mode(0)): dQ and dV bit for bit, dK to the last bf16 bit (it forms
+    # p (dP - D) from the fp32 p, the paired pass from the bf16 p that also enters dV) and as close to autograd
+    ops.attention_bwd_set_mode(0)
+    try:
+        dq3, dk3, dqkv3 = torch.empty_like(dq), torch.empty_like(dk), torch.full_like(qkvd, 5.0)
+        ops.attention_bwd(qd, kd, qkvd[:, :, 2 * D:], doutd[:, :, :D], lse, dsum, dq3, dk3, dqkv3[:, :, 2 * D:])
+        torch.cuda.synchronize()
+    finally:
+        ops.attention_bwd_set_mode(1)
+    assert torch.equal(dq, dq3) and torch.equal(dqkv, dqkv3)
+    close_bf16(f"attention_bwd dk (three passes) B{B} H{H} S{S}", dk3, kr.grad, tol=2e-2)
+    scale_k = kr.grad.abs().max().item()
+    assert (dk.float() - dk3.float()).abs().max().item() <= 2.0 ** -6 * scale_k

@@ -1,5 +1,6 @@
-"""Attention backward (three passes) at the path's training shapes for ONE build of the library (FK_LIB_PATH selects it);
-run it alternately on two builds for an A/B.  Prints ms per call, the TF/s-equivalent at 8 tile products (what the three
+"""Attention backward at the path's training shapes for ONE build of the library (FK_LIB_PATH selects it); run it
+alternately on two builds for an A/B.  Interleaves the two forms the build offers (fk_attention_bwd_set_mode: 1 = dQ pass +
+paired dK / dV pass, 0 = three passes) and prints ms per call, the TF/s-equivalent at 8 tile products (what the three
 passes execute) and a checksum of the three gradients (bit-identical builds print identical checksums).
 
     FK_LIB_PATH=build_ab/base/gpt_image_edit_amd/libfk_gfx950.so python tools/ab_attention_bwd.py [tag]
@@ -11,12 +12,12 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gpt_image_edit_amd import ops  # noqa: E402
+from gpt_image_edit_amd import libfk, ops  # noqa: E402
 
 BF = torch.bfloat16
 tag = sys.argv[1] if len(sys.argv) > 1 else "lib"
 H, D = 24, 3072
-for B, S in [(1, 8704), (1, 2560)]:
+for B, S in [(1, int(x)) for x in os.environ.get("AB_S", "8704,2560").split(",")]:
     g = torch.Generator(device="cuda").manual_seed(S)
     q = torch.randn(B, H, S, 128, device="cuda", generator=g).to(BF)
     k = torch.randn(B, H, S, 128, device="cuda", generator=g).to(BF)
@@ -28,18 +29,29 @@ for B, S in [(1, 8704), (1, 2560)]:
     dsum = ops.rowdot(do, o, H)
     dq, dk, dqkv = torch.empty_like(q), torch.empty_like(k), torch.zeros_like(qkv)
     fn = lambda: ops.attention_bwd(q, k, qkv[:, :, 2 * D:], do, lse, dsum, dq, dk, dqkv[:, :, 2 * D:])  # noqa: E731
-    fn()
-    torch.cuda.synchronize()
-    ms = []
-    for _ in range(4):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(8):
+    lib = libfk.load()
+    modes = [1, 0] if hasattr(lib, "fk_attention_bwd_set_mode") and os.environ.get("AB_MODES", "1,0") == "1,0" else [None]
+    ms = {m: [] for m in modes}
+    cs = {}
+    for rnd in range(5):
+        for m in modes:
+            if m is not None:
+                lib.fk_attention_bwd_set_mode(m)
             fn()
-        e1.record()
-        e1.synchronize()
-        ms.append(e0.elapsed_time(e1) / 8)
-    m = statistics.median(ms)
+            torch.cuda.synchronize()
+            if rnd == 0:
+                cs[m] = dq.float().abs().sum().item() + dk.float().abs().sum().item() + dqkv.float().abs().sum().item()
+                continue
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                fn()
+            e1.record()
+            e1.synchronize()
+            ms[m].append(e0.elapsed_time(e1) / 8)
+    if modes[0] is not None:
+        lib.fk_attention_bwd_set_mode(1)
     fl = 8 * 2.0 * B * H * S * S * 128
-    cs = dq.float().abs().sum().item() + dk.float().abs().sum().item() + dqkv.float().abs().sum().item()
-    print(f"{tag} attention_bwd B{B} S{S}: {m:.3f} ms  {fl / (m * 1e-3) / 1e12:.0f} TF/s at 8 products  checksum {cs:.8e}", flush=True)
+    for m in modes:
+        t = statistics.median(ms[m])
+        print(f"{tag} mode {m} attention_bwd B{B} S{S}: {t:.3f} ms  {fl / (t * 1e-3) / 1e12:.0f} TF/s at 8 products  checksum {cs[m]:.8e}", flush=True)
