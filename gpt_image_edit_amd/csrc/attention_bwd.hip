@@ -208,13 +208,10 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
   // one static priority raise for it (MI355X_MICROARCH.md, "Two waves per SIMD", item 4); the condition is wave-uniform
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 
-  for (int t = 0; t < nt; ++t) {
-    if (t + PF - 1 < nt) wait_vmcnt<(PF - 1) * LOADS>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (t + PF < nt) issue_tile(t + PF, st_pf);
-    const char* sb = smem + st_cur * STAGE_BYTES;
-    const bool mask = ragged && t == nt - 1;
+  // one streamed tile; with the mask tag the ragged last one (w of the columns beyond S zeroed) -- two instantiations,
+  // so the 135 full tiles of a 136-tile row do not carry the compare / select pairs
+  auto tile_body = [&](const char* sb, int t, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       // Operand fragments are read two MFMAs ahead of their use and the order is pinned (one DS read, then one MFMA), as
@@ -248,10 +245,11 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g + j;
-          const float pr = __builtin_amdgcn_exp2f(fminf(fmaf(s[r], p.scale_log2, -lv[j]), 0.f));
+          const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, -lv[j]));
           float wv = pr;
-          if constexpr (HAS_C) wv = pr * (dp[r] - dv[j]) * p.scale;
-          if (mask && t * CBLK + 32 * kb + 8 * g + 4 * hh + j >= p.S) wv = 0.f;
+          if constexpr (HAS_C) wv = pr * (dp[r] - dv[j]);   // the softmax scale multiplies the accumulator at the store
+          if constexpr (MASK)
+            if (t * CBLK + 32 * kb + 8 * g + 4 * hh + j >= p.S) wv = 0.f;
           w[r] = wv;
         }
       }
@@ -279,20 +277,33 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
         }
       }
     }
+  };
+
+  auto acquire = [&](int t) {   // tile t has landed everywhere; the stage of tile t - 1 is free for tile t + PF
+    if (t + PF - 1 < nt) wait_vmcnt<(PF - 1) * LOADS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + PF < nt) issue_tile(t + PF, st_pf);
+    const char* sb = smem + st_cur * STAGE_BYTES;
     st_cur = (st_cur == STAGES - 1) ? 0 : st_cur + 1;
     st_pf = (st_pf == STAGES - 1) ? 0 : st_pf + 1;
-  }
+    return sb;
+  };
+  const int n_plain = ragged ? nt - 1 : nt;
+  for (int t = 0; t < n_plain; ++t) tile_body(acquire(t), t, std::false_type{});
+  if (ragged) tile_body(acquire(nt - 1), nt - 1, std::true_type{});   // after the loop: one accumulator live range each
 
   // ---- store: lane (row = ql) holds d = 32 df + 8 g + 4 hh + (0..3) ------------------------------------------------
   if (row < p.S) {
+    const float osc = HAS_C ? p.scale : 1.f;   // dQ, dK: the softmax scale left out of w
     bf16_t* op = p.out + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs + (int64_t)row * p.o_ld + 4 * hh;
 #pragma unroll
     for (int df = 0; df < 4; ++df)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         u32x2_t pk;
-        pk[0] = pack_bf2(acc[df][4 * g + 0], acc[df][4 * g + 1]);
-        pk[1] = pack_bf2(acc[df][4 * g + 2], acc[df][4 * g + 3]);
+        pk[0] = pack_bf2(acc[df][4 * g + 0] * osc, acc[df][4 * g + 1] * osc);
+        pk[1] = pack_bf2(acc[df][4 * g + 2] * osc, acc[df][4 * g + 3] * osc);
         *(u32x2_t*)(op + 32 * df + 8 * g) = pk;
       }
   }
@@ -430,83 +441,109 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
     }
   };
 
+  // ---- the producer's tile: S, exponentials, hand-over, dV, half by half --------------------------------------------------
+  auto pack_store = [&](const f32x16_t& w, bf16x8_t (&pf)[2], char* dst) {
+#pragma unroll
+    for (int step = 0; step < 2; ++step) {
+      u32x4_t pw;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pw[e] = pack_bf2(w[8 * step + 2 * e], w[8 * step + 2 * e + 1]);
+      pf[step] = __builtin_bit_cast(bf16x8_t, pw);
+      *(bf16x8_t*)(dst + step * 1024) = pf[step];
+    }
+  };
+  // the plain order (half by half: S, exponentials, dV); with the mask tag the ragged last tile, p of the queries beyond S zeroed
+  auto producer_plain = [&](const char* sb, char* pb, int t, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16_t s;
+      product(s, sb, 0, kb);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4_t lv = *(const f32x4_t*)(sb + 2 * IMG + (32 * kb + 8 * g + 4 * hh) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          float pr = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, -lv[j]));
+          if constexpr (MASK)
+            if (t * CBLK + 32 * kb + 8 * g + 4 * hh + j >= p.S) pr = 0.f;
+          s[r] = pr;
+        }
+      }
+      bf16x8_t pf[2];
+      pack_store(s, pf, pb + kb * 2048);
+      accumulate(sb, 1, kb, pf);
+    }
+  };
+  // ---- the consumer's tile: dP, w from the producer's p, dK, half by half ----------------------------------------------------
+  auto consumer_plain = [&](const char* sb, const char* pb) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16_t dp;
+      product(dp, sb, 1, kb);
+      bf16x8_t wfs[2];
+#pragma unroll
+      for (int step = 0; step < 2; ++step) {
+        const u32x4_t pp = __builtin_bit_cast(u32x4_t, *(const bf16x8_t*)(pb + (2 * kb + step) * 1024));
+        u32x4_t pw;
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {   // registers 8 step + 4 gg + (0..3) = queries 32 kb + 16 step + 8 gg + 4 hh + (0..3)
+          const f32x4_t dv = *(const f32x4_t*)(sb + 2 * IMG + 256 + (32 * kb + 16 * step + 8 * gg + 4 * hh) * 4);
+#pragma unroll
+          for (int e2 = 0; e2 < 2; ++e2) {
+            const int e = 2 * gg + e2, r = 8 * step + 2 * e;
+            const float w0 = bf_lo(pp[e]) * (dp[r] - dv[2 * e2]);   // the softmax scale multiplies dK at the store
+            const float w1 = bf_hi(pp[e]) * (dp[r + 1] - dv[2 * e2 + 1]);
+            pw[e] = pack_bf2(w0, w1);
+          }
+        }
+        wfs[step] = __builtin_bit_cast(bf16x8_t, pw);
+      }
+      accumulate(sb, 0, kb, wfs);
+    }
+  };
+
   char* const pbuf = smem + STAGES * STAGE_BYTES + pair * 8192 + lane * 16;
   issue_tile(0, 0);
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // as in attention_bwd_kernel
 
+  // Iteration i = 0 .. nt of BOTH roles: wait for the own DMA pieces of tile i and the own p stores of tile i - 1, meet,
+  // start the DMA of tile i + 1 into the stage the consumers left in iteration i - 1.  The roles run separate loops (one
+  // accumulator live range each, no copies where they would join); the barrier counts arrivals, not program counters.
   int st_pro = 0, st_con = STAGES - 1, st_dma = 1;   // stages of tiles i, i - 1, i + 1
-  for (int i = 0; i <= nt; ++i) {
-    // own DMA pieces of tile i have landed, own p stores of tile i - 1 are in LDS; then everybody's
+  auto meet = [&](int i) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (i + 1 < nt) issue_tile(i + 1, st_dma);
-    if (producer) {
-      if (i < nt) {
-        const char* sb = smem + st_pro * STAGE_BYTES;
-        char* pb = pbuf + (i & 1) * 4096;
-        const bool mask = ragged && i == nt - 1;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          f32x16_t s;
-          product(s, sb, 0, kb);
-          float w[16];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4_t lv = *(const f32x4_t*)(sb + 2 * IMG + (32 * kb + 8 * g + 4 * hh) * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int r = 4 * g + j;
-              float pr = __builtin_amdgcn_exp2f(fminf(fmaf(s[r], p.scale_log2, -lv[j]), 0.f));
-              if (mask && i * CBLK + 32 * kb + 8 * g + 4 * hh + j >= p.S) pr = 0.f;
-              w[r] = pr;
-            }
-          }
-          bf16x8_t pfs[2];
-#pragma unroll
-          for (int step = 0; step < 2; ++step) {
-            u32x4_t pw;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pw[e] = pack_bf2(w[8 * step + 2 * e], w[8 * step + 2 * e + 1]);
-            pfs[step] = __builtin_bit_cast(bf16x8_t, pw);
-            *(bf16x8_t*)(pb + (2 * kb + step) * 1024) = pfs[step];
-          }
-          accumulate(sb, 1, kb, pfs);
-        }
-      }
-    } else {
-      if (i >= 1) {
-        const char* sb = smem + st_con * STAGE_BYTES;
-        const char* pb = pbuf + ((i - 1) & 1) * 4096;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          f32x16_t dp;
-          product(dp, sb, 1, kb);
-          bf16x8_t wfs[2];
-#pragma unroll
-          for (int step = 0; step < 2; ++step) {
-            const u32x4_t pp = __builtin_bit_cast(u32x4_t, *(const bf16x8_t*)(pb + (2 * kb + step) * 1024));
-            u32x4_t pw;
-#pragma unroll
-            for (int gg = 0; gg < 2; ++gg) {   // registers 8 step + 4 gg + (0..3) = queries 32 kb + 16 step + 8 gg + 4 hh + (0..3)
-              const f32x4_t dv = *(const f32x4_t*)(sb + 2 * IMG + 256 + (32 * kb + 16 * step + 8 * gg + 4 * hh) * 4);
-#pragma unroll
-              for (int e2 = 0; e2 < 2; ++e2) {
-                const int e = 2 * gg + e2, r = 8 * step + 2 * e;
-                const float w0 = bf_lo(pp[e]) * (dp[r] - dv[2 * e2]) * p.scale;
-                const float w1 = bf_hi(pp[e]) * (dp[r + 1] - dv[2 * e2 + 1]) * p.scale;
-                pw[e] = pack_bf2(w0, w1);
-              }
-            }
-            wfs[step] = __builtin_bit_cast(bf16x8_t, pw);
-          }
-          accumulate(sb, 0, kb, wfs);
-        }
-      }
-    }
+  };
+  auto rotate = [&]() {
     st_con = st_pro;
     st_pro = st_dma;
     st_dma = (st_dma == STAGES - 1) ? 0 : st_dma + 1;
+  };
+  if (producer) {
+    const int n_plain = ragged ? nt - 1 : nt;
+    for (int i = 0; i < n_plain; ++i) {
+      meet(i);
+      producer_plain(smem + st_pro * STAGE_BYTES, pbuf + (i & 1) * 4096, i, std::false_type{});
+      rotate();
+    }
+    if (ragged) {
+      meet(nt - 1);
+      producer_plain(smem + st_pro * STAGE_BYTES, pbuf + ((nt - 1) & 1) * 4096, nt - 1, std::true_type{});
+      rotate();
+    }
+    meet(nt);
+  } else {
+    meet(0);
+    rotate();
+    for (int i = 1; i <= nt; ++i) {
+      meet(i);
+      consumer_plain(smem + st_con * STAGE_BYTES, pbuf + ((i - 1) & 1) * 4096);
+      rotate();
+    }
   }
 
   // ---- store: lane (row = ql) holds d = 32 df + 8 g + 4 hh + (0..3); producers hold dV, consumers dK -----------------
@@ -514,13 +551,14 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
     bf16_t* op = producer ? p.out2 + (int64_t)b * p.o2_bs + (int64_t)h * p.o2_hs + (int64_t)row * p.o2_ld
                           : p.out + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs + (int64_t)row * p.o_ld;
     op += 4 * hh;
+    const float osc = producer ? 1.f : p.scale;   // dK: the softmax scale left out of w
 #pragma unroll
     for (int df = 0; df < 4; ++df)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         u32x2_t pk;
-        pk[0] = pack_bf2(acc[df][4 * g + 0], acc[df][4 * g + 1]);
-        pk[1] = pack_bf2(acc[df][4 * g + 2], acc[df][4 * g + 3]);
+        pk[0] = pack_bf2(acc[df][4 * g + 0] * osc, acc[df][4 * g + 1] * osc);
+        pk[1] = pack_bf2(acc[df][4 * g + 2] * osc, acc[df][4 * g + 3] * osc);
         *(u32x2_t*)(op + 32 * df + 8 * g) = pk;
       }
   }
@@ -587,7 +625,7 @@ extern "C" int fk_attention_bwd_bf16(const fk_attn_view* q, const fk_attn_view* 
   set_out(*dq);
   int rc = launch_bwd<MODE_DQ>(p, stream);
   if (rc != FK_OK) return rc;
-  if (bwd_mode() == 1) {
+  if (bwd_mode() != 0) {
     set_out(*dk);
     p.out2 = (bf16_t*)dv->p; p.o2_ld = dv->ld; p.o2_hs = dv->head_stride; p.o2_bs = dv->batch_stride;
     return launch_dkv(p, stream);

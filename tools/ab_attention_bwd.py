@@ -30,7 +30,7 @@ for B, S in [(1, int(x)) for x in os.environ.get("AB_S", "8704,2560").split(",")
     dq, dk, dqkv = torch.empty_like(q), torch.empty_like(k), torch.zeros_like(qkv)
     fn = lambda: ops.attention_bwd(q, k, qkv[:, :, 2 * D:], do, lse, dsum, dq, dk, dqkv[:, :, 2 * D:])  # noqa: E731
     lib = libfk.load()
-    modes = [1, 0] if hasattr(lib, "fk_attention_bwd_set_mode") and os.environ.get("AB_MODES", "1,0") == "1,0" else [None]
+    modes = [int(m) for m in os.environ.get("AB_MODES", "1,0").split(",")] if os.environ.get("AB_MODES", "") != "none" else [None]
     ms = {m: [] for m in modes}
     cs = {}
     for rnd in range(5):
