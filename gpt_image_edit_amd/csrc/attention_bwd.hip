@@ -38,6 +38,13 @@ constexpr int CBLK = 64;                        // columns per tile
 constexpr int IMG = CBLK * HD * 2;              // one LDS image of a tile: 16 KiB
 constexpr int STAGE_BYTES = 2 * IMG + 512;      // image 0 | image 1 | lse[64] dsum[64]
 constexpr int STAGES = 3, PF = STAGES - 1;
+#ifndef FK_BWD_AHEAD
+#define FK_BWD_AHEAD 2
+#endif
+#ifndef FK_BWD_PRIO
+#define FK_BWD_PRIO 1
+#endif
+constexpr int AH = FK_BWD_AHEAD;                // operand fragments are read AH MFMAs ahead of their use (AH <= 4: d blocks of one step)
 constexpr int PBUF_BYTES = 4 * 2 * 4096;        // dK+dV kernel: per wave pair, two tiles of packed p (2 halves x 2 steps x 64 lanes x 16 B)
 enum { MODE_DQ = 0, MODE_DV = 1, MODE_DK = 2 };
 
@@ -121,7 +128,8 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
     if constexpr (HAS_C) {
       const bf16_t* yp = X2.p + (int64_t)b * X2.bs + (int64_t)h * X2.hs + (int64_t)rowc * X2.ld + 8 * hh;
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) x2f[kk] = *(const bf16x8_t*)(yp + 16 * kk);
+      for (int kk = 0; kk < 8; ++kk)   // NEGATED: the dp product accumulates D - dO V^T (dQ: D - V dO^T) on top of D, see below
+        x2f[kk] = __builtin_bit_cast(bf16x8_t, __builtin_bit_cast(u32x4_t, *(const bf16x8_t*)(yp + 16 * kk)) ^ 0x80008000u);
     }
   }
   float lse_l = 0.f, d_l = 0.f;
@@ -129,6 +137,9 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
     lse_l = p.lse[(int64_t)bh * p.S + rowc];
     d_l = p.dsum[(int64_t)bh * p.S + rowc];
   }
+  f32x16_t dini;   // dQ pass: the dp accumulator's start, D of this lane's row in all 16 elements
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dini[r] = d_l;
 
   // ---- LDS-DMA of the streamed tiles: piece = 4 rows x 256 B, lane -> (row = lane / 16, 16-byte slot = lane % 16) ---
   const int prow = lane >> 4, pslot = lane & 15;
@@ -218,36 +229,46 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
       // in attention_fwd.hip: left alone, hipcc issues every ds_read right in front of its MFMA and the wave sits out an
       // LDS round trip 48 times per tile.  Same products in the same order: results are unchanged bit for bit.
       f32x16_t s, dp;
-      auto product = [&](f32x16_t& out, int img, const bf16x8_t (&xf)[8]) {
-        bf16x8_t kf[3];
-        kf[0] = rowfrag(sb, img, kb, 0);
-        kf[1] = rowfrag(sb, img, kb, 1);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      auto product = [&](f32x16_t& out, int img, const bf16x8_t (&xf)[8], const f32x16_t& init) {
+        bf16x8_t kf[AH + 1];
+#pragma unroll
+        for (int a = 0; a < AH; ++a) kf[a] = rowfrag(sb, img, kb, a);
+        __builtin_amdgcn_sched_group_barrier(0x100, AH, 0);
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
-          if (kk + 2 < 8) kf[(kk + 2) % 3] = rowfrag(sb, img, kb, kk + 2);
-          out = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk % 3], xf[kk], kk == 0 ? f32x16_t{} : out, 0, 0, 0);
+          if (kk + AH < 8) kf[(kk + AH) % (AH + 1)] = rowfrag(sb, img, kb, kk + AH);
+          out = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk % (AH + 1)], xf[kk], kk == 0 ? init : out, 0, 0, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
       };
-      product(s, 0, x1f);
-      if constexpr (HAS_C) product(dp, 1, x2f);
+      product(s, 0, x1f, f32x16_t{});
+      // dp: the accumulator STARTS at D (of the row: dQ pass; of the streamed columns: dK pass) and the stationary operand is
+      // negated, so the product delivers D - dP and the elementwise stage is one multiply; the sign joins the scale at the store
+      if constexpr (MODE == MODE_DQ) product(dp, 1, x2f, dini);
+      if constexpr (MODE == MODE_DK) {
+        f32x16_t dcol;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4_t dv = *(const f32x4_t*)(sb + 2 * IMG + 256 + (32 * kb + 8 * g + 4 * hh) * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dcol[4 * g + j] = dv[j];
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        product(dp, 1, x2f, dcol);
+      }
       // ---- elementwise: w = p (DV) or p (dp - D) scale (DQ, DK), p = exp2(s c' - lse) <= 1 -------------------------
       float w[16];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        f32x4_t lv = {lse_l, lse_l, lse_l, lse_l}, dv = {d_l, d_l, d_l, d_l};
-        if constexpr (COL_STATS) {
-          lv = *(const f32x4_t*)(sb + 2 * IMG + (32 * kb + 8 * g + 4 * hh) * 4);
-          if constexpr (MODE == MODE_DK) dv = *(const f32x4_t*)(sb + 2 * IMG + 256 + (32 * kb + 8 * g + 4 * hh) * 4);
-        }
+        f32x4_t lv = {lse_l, lse_l, lse_l, lse_l};
+        if constexpr (COL_STATS) lv = *(const f32x4_t*)(sb + 2 * IMG + (32 * kb + 8 * g + 4 * hh) * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g + j;
           const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, -lv[j]));
           float wv = pr;
-          if constexpr (HAS_C) wv = pr * (dp[r] - dv[j]);   // the softmax scale multiplies the accumulator at the store
+          if constexpr (HAS_C) wv = pr * dp[r];   // = -p (dP - D); sign and softmax scale multiply the accumulator at the store
           if constexpr (MASK)
             if (t * CBLK + 32 * kb + 8 * g + 4 * hh + j >= p.S) wv = 0.f;
           w[r] = wv;
@@ -263,15 +284,15 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
         pfs[step] = __builtin_bit_cast(bf16x8_t, pw);
       }
       {
-        bf16x8_t tf[3];
-        tf[0] = trfrag(sb, 2 * kb, 0);
-        tf[1] = trfrag(sb, 2 * kb, 1);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // two transpose reads per fragment
+        bf16x8_t tf[AH + 1];
+#pragma unroll
+        for (int a = 0; a < AH; ++a) tf[a] = trfrag(sb, 2 * kb, a);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * AH, 0);   // two transpose reads per fragment
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int df = i & 3;
-          if (i + 2 < 8) tf[(i + 2) % 3] = trfrag(sb, 2 * kb + ((i + 2) >> 2), (i + 2) & 3);
-          acc[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[i % 3], pfs[i >> 2], acc[df], 0, 0, 0);
+          if (i + AH < 8) tf[(i + AH) % (AH + 1)] = trfrag(sb, 2 * kb + ((i + AH) >> 2), (i + AH) & 3);
+          acc[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[i % (AH + 1)], pfs[i >> 2], acc[df], 0, 0, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
@@ -295,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
 
   // ---- store: lane (row = ql) holds d = 32 df + 8 g + 4 hh + (0..3) ------------------------------------------------
   if (row < p.S) {
-    const float osc = HAS_C ? p.scale : 1.f;   // dQ, dK: the softmax scale left out of w
+    const float osc = HAS_C ? -p.scale : 1.f;   // dQ, dK: the sign and the softmax scale left out of w
     bf16_t* op = p.out + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs + (int64_t)row * p.o_ld + 4 * hh;
 #pragma unroll
     for (int df = 0; df < 4; ++df)
@@ -342,8 +363,10 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
   {
     const bf16_t* xb = producer ? p.k.p + (int64_t)b * p.k.bs + (int64_t)h * p.k.hs + (int64_t)rowc * p.k.ld
                                 : p.v.p + (int64_t)b * p.v.bs + (int64_t)h * p.v.hs + (int64_t)rowc * p.v.ld;
+    const uint32_t sgn = producer ? 0u : 0x80008000u;   // the consumer's V is NEGATED: its product delivers D - dP (below)
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) xf[kk] = *(const bf16x8_t*)(xb + 8 * hh + 16 * kk);
+    for (int kk = 0; kk < 8; ++kk)
+      xf[kk] = __builtin_bit_cast(bf16x8_t, __builtin_bit_cast(u32x4_t, *(const bf16x8_t*)(xb + 8 * hh + 16 * kk)) ^ sgn);
   }
 
   // ---- LDS-DMA of the query tiles: image 0 = Q, image 1 = dO, then lse and D of the 64 queries ------------------------
@@ -412,30 +435,30 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
     for (int r = 0; r < 16; ++r) acc[df][r] = 0.f;
 
   // one 32 x 32 tile product against the stationary rows, operand reads pinned two MFMAs ahead (attention_bwd_kernel)
-  auto product = [&](f32x16_t& out, const char* sb, int img, int kb) {
-    bf16x8_t kf[3];
-    kf[0] = rowfrag(sb, img, kb, 0);
-    kf[1] = rowfrag(sb, img, kb, 1);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+  auto product = [&](f32x16_t& out, const char* sb, int img, int kb, const f32x16_t& init) {
+    bf16x8_t kf[AH + 1];
+#pragma unroll
+    for (int a = 0; a < AH; ++a) kf[a] = rowfrag(sb, img, kb, a);
+    __builtin_amdgcn_sched_group_barrier(0x100, AH, 0);
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      if (kk + 2 < 8) kf[(kk + 2) % 3] = rowfrag(sb, img, kb, kk + 2);
-      out = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk % 3], xf[kk], kk == 0 ? f32x16_t{} : out, 0, 0, 0);
+      if (kk + AH < 8) kf[(kk + AH) % (AH + 1)] = rowfrag(sb, img, kb, kk + AH);
+      out = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk % (AH + 1)], xf[kk], kk == 0 ? init : out, 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
   };
   // acc^T[d][row] += image^T w for the two 16-query steps of half kb
   auto accumulate = [&](const char* sb, int img, int kb, const bf16x8_t (&pf)[2]) {
-    bf16x8_t tf[3];
-    tf[0] = trfrag(sb, img, 2 * kb, 0);
-    tf[1] = trfrag(sb, img, 2 * kb, 1);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    bf16x8_t tf[AH + 1];
+#pragma unroll
+    for (int a = 0; a < AH; ++a) tf[a] = trfrag(sb, img, 2 * kb, a);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * AH, 0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int df = i & 3;
-      if (i + 2 < 8) tf[(i + 2) % 3] = trfrag(sb, img, 2 * kb + ((i + 2) >> 2), (i + 2) & 3);
-      acc[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[i % 3], pf[i >> 2], acc[df], 0, 0, 0);
+      if (i + AH < 8) tf[(i + AH) % (AH + 1)] = trfrag(sb, img, 2 * kb + ((i + AH) >> 2), (i + AH) & 3);
+      acc[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[i % (AH + 1)], pf[i >> 2], acc[df], 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
@@ -458,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16_t s;
-      product(s, sb, 0, kb);
+      product(s, sb, 0, kb, f32x16_t{});
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4_t lv = *(const f32x4_t*)(sb + 2 * IMG + (32 * kb + 8 * g + 4 * hh) * 4);
@@ -480,23 +503,24 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
   auto consumer_plain = [&](const char* sb, const char* pb) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      f32x16_t dp;
-      product(dp, sb, 1, kb);
+      f32x16_t dp;   // starts at D of the 32 queries, accumulates -dO V^T on top: D - dP
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4_t dv = *(const f32x4_t*)(sb + 2 * IMG + 256 + (32 * kb + 8 * g + 4 * hh) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dp[4 * g + j] = dv[j];
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      product(dp, sb, 1, kb, dp);
       bf16x8_t wfs[2];
 #pragma unroll
       for (int step = 0; step < 2; ++step) {
         const u32x4_t pp = __builtin_bit_cast(u32x4_t, *(const bf16x8_t*)(pb + (2 * kb + step) * 1024));
         u32x4_t pw;
 #pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {   // registers 8 step + 4 gg + (0..3) = queries 32 kb + 16 step + 8 gg + 4 hh + (0..3)
-          const f32x4_t dv = *(const f32x4_t*)(sb + 2 * IMG + 256 + (32 * kb + 16 * step + 8 * gg + 4 * hh) * 4);
-#pragma unroll
-          for (int e2 = 0; e2 < 2; ++e2) {
-            const int e = 2 * gg + e2, r = 8 * step + 2 * e;
-            const float w0 = bf_lo(pp[e]) * (dp[r] - dv[2 * e2]);   // the softmax scale multiplies dK at the store
-            const float w1 = bf_hi(pp[e]) * (dp[r + 1] - dv[2 * e2 + 1]);
-            pw[e] = pack_bf2(w0, w1);
-          }
+        for (int e = 0; e < 4; ++e) {   // = -p (dP - D); sign and softmax scale multiply dK at the store
+          const int r = 8 * step + 2 * e;
+          pw[e] = pack_bf2(bf_lo(pp[e]) * dp[r], bf_hi(pp[e]) * dp[r + 1]);
         }
         wfs[step] = __builtin_bit_cast(bf16x8_t, pw);
       }
@@ -506,7 +530,11 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
 
   char* const pbuf = smem + STAGES * STAGE_BYTES + pair * 8192 + lane * 16;
   issue_tile(0, 0);
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // as in attention_bwd_kernel
+#if FK_BWD_PRIO == 1
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // as in attention_bwd_kernel: the consumers
+#elif FK_BWD_PRIO == 2
+  if (wave < 4) __builtin_amdgcn_s_setprio(1);    // the producers
+#endif
 
   // Iteration i = 0 .. nt of BOTH roles: wait for the own DMA pieces of tile i and the own p stores of tile i - 1, meet,
   // start the DMA of tile i + 1 into the stage the consumers left in iteration i - 1.  The roles run separate loops (one
@@ -551,7 +579,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
     bf16_t* op = producer ? p.out2 + (int64_t)b * p.o2_bs + (int64_t)h * p.o2_hs + (int64_t)row * p.o2_ld
                           : p.out + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs + (int64_t)row * p.o_ld;
     op += 4 * hh;
-    const float osc = producer ? 1.f : p.scale;   // dK: the softmax scale left out of w
+    const float osc = producer ? 1.f : -p.scale;   // dK: the sign and the softmax scale left out of w
 #pragma unroll
     for (int df = 0; df < 4; ++df)
 #pragma unroll
