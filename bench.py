@@ -344,6 +344,7 @@ def train_step_bench(device, steps=3, warmup=1, world=1):
     t0 = time.perf_counter()
     for _ in range(steps):
         out = ts.step(**batch)
+    t_host = (time.perf_counter() - t0) / steps      # the host is done enqueueing; the GPU may still be working
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -354,7 +355,7 @@ def train_step_bench(device, steps=3, warmup=1, world=1):
     fwd = flops_forward(S)
     return {"value": B * world / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "n_gpus": world, "steps": steps, "warmup": warmup,
             "loss": float(out["loss"].item()), "trainable_params": n_train, "seq_len": S,
-            "peak_memory_gb": torch.cuda.max_memory_allocated(device) / 1e9,
+            "peak_memory_gb": torch.cuda.max_memory_allocated(device) / 1e9, "host_enqueue_ms_per_step": t_host * 1e3,
             "zero2_buckets": len(ts.opt.layout.buckets),
             "forward_tflop": fwd / 1e12,
             "model_tflops_3x_forward": 3 * fwd / dt / 1e12,

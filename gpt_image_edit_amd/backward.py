@@ -24,6 +24,7 @@ Token reductions are fixed-order two-stage sums and the attention backward uses 
 from run to run.  Weight gradients are bf16 (what autograd produces for bf16 parameters); bias, norm-weight and
 modulation reductions stay fp32 (``fk_adamw_step`` takes either).
 """
+import os
 from types import SimpleNamespace
 
 import torch
@@ -31,6 +32,11 @@ import torch
 from . import ops
 
 BF16 = torch.bfloat16
+# K-major GEMM operands (fk_gemm_args.layout 1 / 2): gradients read weights and activations as they lie in memory instead of
+# physically transposed copies (same results bit for bit).  FK_BWD_K_MAJOR: 0 = copies everywhere, 1 = weight gradients read
+# dY and X token-major (layout 2), 2 = data gradients read the stored weight as well (layout 1: no W^T copies, 24 GB less
+# at the cost of a slower operand path -- DESIGN.md section 4a).
+K_MAJOR = int(os.environ.get("FK_BWD_K_MAJOR", "1"))
 
 
 def _pad64(n):
@@ -38,11 +44,15 @@ def _pad64(n):
 
 
 def wgrad(buf, dy, x, out=None):
-    """Weight gradient dW[N, K] = dY^T X over the rows of two [B, R, *] views: both operands transposed into K-major
-    buffers whose row count is padded to the GEMM's 64 (pad columns zeroed on every call), then one fk_gemm_bf16.
+    """Weight gradient dW[N, K] = dY^T X over the rows of two [B, R, *] views: one fk_gemm_bf16 on the views themselves
+    (layout 2) when the shapes allow (whole 256 x 256 tiles, a multiple of 64 tokens, uniformly strided rows); else both
+    operands transposed into K-major buffers whose row count is padded to the GEMM's 64 (pad columns zeroed on every call).
     ``buf(name, shape, zero=...)`` hands out the caller's cached workspace tensors."""
     B, R, N = dy.shape
     K = x.shape[-1]
+    uniform = B == 1 or (dy.stride(0) == R * dy.stride(1) and x.stride(0) == R * x.stride(1))
+    if K_MAJOR >= 1 and N % 256 == 0 and K % 256 == 0 and (B * R) % 64 == 0 and uniform:
+        return ops.gemm(dy, x, out=out, layout=2)      # both operands token-major, as the forward left them
     Mp = _pad64(B * R)
     dyT = buf(f"dyT{N}x{Mp}", (N, Mp), zero=True)
     xT = buf(f"xT{K}x{Mp}", (K, Mp), zero=True)
@@ -76,6 +86,8 @@ class FluxBackward:
             raise NotImplementedError(
                 "FluxBackward has no weight gradient for " + ", ".join(unsupported[:6]) + (" ..." if len(unsupported) > 6 else "")
                 + ": trainable parameters must belong to transformer_blocks.* / single_transformer_blocks.*")
+        if not model._train_packs:     # from now on the model fuses nothing an optimiser rewrites (transformer.pack_weights)
+            model._train_packs, model._packed = True, None
         self._wT = {}          # name -> (W^T (bf16 [in, out]) for the data gradients, stamp of its source)
         self._buf = {}
         self._saved = None
@@ -104,6 +116,26 @@ class FluxBackward:
     def _packedT(self, key, w, pk):
         return self._transposed("packed:" + key, w, stamp=("pack", pk.serial))
 
+    # ---- operands of the data gradient dX = dY W ------------------------------------------------------------------------
+    @staticmethod
+    def _k_major_ok(w):
+        """fk_gemm_args.layout 1 takes the weight [out, in] as stored: in % 256 == 0, out % 64 == 0 (every MMDiT linear)."""
+        return K_MAJOR >= 2 and w.shape[1] % 256 == 0 and w.shape[0] % 64 == 0 and w.stride(1) == 1
+
+    def dW(self, name, cols=None):
+        """``w=, layout=`` of the GEMM that carries a gradient back through the linear ``name`` (``cols``: only these input
+        columns of it): the stored weight itself when the K-major path takes it, else its cached transpose."""
+        w = self.m.p(name).data
+        w = w if cols is None else w[:, cols]
+        if self._k_major_ok(w):
+            return dict(w=w, layout=1)
+        wt = self.wT(name)
+        return dict(w=wt if cols is None else wt[cols], layout=0)
+
+    def dWp(self, key, w, pk):
+        """The same for a fused operand of the model's packs (QKV)."""
+        return dict(w=w, layout=1) if self._k_major_ok(w) else dict(w=self._packedT(key, w, pk), layout=0)
+
     def refresh(self):
         """After an optimiser step through libfk (``fk_adamw_step`` rewrites the bf16 parameters through raw pointers,
         which torch's version counters do not see): invalidate the transposes of the trainable weights and the model's
@@ -111,7 +143,7 @@ class FluxBackward:
         for k, (t, _) in list(self._wT.items()):
             if k in self.trainable or k.startswith("packed:"):
                 self._wT[k] = (t, None)
-        self.m._packed = None
+        self.m.repack(self.trainable)
 
     # ---- buffers ---------------------------------------------------------------------------------------------------
     def _b(self, name, shape, dtype=BF16, zero=False):
@@ -278,7 +310,7 @@ class FluxBackward:
         dmod_out = self._b("dmod_out", (B, 2 * D), torch.float32)
         # head: sample = proj_out(LN(h) (1 + scale) + shift); AdaLayerNormContinuous and proj_out are frozen
         dn = self._b("dn", (B, S, D))
-        ops.gemm(dsample.to(BF16).contiguous(), self.wT("proj_out.weight"), out=dn[:, S_txt:])
+        ops.gemm(dsample.to(BF16).contiguous(), out=dn[:, S_txt:], **self.dW("proj_out.weight"))
         ops.ln_modulate_bwd(sv.ckpt[nd + ns][:, S_txt:], dn[:, S_txt:], mod[:, pk.mod_out: pk.mod_out + D], g[:, S_txt:], dmod_out)
         s = ws.s
 
@@ -302,7 +334,7 @@ class FluxBackward:
             bg = {}
             self._double_backward(i, sv, g, bg)
             emit(bg)
-        d_enc = ops.gemm(g[:, :S_txt], self.wT("context_embedder.weight"))
+        d_enc = ops.gemm(g[:, :S_txt], **self.dW("context_embedder.weight"))
         self._saved = None
         return grads, d_enc
 
@@ -331,23 +363,23 @@ class FluxBackward:
                 if p + f"{ff}.net.2.weight" in T:
                     grads[p + f"{ff}.net.2.weight"] = self._wgrad(dy[:, sl], ws.ff[:, sl])
                     grads[p + f"{ff}.net.2.bias"] = ops.colsum(dy[:, sl])
-        ops.gemm_grouped([dict(a=dy[:, img], w=self.wT(p + "ff.net.2.weight"), out=dff[:, img]),
-                          dict(a=dy[:, txt], w=self.wT(p + "ff_context.net.2.weight"), out=dff[:, txt])])
+        ops.gemm_grouped([dict(a=dy[:, img], out=dff[:, img], **self.dW(p + "ff.net.2.weight")),
+                          dict(a=dy[:, txt], out=dff[:, txt], **self.dW(p + "ff_context.net.2.weight"))])
         ops.gelu_bwd(h1, dff, out=dff)
         for ff, sl in ffs:
             if p + f"{ff}.net.0.proj.weight" in T:
                 grads[p + f"{ff}.net.0.proj.weight"] = self._wgrad(dff[:, sl], n2[:, sl])
                 grads[p + f"{ff}.net.0.proj.bias"] = ops.colsum(dff[:, sl])
-        ops.gemm_grouped([dict(a=dff[:, img], w=self.wT(p + "ff.net.0.proj.weight"), out=dn[:, img]),
-                          dict(a=dff[:, txt], w=self.wT(p + "ff_context.net.0.proj.weight"), out=dn[:, txt])])
+        ops.gemm_grouped([dict(a=dff[:, img], out=dn[:, img], **self.dW(p + "ff.net.0.proj.weight")),
+                          dict(a=dff[:, txt], out=dn[:, txt], **self.dW(p + "ff_context.net.0.proj.weight"))])
         ops.ln_modulate_bwd(x1[:, img], dn[:, img], ch(mi, 4), g[:, img], dm_i[:, 3 * D:5 * D], dx_in=g[:, img])
         ops.ln_modulate_bwd(x1[:, txt], dn[:, txt], ch(mt, 4), g[:, txt], dm_t[:, 3 * D:5 * D], dx_in=g[:, txt])
         # -- attention output projection: x1 = x0 + gate_msa * y1
         ops.gate_res_bwd(g[:, img], y1[:, img], ch(mi, 2), dy[:, img], dm_i[:, 2 * D:3 * D])
         ops.gate_res_bwd(g[:, txt], y1[:, txt], ch(mt, 2), dy[:, txt], dm_t[:, 2 * D:3 * D])
         do = self._b("do", (B, S, D))
-        ops.gemm_grouped([dict(a=dy[:, img], w=self.wT(p + "attn.to_out.0.weight"), out=do[:, img]),
-                          dict(a=dy[:, txt], w=self.wT(p + "attn.to_add_out.weight"), out=do[:, txt])])
+        ops.gemm_grouped([dict(a=dy[:, img], out=do[:, img], **self.dW(p + "attn.to_out.0.weight")),
+                          dict(a=dy[:, txt], out=do[:, txt], **self.dW(p + "attn.to_add_out.weight"))])
         o, lse = sv.o_ckpt[i], sv.lse_ckpt[i]
         if p + "attn.to_out.0.weight" in self.trainable:
             grads[p + "attn.to_out.0.weight"] = self._wgrad(dy[:, img], o[:, img])     # ops.gemm hands out a fresh tensor
@@ -365,8 +397,8 @@ class FluxBackward:
         # views of this call's own fresh [2, 2, 128] result: nothing to clone
         grads[p + "attn.norm_q.weight"], grads[p + "attn.norm_k.weight"] = dw[0, 0], dw[1, 0]
         grads[p + "attn.norm_added_q.weight"], grads[p + "attn.norm_added_k.weight"] = dw[0, 1], dw[1, 1]
-        ops.gemm_grouped([dict(a=dqkv[:, img], w=self._packedT(p + "qkv_img", blk.wqkv_img, pk), out=dn[:, img]),
-                          dict(a=dqkv[:, txt], w=self._packedT(p + "qkv_txt", blk.wqkv_txt, pk), out=dn[:, txt])])
+        ops.gemm_grouped([dict(a=dqkv[:, img], out=dn[:, img], **self.dWp(p + "qkv_img", blk.wqkv_img, pk)),
+                          dict(a=dqkv[:, txt], out=dn[:, txt], **self.dWp(p + "qkv_txt", blk.wqkv_txt, pk))])
         if p + "attn.to_q.weight" in self.trainable:
             dwqkv = self._wgrad(dqkv[:, img], n1[:, img])
             dbqkv = ops.colsum(dqkv[:, img])
@@ -418,9 +450,9 @@ class FluxBackward:
         dn = self._b("dn", (B, S, D))
         # x' = x + gate * y, y = proj_out([attn | gelu(mlp)])
         ops.gate_res_bwd(g, y1, ch(2), dy, dmod[:, 2 * D:3 * D])
-        woT = self.wT(p + "proj_out.weight")                       # [5D, D]: rows [0, D) -> attention, [D, 5D) -> MLP
-        ops.gemm(dy, woT[:D], out=do)
-        ops.gemm(dy, woT[D:], out=dff)
+        # proj_out [D, 5D]: input columns [0, D) -> attention, [D, 5D) -> MLP
+        ops.gemm(dy, out=do, **self.dW(p + "proj_out.weight", slice(0, D)))
+        ops.gemm(dy, out=dff, **self.dW(p + "proj_out.weight", slice(D, 5 * D)))
         ops.gelu_bwd(h1, dff, out=dff)
         dqkv = self._b("dqkv", (B, S, 3 * D))
         dq, dk = self._b("dq", (B, H, S, 128)), self._b("dk", (B, H, S, 128))
@@ -430,8 +462,8 @@ class FluxBackward:
         dw = ops.qkv_post_bwd(dq, dk, bb.qkv, dqkv, P(p + "attn.norm_q.weight"), P(p + "attn.norm_k.weight"), None, None,
                               sv.cos, sv.sin, 0)
         grads[p + "attn.norm_q.weight"], grads[p + "attn.norm_k.weight"] = dw[0, 0], dw[1, 0]
-        ops.gemm(dqkv, self._packedT(p + "qkv", blk.wqkv, pk), out=dn)
-        ops.gemm(dff, self.wT(p + "proj_mlp.weight"), out=dn, epilogue=ops.FK_EPI_RES, res=dn)
+        ops.gemm(dqkv, out=dn, **self.dWp(p + "qkv", blk.wqkv, pk))
+        ops.gemm(dff, out=dn, epilogue=ops.FK_EPI_RES, res=dn, **self.dW(p + "proj_mlp.weight"))
         if p + "attn.to_q.weight" in self.trainable:
             dwqkv = self._wgrad(dqkv, n1)
             dbqkv = ops.colsum(dqkv)

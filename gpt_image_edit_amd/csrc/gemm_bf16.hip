@@ -354,6 +354,15 @@ extern "C" int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const int rc = validate_gemm(p);
   if (rc != FK_OK) return rc;
+  if (p.layout != 0) {   // K-major operands: the 256 x 256 ping-pong kernel only (it reports what it cannot take)
+    FK_CHECK_ARG(!p.out_fp32, "fk_gemm_bf16: layout %d has bf16 output only", p.layout);
+    const int rc2 = fk_gemm2_launch(&p, 1, 0, stream);
+    if (rc2 == FK_E2BIG_STRIDES) {
+      fk_set_error("fk_gemm_bf16: layout %d needs row strides that keep a 256-row tile within 2 GiB", p.layout);
+      return FK_EUNSUPPORTED;
+    }
+    return rc2;
+  }
   if (p.out_fp32) {
     switch (p.epilogue) {
       case FK_EPI_NONE: return launch<FK_EPI_NONE, true>(p, stream);
@@ -392,6 +401,14 @@ extern "C" int fk_gemm_bf16_grouped(const fk_gemm_args* args, int32_t n, fk_stre
   }
   hipStream_t stream = (hipStream_t)stream_;
   int rc2 = FK_E2BIG_STRIDES;
+  if (args[0].layout != 0) {
+    rc2 = fk_gemm2_launch(args, n, 0, stream);
+    if (rc2 == FK_E2BIG_STRIDES) {
+      fk_set_error("fk_gemm_bf16_grouped: layout %d needs row strides that keep a 256-row tile within 2 GiB", args[0].layout);
+      return FK_EUNSUPPORTED;
+    }
+    return rc2;
+  }
   if (gemm_impl_override() != 1 || args[0].epilogue == FK_EPI_QKV) {
     rc2 = fk_gemm2_launch(args, n, gemm_bn_override(), stream);
     if (rc2 != FK_E2BIG_STRIDES) return rc2;

@@ -64,6 +64,11 @@ struct GroupArgs {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+FK_DEV s16x4_t lds_tr16(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+}
+
 // buffer form of the LDS-DMA load.  The builtin exists for the device target only; seen by the host pass it silently
 // suppresses the kernel's host stub.
 FK_DEV void buffer_lds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset, int soffset) {
@@ -389,9 +394,19 @@ struct Cfg8 {
 
 // sk_half < 0: the whole K range.  sk_half = 0 / 1 (split-K launch): this workgroup multiplies K-tiles
 // [sk_half * nk, (sk_half + 1) * nk), nk = K / 128, and meets its partner through workspace slot sk_slot (below).
-template <int EPI, int BN>
+//
+// LAY (fk_gemm_args.layout) -- the backward pass's operands as they lie in memory, no transposed copies:
+//   0  A [M, K], W [N, K]                 (K contiguous in both: the forward)
+//   1  A [M, K], W [K, N]                 data gradient dX = dY W: the weight as stored
+//   2  A [K, M], W [K, N]                 weight gradient dW = dY^T X: both operands token-major
+// A K-major operand's half-tile is staged as 64 k-rows x 128 columns (256-byte rows, the 64-byte block b of row r at
+// block b ^ (r & 3)) and its MFMA fragments come through ds_read_b64_tr_b16 -- two reads of rows 8 hh + tj and + 4, which
+// deliver k = 8 hh + 0..7 in the slot order of the ds_read_b128 path, so a K-major operand multiplies a row-major one and
+// the sums are those of the LAY 0 kernel on transposed copies bit for bit (attention_fwd.hip's V^T operand is the recipe).
+template <int EPI, int BN, int LAY = 0>
 FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, int sk_half, int sk_slot) {
   using C = Cfg8<BN>;
+  constexpr bool AT = LAY == 2, WT = LAY >= 1;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -403,32 +418,39 @@ FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, 
   // ---- LDS-DMA sources: piece = 8 rows x 128 B, lane -> (row, slot), source chunk = slot ^ swz(row).
   // Wave w requests pieces 2w and 2w + 1 of every half-tile.
   const int lrow = lane >> 3, slot = lane & 7;
-  const __amdgpu_buffer_rsrc_t rs_a =
-      __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.A + fk_row_offset(p.a, m0)), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w =
-      __builtin_amdgcn_make_buffer_rsrc((void*)((const bf16_t*)p.W + (int64_t)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
+  const int prow = lane >> 4, pslot = lane & 15;   // K-major operands: piece = 4 k-rows x 256 B, lane -> (row, 16-byte chunk)
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const bf16_t*)p.A + (AT ? (int64_t)m0 : fk_row_offset(p.a, m0))), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const bf16_t*)p.W + (WT ? (int64_t)n0 : (int64_t)n0 * p.ldw)), 0, 0x7fffffff, 0x00020000);
   int a_voff[2][2], w_voff[2][2];   // [half][piece]
   {
     const TileRows arow(p.a, m0);
-    const int ldw2 = (int)p.ldw * 2;
+    const int ldw2 = (int)p.ldw * 2, lda2 = (int)p.a.ld * 2;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int rl = h * 128 + (wave * 2 + j) * 8 + lrow;   // row inside the 256-row tile
         const int sw = (slot ^ C::swz(rl)) << 4;
-        a_voff[h][j] = arow.off(min(rl, p.M - 1 - m0)) * 2 + sw;
-        w_voff[h][j] = min(rl, p.N - 1 - n0) * ldw2 + sw;
+        // K-major: k-row kl of the K-tile, logical 16-byte chunk of the half's 128 columns behind physical chunk pslot
+        const int kl = (wave * 2 + j) * 4 + prow;
+        const int ct = (h * 128 + (((((pslot >> 2) ^ prow) << 2) | (pslot & 3)) << 3)) * 2;
+        a_voff[h][j] = AT ? kl * lda2 + ct : arow.off(min(rl, p.M - 1 - m0)) * 2 + sw;
+        w_voff[h][j] = WT ? kl * ldw2 + ct : min(rl, p.N - 1 - n0) * ldw2 + sw;
       }
   }
   // which: 0 = A0, 1 = A1, 2 = W0, 3 = W1; kt is clamped (surplus requests are never read)
+  const int kstep_a = AT ? C::BK * (int)p.a.ld * 2 : C::BK * 2, kstep_w = WT ? C::BK * (int)p.ldw * 2 : C::BK * 2;
   auto dma_half = [&](int which, int buf, int kt) {
-    const int koff = kbase + min(kt, nk - 1) * (C::BK * 2);
+    const int ktc = min(kt, nk - 1);
     char* dst = smem + buf * C::BUF_BYTES + which * C::HALF_BYTES + wave * 2048;
     if (which < 2) {
+      const int koff = (AT ? 0 : kbase) + ktc * kstep_a;
       buffer_lds16(rs_a, dst, a_voff[which][0], koff);
       buffer_lds16(rs_a, dst + 1024, a_voff[which][1], koff);
     } else {
+      const int koff = (WT ? 0 : kbase) + ktc * kstep_w;
       buffer_lds16(rs_w, dst, w_voff[which - 2][0], koff);
       buffer_lds16(rs_w, dst + 1024, w_voff[which - 2][1], koff);
     }
@@ -451,17 +473,35 @@ FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   bf16x8_t af[2][4], wf[2][4];   // A half in use [sub][kk]; W halves [j][kk]
+  // K-major half-tile: fragment (k-step kk, 32-column block df) through two transpose reads
+  const int tj = (lane & 15) >> 2;
+  const int t_lo = (8 * fhalf + tj) * 256 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+  auto trfrag = [&](const char* half, int kk, int df) {
+    const char* vp = half + kk * 4096 + ((df ^ tj) << 6) + t_lo;
+    const s16x4_t lo = lds_tr16(vp);
+    const s16x4_t hi = lds_tr16(vp + 4 * 256);
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+  };
   auto read_a = [&](int buf, int h) {
-    const char* b = smem + buf * C::BUF_BYTES + h * C::HALF_BYTES + a_rd;
+    const char* b = smem + buf * C::BUF_BYTES + h * C::HALF_BYTES;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) af[sub][kk] = *(const bf16x8_t*)(b + sub * 4096 + koffs[kk]);
+      for (int kk = 0; kk < 4; ++kk) {
+        if constexpr (AT) af[sub][kk] = trfrag(b, kk, wm * 2 + sub);
+        else af[sub][kk] = *(const bf16x8_t*)(b + a_rd + sub * 4096 + koffs[kk]);
+      }
   };
   auto read_w = [&](int buf, int j) {
-    const char* b = smem + buf * C::BUF_BYTES + (2 + j) * C::HALF_BYTES + w_rd;
+    const char* b = smem + buf * C::BUF_BYTES + (2 + j) * C::HALF_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) wf[j][kk] = *(const bf16x8_t*)(b + koffs[kk]);
+    for (int kk = 0; kk < 4; ++kk) {
+      if constexpr (WT) wf[j][kk] = trfrag(b, kk, wn);
+      else wf[j][kk] = *(const bf16x8_t*)(b + w_rd + koffs[kk]);
+    }
   };
   // quadrant (i, j): 2 m-blocks x 1 n-block x 4 k-steps, accumulators alternating
   auto mma = [&](int i, int j) {
@@ -577,17 +617,17 @@ FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, 
   store_tile<EPI, BN, C>(acc, p, smem, m0, n0, wm, wn);
 }
 
-template <int EPI, int BN, bool SPLITK>
+template <int EPI, int BN, bool SPLITK, int LAY = 0>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int pi, m0, n0;
   const int t = xcd_chunk_index();
   if constexpr (SPLITK) {
     select_tile<BN>(ga, t >> 1, pi, m0, n0);
-    gemm8_body<EPI, BN>(ga, smem, pi, m0, n0, t & 1, t >> 1);
+    gemm8_body<EPI, BN, LAY>(ga, smem, pi, m0, n0, t & 1, t >> 1);
   } else {
     select_tile<BN>(ga, t, pi, m0, n0);
-    gemm8_body<EPI, BN>(ga, smem, pi, m0, n0, -1, 0);
+    gemm8_body<EPI, BN, LAY>(ga, smem, pi, m0, n0, -1, 0);
   }
 }
 
@@ -602,10 +642,10 @@ int count_tiles(GroupArgs& ga, const fk_gemm_args* probs, int n) {
   return total;
 }
 
-template <int EPI, int BN, bool SPLITK>
+template <int EPI, int BN, bool SPLITK, int LAY = 0>
 int launch8(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) {
   const int total = count_tiles<BN>(ga, probs, n);
-  auto kern = gemm8_kernel<EPI, BN, SPLITK>;
+  auto kern = gemm8_kernel<EPI, BN, SPLITK, LAY>;
   FK_ENSURE_MAX_LDS(kern, Cfg8<BN>::SMEM_BYTES, "fk_gemm_bf16 (256 x 256 tile, 8 waves ping-pong)");
   hipLaunchKernelGGL(kern, dim3(SPLITK ? 2 * total : total), dim3(512), Cfg8<BN>::SMEM_BYTES, stream, ga);
   FK_CHECK_LAUNCH("fk_gemm_bf16 (256 x 256 tile, 8 waves ping-pong)");
@@ -978,6 +1018,29 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int variant_hint, hipStrea
     }
   }
   if (!ok32) return FK_E2BIG_STRIDES;   // caller falls back to the 128 x 128 kernel (64-bit addressing)
+
+  // K-major operands (layout 1: W [K, N]; layout 2: A [K, M] too): the 256 x 256 kernel only, whole tiles only
+  const int lay = probs[0].layout;
+  if (lay != 0) {
+    for (int i = 0; i < n; ++i) {
+      const fk_gemm_args& q = probs[i];
+      const bool uniform_a = q.a.rows_per_batch <= 0 || q.a.batch_stride == q.a.rows_per_batch * q.a.ld;
+      if (q.layout != lay || q.N % 256 != 0 || q.K % 64 != 0 || q.ldw % 8 != 0 || (int64_t)q.K * q.ldw * 2 >= (1ll << 31) ||
+          (lay == 2 && (q.M % 256 != 0 || !uniform_a || q.a.ld % 8 != 0 || (int64_t)q.K * q.a.ld * 2 >= (1ll << 31))) ||
+          (q.epilogue != FK_EPI_NONE && !(lay == 1 && q.epilogue == FK_EPI_RES))) {
+        fk_set_error("fk_gemm_bf16: layout %d needs N %% 256 == 0, K %% 64 == 0%s, epilogue none%s and operands below 2 GiB "
+                     "(M %d N %d K %d epilogue %d)", lay, lay == 2 ? ", M % 256 == 0, uniformly strided A rows" : "",
+                     lay == 1 ? " / residual" : "", q.M, q.N, q.K, q.epilogue);
+        return FK_EUNSUPPORTED;
+      }
+    }
+    g_last_variant = 256;
+    if (lay == 1 && probs[0].epilogue == FK_EPI_RES) return launch8<FK_EPI_RES, 256, false, 1>(ga, probs, n, stream);
+    if (lay == 1) return launch8<FK_EPI_NONE, 256, false, 1>(ga, probs, n, stream);
+    if (lay == 2) return launch8<FK_EPI_NONE, 256, false, 2>(ga, probs, n, stream);
+    fk_set_error("fk_gemm_bf16: unknown layout %d", lay);
+    return FK_EUNSUPPORTED;
+  }
 
   // split-K workspace (optional, caller-owned): slots x 256 KiB of fp32 partial tiles, then slots x 2 control words
   const int ws_slots = probs[0].splitk_ws ? probs[0].splitk_slots : 0;

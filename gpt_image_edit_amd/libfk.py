@@ -32,7 +32,7 @@ class GemmArgs(ctypes.Structure):
         ("M", c_i32), ("N", c_i32), ("K", c_i32),
         ("epilogue", c_i32), ("out_fp32", c_i32), ("alpha", c_f32),
         ("q_out", c_vp), ("k_out", c_vp), ("wq", c_vp), ("wk", c_vp), ("rope_cs", c_vp), ("splitk_ws", c_vp),
-        ("qkv_s_offset", c_i32), ("qkv_s_total", c_i32), ("qkv_heads", c_i32), ("splitk_slots", c_i32),
+        ("qkv_s_offset", c_i32), ("qkv_s_total", c_i32), ("qkv_heads", c_i32), ("splitk_slots", c_i32), ("layout", c_i32), ("reserved0", c_i32),
     ]
 
 

@@ -67,23 +67,42 @@ def splitk_workspace(device):
     return ws, SPLITK_SLOTS
 
 
-def _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv=None):
+def _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv=None, layout=0):
     _need_cuda(a, w, bias, out, res, gate)
-    M, ra = rows_of(a)
-    N, K = w.shape
-    if a.shape[-1] != K:
-        raise ValueError(f"K mismatch: a {tuple(a.shape)} vs w {tuple(w.shape)}")
     if a.dtype != BF16 or w.dtype != BF16:
         raise TypeError("fk_gemm_bf16 takes bf16 operands")
+    if layout == 0:
+        M, ra = rows_of(a)
+        N, K = w.shape
+        if a.shape[-1] != K:
+            raise ValueError(f"K mismatch: a {tuple(a.shape)} vs w {tuple(w.shape)}")
+        out_shape = (*a.shape[:-1], N)
+    elif layout == 1:     # w is [K, N]: out = a @ w
+        M, ra = rows_of(a)
+        K, N = w.shape
+        if a.shape[-1] != K or w.stride(1) != 1:
+            raise ValueError(f"layout 1: a {tuple(a.shape)} @ w {tuple(w.shape)} (w rows contiguous)")
+        out_shape = (*a.shape[:-1], N)
+    elif layout == 2:     # a is [K, M] (or [B, R, M] rows = K), w is [K, N]: out = a^T @ w
+        a = a[0] if a.dim() == 3 and a.shape[0] == 1 else a      # one batch: any batch stride
+        w = w[0] if w.dim() == 3 and w.shape[0] == 1 else w
+        K, ra = rows_of(a)
+        M, N = a.shape[-1], w.shape[-1]
+        Kw, rw = rows_of(w)
+        if Kw != K or w.stride(-1) != 1 or (rw.rows_per_batch > 0 and rw.batch_stride != rw.rows_per_batch * rw.ld):
+            raise ValueError(f"layout 2: a {tuple(a.shape)} ^T @ w {tuple(w.shape)} (uniformly strided w rows)")
+        out_shape = (M, N)
+    else:
+        raise ValueError(f"layout {layout}")
     if out is None:
-        shape = (*a.shape[:-1], N)
-        out = torch.empty(shape, device=a.device, dtype=torch.float32 if out_fp32 else BF16)
+        out = torch.empty(out_shape, device=a.device, dtype=torch.float32 if out_fp32 else BF16)
     Mo, rc = rows_of(out)
     if Mo != M or out.shape[-1] != N:
         raise ValueError(f"output shape {tuple(out.shape)} does not match M={M}, N={N}")
     args = GemmArgs()
+    args.layout = layout
     args.A, args.a = a.data_ptr(), ra
-    args.W, args.ldw = w.data_ptr(), w.stride(0)
+    args.W, args.ldw = w.data_ptr(), (w.stride(0) if layout != 2 else rw.ld)
     args.bias = bias.data_ptr() if bias is not None else None
     args.C, args.c = out.data_ptr(), rc
     if res is not None:
@@ -99,7 +118,7 @@ def _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv=None):
         args.gate_rows_per_batch = a.shape[1]
     args.M, args.N, args.K = M, N, K
     args.epilogue, args.out_fp32, args.alpha = epilogue, int(out_fp32), float(alpha)
-    if K >= 6144 and N % 256 == 0 and M <= 256 * SPLITK_SLOTS and not out_fp32:   # the only shapes the planner may split
+    if K >= 6144 and N % 256 == 0 and M <= 256 * SPLITK_SLOTS and not out_fp32 and layout == 0:   # the only shapes the planner may split
         ws, slots = splitk_workspace(a.device)
         args.splitk_ws, args.splitk_slots = ws.data_ptr(), slots
     if epilogue == FK_EPI_QKV:
@@ -114,15 +133,19 @@ def _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv=None):
     return args, out
 
 
-def gemm(a, w, bias=None, out=None, epilogue=FK_EPI_NONE, res=None, gate=None, out_fp32=False, alpha=1.0, qkv=None):
+def gemm(a, w, bias=None, out=None, epilogue=FK_EPI_NONE, res=None, gate=None, out_fp32=False, alpha=1.0, qkv=None, layout=0):
     """out = epilogue(a @ w.T + bias).  a: [M,K] / [B,R,K] view; w: [N,K]; out likewise (may alias res).
+
+    layout (fk_gemm_args.layout): 1 = ``w`` is [K, N] and out = a @ w (the data gradient reads the weight as stored);
+    2 = ``a`` is [K, M] / [B, R, M] and ``w`` [K, N] / [B, R, N], out [M, N] = a^T @ w (the weight gradient reads both
+    operands token-major).  N % 256 == 0 (2: M % 256 == 0), K % 64 == 0, no epilogue (1: FK_EPI_RES allowed).
 
     gate: [B, N] view (row stride = batch stride); used with FK_EPI_GATE_RES and a 3-D ``a``.
     qkv (FK_EPI_QKV): dict(q_out, k_out [B,H,S_total,128], wq, wk [128], cs fp32 [S_total,64,2] (pack_rope; or cos, sin
     fp32 [S_total,128], packed per call), s_offset)
     -- the fused QKV projection: q / k thirds get RMSNorm + RoPE + head-major layout, the v third lands in out.
     """
-    args, out = _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv)
+    args, out = _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv, layout)
     libfk.check(libfk.load().fk_gemm_bf16(ctypes.byref(args), _stream()), "fk_gemm_bf16")
     return out
 
@@ -141,7 +164,7 @@ def gemm_grouped(problems, epilogue=FK_EPI_NONE):
     outs = []
     for i, pr in enumerate(problems):
         args, out = _gemm_args(pr["a"], pr["w"], pr.get("bias"), pr.get("out"), epilogue, pr.get("res"),
-                               pr.get("gate"), False, 1.0, pr.get("qkv"))
+                               pr.get("gate"), False, 1.0, pr.get("qkv"), pr.get("layout", 0))
         arr[i] = args
         outs.append(out)
     libfk.check(libfk.load().fk_gemm_bf16_grouped(arr, n, _stream()), "fk_gemm_bf16_grouped")

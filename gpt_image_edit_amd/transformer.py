@@ -80,6 +80,7 @@ class HipFluxTransformer2DModel(ParamTreeMixin, nn.Module):
         self._names = list(shapes.keys())
         self.__dict__["_pmap"] = build_param_tree(self, state, requires_grad=False)
         self._packed = None
+        self._train_packs = False     # training (backward.FluxBackward sets it): no fused copy of anything an optimiser rewrites
         self._ws = {}
         self._rope_cache = {}
         self._freqs = None
@@ -108,59 +109,92 @@ class HipFluxTransformer2DModel(ParamTreeMixin, nn.Module):
 
     # ---- one-time weight packing (fused QKV, all-block modulation) -----------------------------------------
     def packed(self):
-        """The fused copies, rebuilt when a source parameter was rewritten since they were made (an optimiser step,
-        ``param.data = ...``, an all-gather into the flat ZeRO buffer): the check is one (data_ptr, version) tuple."""
+        """The fused operands, rebuilt when a source parameter of a fused COPY was rewritten since it was made (an optimiser
+        step, ``param.data = ...``) or an aliased source moved: the check is one (data_ptr, version) tuple."""
         pk = self._packed
-        if pk is None or pk.versions != self.param_versions(pk.sources):
+        if pk is None or pk.versions != self.param_versions(pk.sources) or pk.alias_ptrs != self._ptrs(pk.aliased):
             pk = self.pack_weights()
         return pk
 
+    def _ptrs(self, names):
+        pm = self._pmap
+        return tuple(pm[n].data_ptr() for n in names)
+
+    def _fuse(self, pk, names):
+        """q | k | v (weights [3D, D] or biases [3D]) as ONE operand: a view when the three already lie side by side in
+        memory (``zero.backward_order`` puts them so in the flat ZeRO buffer: an optimiser step then needs no re-pack), else
+        a copy, whose sources join the version check."""
+        ts = [self.p(n).data for n in names]
+        side_by_side = all(t.is_contiguous() and t.untyped_storage().data_ptr() == ts[0].untyped_storage().data_ptr() for t in ts) and all(
+            b.data_ptr() == a.data_ptr() + a.numel() * a.element_size() for a, b in zip(ts, ts[1:]))
+        if side_by_side and self._train_packs:
+            shape = (sum(t.shape[0] for t in ts),) + tuple(ts[0].shape[1:])
+            pk.aliased += names
+            return ts[0].new_empty(0).set_(ts[0].untyped_storage(), ts[0].storage_offset(), shape)
+        pk.sources += names
+        t = torch.cat(ts).contiguous()
+        pk.copies.append((t, names))
+        return t
+
+    def repack(self, changed):
+        """After ``changed`` parameters were rewritten behind torch's version counters (``fk_adamw_step`` writes through raw
+        pointers): refresh, in place, the fused copies built from them.  Aliased operands need nothing."""
+        pk = self._packed
+        if pk is None:
+            return
+        if pk.mod_w is not None and any(n in changed for n in pk.mod_sources):
+            self._packed = None
+            return
+        for t, names in pk.copies:
+            if any(n in changed for n in names):
+                torch.cat([self.p(n).data for n in names], out=t)
+
     def pack_weights(self):
         c, D = self.config, self.inner_dim
-        pk = SimpleNamespace(double=[], single=[])
-        sources = []
-        for i in range(c.num_layers):
-            p = f"transformer_blocks.{i}."
-            sources += [p + f"attn.{n}.{wb}" for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj")
-                        for wb in ("weight", "bias")]
-            sources += [p + f"{n}.linear.{wb}" for n in ("norm1", "norm1_context") for wb in ("weight", "bias")]
-        for i in range(c.num_single_layers):
-            p = f"single_transformer_blocks.{i}."
-            sources += [p + f"attn.{n}.{wb}" for n in ("to_q", "to_k", "to_v") for wb in ("weight", "bias")]
-            sources += [p + f"norm.linear.{wb}" for wb in ("weight", "bias")]
-        sources += ["norm_out.linear.weight", "norm_out.linear.bias"]
-        pk.sources, pk.versions = sources, self.param_versions(sources)
-        self.__dict__["_pack_serial"] = pk.serial = self.__dict__.get("_pack_serial", 0) + 1
-        mod_w, mod_b, off = [], [], 0
+        pk = SimpleNamespace(double=[], single=[], sources=[], aliased=[], copies=[])
+        mod_w, mod_b, mod_names, off = [], [], [], 0
+        qkv = lambda p, trio, wb: [p + f"attn.{n}.{wb}" for n in trio]  # noqa: E731
         for i in range(c.num_layers):
             p = f"transformer_blocks.{i}."
             blk = SimpleNamespace()
-            blk.wqkv_img = torch.cat([self.p(p + f"attn.{n}.weight") for n in ("to_q", "to_k", "to_v")]).contiguous()
-            blk.bqkv_img = torch.cat([self.p(p + f"attn.{n}.bias") for n in ("to_q", "to_k", "to_v")]).contiguous()
-            blk.wqkv_txt = torch.cat([self.p(p + f"attn.{n}.weight") for n in ("add_q_proj", "add_k_proj", "add_v_proj")]).contiguous()
-            blk.bqkv_txt = torch.cat([self.p(p + f"attn.{n}.bias") for n in ("add_q_proj", "add_k_proj", "add_v_proj")]).contiguous()
+            blk.wqkv_img = self._fuse(pk, qkv(p, ("to_q", "to_k", "to_v"), "weight"))
+            blk.bqkv_img = self._fuse(pk, qkv(p, ("to_q", "to_k", "to_v"), "bias"))
+            blk.wqkv_txt = self._fuse(pk, qkv(p, ("add_q_proj", "add_k_proj", "add_v_proj"), "weight"))
+            blk.bqkv_txt = self._fuse(pk, qkv(p, ("add_q_proj", "add_k_proj", "add_v_proj"), "bias"))
             blk.mod_img, blk.mod_txt = off, off + 6 * D
             off += 12 * D
-            mod_w += [self.p(p + "norm1.linear.weight"), self.p(p + "norm1_context.linear.weight")]
-            mod_b += [self.p(p + "norm1.linear.bias"), self.p(p + "norm1_context.linear.bias")]
+            mod_names += [p + "norm1.linear", p + "norm1_context.linear"]
             pk.double.append(blk)
         for i in range(c.num_single_layers):
             p = f"single_transformer_blocks.{i}."
             blk = SimpleNamespace()
-            blk.wqkv = torch.cat([self.p(p + f"attn.{n}.weight") for n in ("to_q", "to_k", "to_v")]).contiguous()
-            blk.bqkv = torch.cat([self.p(p + f"attn.{n}.bias") for n in ("to_q", "to_k", "to_v")]).contiguous()
+            blk.wqkv = self._fuse(pk, qkv(p, ("to_q", "to_k", "to_v"), "weight"))
+            blk.bqkv = self._fuse(pk, qkv(p, ("to_q", "to_k", "to_v"), "bias"))
             blk.mod = off
             off += 3 * D
-            mod_w.append(self.p(p + "norm.linear.weight"))
-            mod_b.append(self.p(p + "norm.linear.bias"))
+            mod_names.append(p + "norm.linear")
             pk.single.append(blk)
         pk.mod_out = off
         off += 2 * D
-        mod_w.append(self.p("norm_out.linear.weight"))
-        mod_b.append(self.p("norm_out.linear.bias"))
-        pk.mod_w = torch.cat(mod_w).contiguous()
-        pk.mod_b = torch.cat(mod_b).contiguous()
+        mod_names.append("norm_out.linear")
         pk.mod_total = off
+        pk.mod_sources = [n + s for n in mod_names for s in (".weight", ".bias")]
+        if self._train_packs:
+            # training: the 6.5 GB of modulation weights are half of the trainable parameters -- no fused copy to rebuild after
+            # every optimiser step; the conditioning runs one small-M GEMM per block on the parameters themselves
+            pk.mod_w = pk.mod_b = None
+            pk.mod_parts, o = [], 0
+            for n in mod_names:
+                w = self.p(n + ".weight")
+                pk.mod_parts.append((n, o, w.shape[0]))
+                o += w.shape[0]
+            assert o == off
+        else:
+            pk.mod_w = torch.cat([self.p(n + ".weight") for n in mod_names]).contiguous()
+            pk.mod_b = torch.cat([self.p(n + ".bias") for n in mod_names]).contiguous()
+            pk.sources += pk.mod_sources
+        pk.versions, pk.alias_ptrs = self.param_versions(pk.sources), self._ptrs(pk.aliased)
+        self.__dict__["_pack_serial"] = pk.serial = self.__dict__.get("_pack_serial", 0) + 1
         self._packed = pk
         return pk
 
@@ -236,7 +270,11 @@ class HipFluxTransformer2DModel(ParamTreeMixin, nn.Module):
         ops.add3(t_emb, g_emb, p_emb, out=temb)
         # every block's modulation vectors in one weight-streaming GEMM
         ops.silu(temb, out=act)
-        ops.gemm(act, pk.mod_w, pk.mod_b, out=mod)
+        if pk.mod_w is not None:
+            ops.gemm(act, pk.mod_w, pk.mod_b, out=mod)
+        else:   # training packs: per block, on the parameters themselves (same kernel, same rows: same bits)
+            for n, o, rows in pk.mod_parts:
+                ops.gemm(act, P(n + ".weight"), P(n + ".bias"), out=mod[:, o:o + rows])
 
     @torch.no_grad()
     def prepare_conditioning(self, timesteps, guidance, pooled_projections):

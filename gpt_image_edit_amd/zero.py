@@ -38,13 +38,23 @@ DEFAULT_BUCKET = 540_000_000    # zero2.json: reduce_bucket_size 5.4e8
 def backward_order(names):
     """Names sorted by when ``backward.FluxBackward.backward`` finishes their gradients: single blocks 37 .. 0, double
     blocks 18 .. 0, then everything else (the ``denoise_projector``, fed by the gradient of ``prompt_embeds``)."""
+    def inner(n):
+        # q, k, v of one projection side by side in that order (weights, then biases): in the flat buffer they ARE the
+        # fused [3D, D] / [3D] operands of the QKV GEMM, which the model then aliases instead of re-packing every step
+        for trio, tag in ((("to_q", "to_k", "to_v"), "attn.0qkv"), (("add_q_proj", "add_k_proj", "add_v_proj"), "attn.0qkv_added")):
+            for i, t in enumerate(trio):
+                for wb in ("weight", "bias"):
+                    if n.endswith(f"attn.{t}.{wb}"):
+                        return (tag, wb, i)
+        return (n, "", 0)
+
     def key(n):
         parts = n.split(".")
         if parts[0] == "single_transformer_blocks":
-            return (0, -int(parts[1]), n)
+            return (0, -int(parts[1])) + inner(n)
         if parts[0] == "transformer_blocks":
-            return (1, -int(parts[1]), n)
-        return (2, 0, n)
+            return (1, -int(parts[1])) + inner(n)
+        return (2, 0) + inner(n)
     return sorted(names, key=key)
 
 
@@ -102,10 +112,11 @@ class FlatLayout:
 
 class ShardedAdamW:
     def __init__(self, params, lr=1e-6, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, kernels=None,
-                 group=None, order=None, bucket_numel=DEFAULT_BUCKET):
+                 group=None, order=None, bucket_numel=DEFAULT_BUCKET, stage_always=False):
         """``params``: dict name -> bf16 tensor (the trainable subset, e.g. ``training.trainable_names``).  After
         construction ``self.params`` holds views of ONE flat bf16 buffer that replace them in the model.  ``order``:
-        the names in the order their gradients become available (``backward_order``); default: sorted."""
+        the names in the order their gradients become available (``backward_order``); default: sorted.
+        ``stage_always``: keep the staging buffers on one rank too (tests of the multi-rank intake on one process)."""
         self.group = group
         on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if on else 1
@@ -126,8 +137,10 @@ class ShardedAdamW:
         self.exp_avg = torch.zeros_like(self.master)
         self.exp_avg_sq = torch.zeros_like(self.master)
         self.grad_slice = torch.zeros_like(self.master)
-        # two alternating fp32 staging buffers: bucket b fills while bucket b - 1 is on the wire
-        n_stage = min(2, len(L.buckets))
+        # two alternating fp32 staging buffers: bucket b fills while bucket b - 1 is on the wire.  One rank: nothing goes on a
+        # wire and a bucket's chunk is the bucket -- gradients are cast straight into `grad_slice`, no staging, no copy
+        self.direct = self.world == 1 and not stage_always
+        n_stage = 0 if self.direct else min(2, len(L.buckets))
         self.staging = [torch.zeros(L.max_bucket, dtype=torch.float32, device=dev) for _ in range(n_stage)]
         self.step_count = 0
         self.last_grad_norm = None
@@ -142,6 +155,9 @@ class ShardedAdamW:
 
     def _stage_for(self, b):
         """Staging buffer of bucket b (waits for the reduction of the bucket that used it before)."""
+        if self.direct:
+            bk = self.layout.buckets[b]
+            return self.grad_slice[bk["state_offset"]: bk["state_offset"] + bk["chunk"]]
         slot = b % len(self.staging)
         owner = self._stage_owner[slot]
         if owner != b:
@@ -183,6 +199,10 @@ class ShardedAdamW:
         dst = self.grad_slice[bk["state_offset"]: bk["state_offset"] + bk["chunk"]]
         if self.world > 1:
             self._work[b] = dist.reduce_scatter_tensor(dst, stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        elif self.direct:   # `stage` IS `dst`; tensors that received no gradient this step count as zero (the padding never changes)
+            for n in bk["names"]:
+                if n not in self._seen[b]:
+                    self.grad_view(n).zero_()
         else:
             dst.copy_(stage[: bk["chunk"]])
         self._launched[b] = True
@@ -192,8 +212,10 @@ class ShardedAdamW:
     def grads(self):
         """dict name -> fp32 staging view; writing all of them and calling ``step()`` is the unbucketed use.  Only valid
         when everything fits the staging buffers (at most two buckets)."""
-        if len(self.layout.buckets) > len(self.staging):
+        if not self.direct and len(self.layout.buckets) > len(self.staging):
             raise RuntimeError("grads views need <= 2 buckets; feed gradients through accumulate()")
+        for b, bk in enumerate(self.layout.buckets):     # the caller writes all of them
+            self._seen[b].update(bk["names"])
         return {n: self.grad_view(n) for n in self.layout.names}
 
     def state_bytes(self):

@@ -100,6 +100,13 @@ typedef struct fk_gemm_args {
   void* splitk_ws;
   int32_t qkv_s_offset, qkv_s_total, qkv_heads;
   int32_t splitk_slots;
+  /* Operand layout (the backward pass's operands as they lie in memory; reference: autograd through nn.Linear,
+   * train_denoiser.py:1172):  0 = A [M, K], W [N, K] (above);  1 = W is [K, N] (ldw = its row stride): the data gradient
+   * dX = dY W reads the weight as stored;  2 = A is [K, M] as well (a = its K rows, uniformly strided): the weight
+   * gradient dW = dY^T X reads both operands token-major.  1 / 2: N % 256 == 0, K % 64 == 0, epilogue none (1: also
+   * FK_EPI_RES), 2: M % 256 == 0; same sums, bit for bit, as layout 0 on transposed copies. */
+  int32_t layout;
+  int32_t reserved0;
 } fk_gemm_args;
 #define FK_SPLITK_SLOT_BYTES (256 * 256 * 4 + 8)
 

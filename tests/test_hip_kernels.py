@@ -225,6 +225,57 @@ def test_gemm_fused_qkv_epilogue(ops):
     assert torch.equal(q1, q2) and torch.equal(k1, k2) and torch.equal(qkv1[:, :, 2 * D:], qkv2[:, :, 2 * D:])
 
 
+def test_gemm_k_major_operands(ops):
+    """fk_gemm_args.layout 1 / 2: the data gradient reads the weight as stored ([K, N]), the weight gradient both operands
+    token-major ([K, M], [K, N]) -- the same sums, bit for bit, as the row-major kernel on physically transposed copies
+    (the K-major fragments come through ds_read_b64_tr_b16 in the b128 path's k-slot order)."""
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(11)
+    rnd = lambda *sh, sc=1.0: ((torch.rand(*sh, device=dev, generator=g) * 2 - 1) * sc).to(BF)  # noqa: E731
+    ops.gemm_set_plan(1)     # no split-K pairs in the row-major reference (they differ in the last bits by design)
+    try:
+        _k_major_cases(ops, rnd, dev)
+    finally:
+        ops.gemm_set_plan(3)
+
+
+def _k_major_cases(ops, rnd, dev):
+    # ---- layout 1: dX = dY W, W [N_out (= K), K_in (= N)], whole and as a column slice of a wider weight ----------------
+    for (M, K, N, wide) in [(2560, 3072, 3072, 0), (300, 768, 512, 0), (8704, 3072, 3072, 15360), (777, 12288, 3072, 0)]:
+        dy = rnd(M, K)
+        Wfull = rnd(K, wide or N, sc=0.05)
+        W = Wfull[:, 256:256 + N] if wide else Wfull
+        ref = ops.gemm(dy, W.t().contiguous())
+        got = ops.gemm(dy, W, layout=1)
+        assert torch.equal(ref, got), f"layout 1 {M}x{N}x{K}: max diff {(ref.float() - got.float()).abs().max().item()}"
+        acc = rnd(M, N)
+        ref2 = ops.gemm(dy, W.t().contiguous(), out=acc.clone(), epilogue=ops.FK_EPI_RES, res=acc)
+        a2 = acc.clone()
+        got2 = ops.gemm(dy, W, out=a2, epilogue=ops.FK_EPI_RES, res=a2, layout=1)
+        assert torch.equal(ref2, got2)
+    # grouped (image / text rows of one [B, S, *] buffer, two weights), 3-D views with a batch stride
+    B, S, S_txt, K, N = 2, 640, 128, 1024, 768
+    dy, out_r, out_g = rnd(B, S, K), torch.zeros(B, S, N, device=dev, dtype=BF), torch.zeros(B, S, N, device=dev, dtype=BF)
+    Wi, Wt = rnd(K, N, sc=0.05), rnd(K, N, sc=0.05)
+    ops.gemm_grouped([dict(a=dy[:, S_txt:], w=Wi.t().contiguous(), out=out_r[:, S_txt:]), dict(a=dy[:, :S_txt], w=Wt.t().contiguous(), out=out_r[:, :S_txt])])
+    ops.gemm_grouped([dict(a=dy[:, S_txt:], w=Wi, out=out_g[:, S_txt:], layout=1), dict(a=dy[:, :S_txt], w=Wt, out=out_g[:, :S_txt], layout=1)])
+    assert torch.equal(out_r, out_g)
+    # ---- layout 2: dW = dY^T X over the token rows of [1, S, *] views (column slices of wider buffers included) -----------
+    for (T, M, N) in [(8704, 3072, 3072), (512, 768, 1024), (2560, 12288, 3072), (4096, 3072, 12288)]:
+        dyb, xb = rnd(1, T + 64, M + 128), rnd(1, T + 64, N + 256)
+        dy, x = dyb[:, 64:, 128:], xb[:, :T, 256:]
+        ref = ops.gemm(dy[0].t().contiguous(), x[0].t().contiguous())
+        got = ops.gemm(dy, x, layout=2)
+        assert got.shape == (M, N) and torch.equal(ref, got), f"layout 2 {T}: {(ref.float() - got.float()).abs().max().item()}"
+        exact = dy[0].float().t() @ x[0].float()
+        assert_bf16_close(f"gemm layout 2 T{T} {M}x{N}", got, exact.to(BF), max_ulp=1, max_bad_frac=1e-3)
+    # what the K-major path cannot take is refused, not mis-computed
+    with pytest.raises(RuntimeError, match="layout"):
+        ops.gemm(rnd(256, 128), rnd(128, 200), layout=1)            # N % 256
+    with pytest.raises(RuntimeError, match="layout"):
+        ops.gemm(rnd(2, 128, 384), rnd(2, 128, 256), layout=2)      # M % 256
+
+
 def test_gemm_rejects_bad_arguments(ops):
     a, w = randn(64, 96).cuda(), randn(64, 96).cuda()  # K = 96 is not a multiple of 64
     with pytest.raises(RuntimeError, match="multiple of 64"):

@@ -172,3 +172,33 @@ def test_projector_trains_along():
     assert out[0][:2] == out[1][:2]
     for k in sd:
         assert torch.equal(out[0][2][k], out[1][2][k]), k
+
+
+def test_k_major_operands_give_the_same_gradients(monkeypatch):
+    """backward.K_MAJOR 0 / 1 / 2: transposed copies, token-major weight-gradient operands (fk_gemm_args.layout 2), stored
+    weights in the data gradients as well (layout 1) -- the same products summed in the same order: every gradient, the loss
+    and d(prompt_embeds) bit for bit (B = 1: whole-tile shapes take the K-major path; B = 2 slices fall back per call)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd import backward, ops
+    from gpt_image_edit_amd.train_step import DenoiserTrainStep
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    ops.gemm_set_plan(1)      # no split-K pairs: the row-major and K-major launches must add in the same order
+    try:
+        for B in (1, 2):
+            cfg, sd_bf, batch, trainable = _setup(B=B, S_txt=64, h=32, w=32)
+            res = {}
+            for level in (0, 1, 2):
+                monkeypatch.setattr(backward, "K_MAJOR", level)
+                model = HipFluxTransformer2DModel(cfg, device="cuda")
+                model.load_state_dict(sd_bf)
+                ts = DenoiserTrainStep(model, lr=1e-3)
+                loss, grads, d_enc = ts.forward_backward(**{k: v.cuda() for k, v in batch.items()})
+                torch.cuda.synchronize()
+                res[level] = (loss.clone(), {k: v.clone() for k, v in grads.items()}, d_enc.clone())
+            for level in (1, 2):
+                assert torch.equal(res[0][0], res[level][0]) and torch.equal(res[0][2], res[level][2])
+                for k in trainable:
+                    assert torch.equal(res[0][1][k], res[level][1][k]), f"K_MAJOR {level}, B {B}: {k}"
+    finally:
+        ops.gemm_set_plan(3)

@@ -195,3 +195,55 @@ def test_save_pretrained_round_trip(tmp_path):
     sd, sd2 = m.state_dict(), m2.state_dict()
     assert list(sd) == list(sd2) and all(torch.equal(sd[k], sd2[k]) for k in sd)
     assert vars(m2.config) == vars(m.config)
+
+
+def test_training_packs_alias_the_flat_zero_buffer():
+    """With ZeRO's flat buffer in ``backward_order`` the q | k | v thirds of every fused QKV operand lie side by side: the
+    model's training packs are VIEWS of the parameters (an optimiser step through raw pointers needs no re-pack), the frozen
+    text-branch operands are copies made once, and the modulation weights are not fused at all."""
+    from gpt_image_edit_amd import flux_spec, training
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    from gpt_image_edit_amd.zero import FlatLayout, backward_order
+    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=2, num_single_layers=2, num_attention_heads=2, joint_attention_dim=64,
+               pooled_projection_dim=32)
+    m = HipFluxTransformer2DModel(cfg, device="cpu", init="synthetic", seed=3)
+    D = m.inner_dim
+    fused_before = m.pack_weights()
+    assert fused_before.mod_w is not None and not fused_before.aliased
+    ref_w = fused_before.single[1].wqkv.clone()
+    names = sorted(training.trainable_names(list(m._pmap.keys())))
+    order = backward_order(names)
+    blk = [n for n in order if n.startswith("single_transformer_blocks.1.attn.to_")]
+    assert blk == [f"single_transformer_blocks.1.attn.{t}.{wb}" for wb in ("bias", "weight") for t in ("to_q", "to_k", "to_v")]
+    L = FlatLayout({n: m.p(n).shape for n in names}, 1, order=order, bucket_numel=3 * D * D)     # several buckets
+    flat = torch.zeros(L.total, dtype=torch.bfloat16)
+    views = L.views(flat)
+    for n in names:
+        views[n].copy_(m.p(n).data)
+        m.p(n).data = views[n]
+    m._train_packs, m._packed = True, None
+    pk = m.packed()
+    assert pk.mod_w is None and [n for n, _, _ in pk.mod_parts][-1] == "norm_out.linear" and pk.mod_parts[-1][1] + 2 * D == pk.mod_total
+    assert torch.equal(pk.single[1].wqkv, ref_w)
+    # image-branch and single-block operands alias the flat buffer unless a bucket boundary separates the thirds
+    aliased = set(pk.aliased)
+    assert "single_transformer_blocks.1.attn.to_q.bias" in aliased and len(aliased) >= 0.5 * 6 * 4
+    assert not any("add_q_proj" in n for n in aliased) and any("add_q_proj" in n for n in pk.sources)     # frozen: copied once
+    # an update behind torch's back (fk_adamw_step writes through raw pointers) shows through the aliased operand at once ...
+    views["single_transformer_blocks.1.attn.to_k.weight"].view(torch.int16).add_(1)
+    assert m.packed() is pk and not torch.equal(pk.single[1].wqkv, ref_w)
+    assert torch.equal(pk.single[1].wqkv[D:2 * D], m.p("single_transformer_blocks.1.attn.to_k.weight").data)
+    # ... and repack() refreshes, in place, the copies built from rewritten tensors (none of the trainable ones here, unless a
+    # bucket boundary split a triple)
+    ptrs = [t.data_ptr() for t, _ in pk.copies]
+    for t, ns in pk.copies:
+        if any(n in set(names) for n in ns):
+            m.p(ns[0]).data.view(torch.int16).add_(1)
+    m.repack(set(names))
+    assert m.packed() is pk and ptrs == [t.data_ptr() for t, _ in pk.copies]
+    for t, ns in pk.copies:
+        assert torch.equal(t, torch.cat([m.p(n).data for n in ns]))
+    # moving an aliased parameter rebuilds the packs
+    m.p("single_transformer_blocks.1.attn.to_q.weight").data = m.p("single_transformer_blocks.1.attn.to_q.weight").data.clone()
+    pk2 = m.packed()
+    assert pk2 is not pk and "single_transformer_blocks.1.attn.to_q.weight" not in pk2.aliased

@@ -146,10 +146,29 @@ def test_flat_layout_single_process():
     assert Lb.slice_numel == sum(b["chunk"] for b in Lb.buckets) and Lb.total == 4 * Lb.slice_numel
     # feeding gradients out of order is an error, not a silent mix-up
     order = backward_order(names)
-    o2 = ShardedAdamW({n: torch.zeros(100, 7, dtype=BF) for n in names}, kernels=TorchKernels, order=order, bucket_numel=1500, **HP)
+    o2 = ShardedAdamW({n: torch.zeros(100, 7, dtype=BF) for n in names}, kernels=TorchKernels, order=order, bucket_numel=1500,
+                      stage_always=True, **HP)      # the multi-rank intake (two staging buffers) on one process
     assert len(o2.layout.buckets) == 3 and len(o2.staging) == 2
     import pytest
     o2.accumulate({order[0]: torch.ones(100, 7)})          # half of bucket 0
     o2.accumulate({order[2]: torch.ones(100, 7), order[3]: torch.ones(100, 7)})   # all of bucket 1: reduced
     with pytest.raises(RuntimeError, match="incomplete"):
         o2.accumulate({order[4]: torch.ones(100, 7)})      # bucket 2 wants bucket 0's staging buffer
+    # one rank without staging: gradients are cast straight into the optimiser's gradient chunk; any arrival order, absent
+    # tensors count as zero, and the result equals the staged intake bit for bit
+    def run(feed, **kw):
+        o = ShardedAdamW({n: torch.full((100, 7), 0.25, dtype=BF) for n in names}, kernels=TorchKernels, order=order, bucket_numel=1500,
+                         **kw, **HP)
+        for step in range(2):
+            for n in feed:
+                o.accumulate({n: torch.full((100, 7), float(len(n) + step), dtype=BF)})
+            o.step()
+        return o
+    staged = run(order[:4], stage_always=True)                  # the last tensor never gets a gradient
+    direct = run(order[:4])
+    shuffled = run([order[3], order[0], order[2], order[1]])    # one rank: no staging buffer to wait for, any order
+    assert len(direct.staging) == 0 and len(staged.staging) == 2
+    for n in names:
+        assert torch.equal(staged.params[n], direct.params[n]) and torch.equal(direct.params[n], shuffled.params[n])
+    assert torch.equal(direct.params[order[4]], torch.full((100, 7), 0.25, dtype=BF))      # zero gradient: two steps of weight decay stay below bf16 resolution
+    assert not torch.equal(direct.params[order[0]], torch.full((100, 7), 0.25, dtype=BF))

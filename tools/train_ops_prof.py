@@ -46,3 +46,27 @@ for e in evs[:rows]:
     stack = " <- ".join(s.split("/")[-1] for s in (e.stack or [])[:4])
     print(f"{t / 1e3:9.3f} ms  x{e.count:5d}  {e.key:40s} {str(e.input_shapes)[:90]:90s} {stack[:160]}")
 print(f"listed: {tot / 1e3:.2f} ms")
+
+# ---- where the HOST spends the step: one step under cProfile (no device synchronisation inside), then the wall time ----------
+import cProfile  # noqa: E402
+import pstats  # noqa: E402
+import time  # noqa: E402
+
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+t0 = time.perf_counter()
+pr.enable()
+ts.step(**batch)
+pr.disable()
+t_host = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_wall = time.perf_counter() - t0
+print(f"host enqueue {t_host * 1e3:.1f} ms (under cProfile), wall {t_wall * 1e3:.1f} ms")
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(28)
+t0 = time.perf_counter()
+for _ in range(3):
+    ts.step(**batch)
+t_host = (time.perf_counter() - t0) / 3
+torch.cuda.synchronize()
+print(f"plain: host enqueue {t_host * 1e3:.1f} ms per step, wall {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms per step")
