@@ -307,12 +307,14 @@ def prompt_encode_time(device, batch=1):
     return bench_prompt_encode(device, batch=batch)
 
 
-def train_step_bench(device, steps=3, warmup=1, world=1):
+def train_step_bench(device, steps=3, warmup=2, world=1):
     """BASELINE.json configs[4] on this rank's GPU: one stage-2 optimisation step of the denoiser at 1024^2, batch 1 per
     GPU (S_txt = 256 projected VLM tokens + 256 T5 prefix tokens, + 4096 target + 4096 condition tokens), the parameters
     the reference un-freezes (`only_tune_image_branch` subset of the MMDiT + the denoise_projector), activations stored
     or one checkpoint per block (`auto`), AdamW on ZeRO-2-sharded fp32 state (with world > 1:
-    fp32 gradient reduce-scatter + bf16 parameter all-gather over RCCL).  Synthetic latents / embeddings / weights."""
+    fp32 gradient reduce-scatter + bf16 parameter all-gather over RCCL).  Synthetic latents / embeddings / weights.
+    Two warm-up steps: the first builds workspaces and transposed weights, the second is the first to start from updated
+    parameters (what every later step does)."""
     from gpt_image_edit_amd import flux_spec
     from gpt_image_edit_amd.projector import HipDenoiseProjector
     from gpt_image_edit_amd.train_step import DenoiserTrainStep
@@ -363,7 +365,7 @@ def train_step_bench(device, steps=3, warmup=1, world=1):
             "what": "train_denoiser.py stage-2 step: denoise_projector on the VLM states, noisy tokens, MMDiT forward, flow-matching "
                     "loss + gradient, backward (adjoints; weight gradients for the un-frozen subset + the projector), "
                     "global-norm clip + AdamW (ZeRO-2 layout); `model_tflops_3x_forward` prices the step at the conventional "
-                    "3 x forward FLOPs (the recompute and the 8-product attention backward are not credited)"}
+                    "3 x forward FLOPs (the 7-product attention backward is not credited beyond that)"}
 
 
 def timed_edits(pipe, inp, steps, warmup, world, device, backend):
