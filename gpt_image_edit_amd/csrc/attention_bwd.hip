@@ -11,12 +11,16 @@
 //   MODE_DV  rows = keys (K in registers),        columns = queries:  s = Q K^T,              w = p,            dV^T += dO^T w
 //   MODE_DK  rows = keys (K, V in registers),     columns = queries:  s = Q K^T, dp = dO V^T, w = p (dp - D) c, dK^T += Q^T w
 // with p = exp2(s c' - lse).  No atomics, no cross-workgroup reduction: gradients are deterministic.
+// The elementwise stage is one fused multiply-add, one exponential and one multiply per score: the dp product's accumulator
+// STARTS at D and its stationary operand (dO resp. V) is held negated, so the MFMAs deliver D - dP; the sign and the softmax
+// scale c multiply the accumulator once at the store; the ragged last tile (compares / selects per score) is its own
+// instantiation outside the main loop.  These kernels are VALU-issue-bound, not MFMA-bound: each of those steps paid.
 //
 // Default since round 3: TWO passes, 7 tile products and 2 exponentials per score instead of 8 and 3.  dK and dV come out
 // of one launch (attention_bwd_dkv_kernel) in which the two waves that share a SIMD split the work on the same 32 keys:
 //   producer (waves 0-3)  s = Q K^T, p = exp2(s c' - lse), hands bf16(p) over through LDS,          dV^T += dO^T p
 //   consumer (waves 4-7)  dp = dO V^T, w = bf16(p) (dp - D) c,                                      dK^T += Q^T w
-// Both accumulators and both stationary operands do not fit 256 registers of one wave; split like this every wave is at
+// Both accumulators and both stationary operands do not fit 256 registers of one wave; split like this every wave needs
 // ~150, every product is computed once, and the hand-over is lane-to-same-lane (the producer's packed B-operand fragments
 // ARE the consumer's), one tile behind, ordered by the per-tile workgroup barrier -- no flags, no polling.
 // fk_attention_bwd_set_mode(0) / FK_ATTN_BWD=0 selects the three-pass form (dK then differs in the last bf16 bit: there

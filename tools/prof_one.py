@@ -1,6 +1,6 @@
 """Run ONE kernel shape a few times (target for `rocprofv3 --pmc ...`).
 
-    python tools/prof_one.py gemm 2560 9216 3072 [epi]      |  attention B S
+    python tools/prof_one.py gemm 2560 9216 3072 [epi]      |  attention B S      |  attention_bwd B S
 """
 import os
 import sys
@@ -34,6 +34,14 @@ else:
     H = 24
     q, k, qkv = rnd(B, H, S, 128), rnd(B, H, S, 128), rnd(B, S, 3 * H * 128)
     o = torch.empty(B, S, H * 128, device="cuda", dtype=BF)
-    for _ in range(5):
-        ops.attention(q, k, qkv[:, :, 2 * H * 128:], o)
+    if kind == "attention_bwd":    # both forms of the backward (FK_ATTN_BWD picks the default one)
+        do, lse = rnd(B, S, H * 128), torch.empty(B, H, S, device="cuda", dtype=torch.float32)
+        ops.attention_lse(q, k, qkv[:, :, 2 * H * 128:], o, lse)
+        dsum = ops.rowdot(do, o, H)
+        dq, dk, dqkv = torch.empty_like(q), torch.empty_like(k), torch.zeros_like(qkv)
+        for _ in range(5):
+            ops.attention_bwd(q, k, qkv[:, :, 2 * H * 128:], do, lse, dsum, dq, dk, dqkv[:, :, 2 * H * 128:])
+    else:
+        for _ in range(5):
+            ops.attention(q, k, qkv[:, :, 2 * H * 128:], o)
 torch.cuda.synchronize()
