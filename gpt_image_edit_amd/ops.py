@@ -7,7 +7,7 @@ import ctypes
 
 import torch
 
-from . import libfk
+from . import libfk, param_tree
 from .libfk import (FK_EPI_GATE_RES, FK_EPI_GELU_TANH, FK_EPI_NONE, FK_EPI_QKV, FK_EPI_RES, FK_EPI_SCALE,  # noqa: F401
                     FK_EPI_SILU, GemmArgs, Rows)
 
@@ -28,13 +28,14 @@ def _need_cuda(*ts):
             raise RuntimeError("gpt_image_edit_amd ops need GPU tensors: the HIP path has no CPU fallback")
 
 
-def pack_rope(cos, sin):
+def pack_rope(cos, sin, check=True):
     """FluxPosEmbed's cos / sin [S, 128] (each value repeated over the two columns of its rotary pair) -> the
     [S, 64, 2] (cos, sin)-per-pair table the fused QKV epilogue reads.  Step-invariant: callers on the hot path
     pack once (transformer._rope) and pass ``cs``; passing cos / sin packs per call and checks the repetition."""
     if cos.shape != sin.shape or cos.dim() != 2 or cos.shape[1] != 128:
         raise ValueError("cos / sin must be [S, 128]")
-    if not (torch.equal(cos[:, 0::2], cos[:, 1::2]) and torch.equal(sin[:, 0::2], sin[:, 1::2])):
+    # check=False: tables that come straight from transformer.rope_tables (torch.equal on device tensors is a host sync)
+    if check and not (torch.equal(cos[:, 0::2], cos[:, 1::2]) and torch.equal(sin[:, 0::2], sin[:, 1::2])):
         raise ValueError("cos / sin do not repeat over the columns of a rotary pair: not FluxPosEmbed tables")
     return torch.stack([cos[:, 0::2], sin[:, 0::2]], dim=-1).to(torch.float32).contiguous()
 
@@ -719,4 +720,6 @@ def adamw_step(master, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), 
                                                   _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(grad_sumsq), float(max_grad_norm),
                                                   float(grad_scale), float(lr), float(betas[0]), float(betas[1]), float(eps),
                                                   float(weight_decay), int(step), master.numel(), _stream()), "fk_adamw_step")
+    if param_bf16 is not None:
+        param_tree.note_raw_write()      # a parameter changed behind torch's version counters
     return master

@@ -15,6 +15,21 @@ import torch
 from torch import nn
 
 
+# Writes through raw pointers (``fk_adamw_step`` rewrites the bf16 copy of a parameter, ``zero.ShardedAdamW.step`` the flat
+# buffer the parameters are views of) bump no torch version counter: ``ops.adamw_step`` counts them here instead, and
+# ``param_versions`` carries the count, so every cache keyed on it (fused QKV copies, W^T caches, prepared conditioning)
+# notices an optimiser step even when the caller forgets ``FluxBackward.refresh()`` / ``model.repack()``.
+_RAW_WRITE_EPOCH = [0]
+
+
+def note_raw_write():
+    _RAW_WRITE_EPOCH[0] += 1
+
+
+def raw_write_epoch():
+    return _RAW_WRITE_EPOCH[0]
+
+
 class ParamNode(nn.Module):
     """A module that only holds parameters and child nodes (the arithmetic lives in libfk)."""
 
@@ -52,9 +67,11 @@ class ParamTreeMixin:
 
     def param_versions(self, names):
         """(data_ptr, in-place version) of each named parameter: changes whenever an optimiser, ``load_state_dict``,
-        ``.data = ...`` or an all-gather into a flat buffer rewrites it."""
+        ``.data = ...`` or an all-gather into a flat buffer rewrites it -- plus, when there is anything to watch, the
+        count of raw-pointer parameter writes (``fk_adamw_step``), which no version counter sees."""
         pm = self._pmap
-        return tuple((pm[n].data_ptr(), pm[n]._version) for n in names)
+        v = tuple((pm[n].data_ptr(), pm[n]._version) for n in names)
+        return v + (raw_write_epoch(),) if v else v
 
 
 def numel_of(params):

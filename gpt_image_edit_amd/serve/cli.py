@@ -272,11 +272,9 @@ def chat(args, pipe, tokenizers, text_encoders, device):
         chat_text = "<|im_end|>\n".join(chat_text.split("<|im_end|>\n")[1:])      # drop the system turn (cli.py:186)
         images = vision_inputs(conversation)                                        # process_vision_info (cli.py:189)
         inputs = processor(text=[chat_text], images=images, padding=True, return_tensors="pt").to(device)
-        if images and getattr(inputs, "image_grid_thw", None) is not None:
-            for im, thw in zip(images, inputs.image_grid_thw.tolist()):                 # the processor must not resize again
-                if (thw[1] * 14, thw[2] * 14) != (im.size[1], im.size[0]):
-                    raise RuntimeError(f"processor re-sized a {im.size[1]} x {im.size[0]} image to grid {thw}: pass "
-                                       "min_pixels / max_pixels = 448 * 448 to AutoProcessor (cli.py:30-35)")
+        # The processor applies its own smart_resize to what process_vision_info already resized (a 600 x 800 input becomes
+        # 364 x 504, below min_pixels, and is scaled up again to 392 x 532): the reference does exactly this double resize
+        # silently (cli.py:189-196) and so does this loop -- the grid the model sees is the processor's.
         t5_embeds, pooled = encode_prompt(text_encoders, tokenizers, txt if not args.no_joint_with_t5 else "", 256, device, 1)
         turn = encode_edit_prompt(model, task_head, inputs, t5_embeds, joint_with_t5=not args.no_joint_with_t5)
         if turn["generate"]:

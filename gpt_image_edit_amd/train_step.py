@@ -42,7 +42,7 @@ class DenoiserTrainStep:
         self.state = {}     # name -> (fp32 master, exp_avg, exp_avg_sq)
         self.opt = None
         self.keep_grads = keep_grads
-        self._sunk = set()
+        self._sunk = {}     # name -> (data_ptr, version) of the gradients already handed to the sharded optimiser
         if sharded:
             from .zero import DEFAULT_BUCKET, ShardedAdamW, backward_order
             names = sorted(self.trainable_names())
@@ -124,12 +124,16 @@ class DenoiserTrainStep:
         loss, grad = ops.flow_loss(pred[:, :S_tgt], model_input.contiguous(), noise.contiguous())
         dsample = torch.zeros_like(pred)
         dsample[:, :S_tgt].copy_(grad)
-        self._sunk = set()
         sink = None
         if self.opt is not None:
+            # a second forward_backward before optimizer_step is a further micro-batch of the same step (the reference's
+            # gradient_accumulation_steps): its gradients are ADDED to the optimiser's chunks, the step uses their mean
+            self.opt.begin_micro_batch()
+
             def sink(block_grads):
                 self.opt.accumulate(block_grads)
-                self._sunk.update(block_grads)
+                for k, g in block_grads.items():
+                    self._sunk[k] = (g.data_ptr(), g._version)
         grads, d_enc = self.bw.backward(dsample, sink=sink, keep=self.keep_grads or self.opt is None)
         if n_proj:
             pg = {self.PROJ + k: g for k, g in self.projector.backward(d_enc[:, :n_proj]).items()}
@@ -146,10 +150,19 @@ class DenoiserTrainStep:
         if self.opt is not None:
             # whatever forward_backward has not already handed to the buckets (gradients from another source); tensors
             # without a gradient this step -- e.g. the projector on a batch that came with ready prompt_embeds -- count as 0
-            rest = {k: g for k, g in grads.items() if k not in self._sunk}
+            rest = {}
+            for k, g in grads.items():
+                stamp = self._sunk.get(k)
+                if stamp is None:
+                    rest[k] = g
+                elif stamp != (g.data_ptr(), g._version):
+                    raise RuntimeError(f"optimizer_step: the gradient passed for {k} is not the one forward_backward already "
+                                       "handed to the sharded optimiser (it was replaced or modified in place afterwards) and "
+                                       "would be ignored: with sharded=True accumulate by calling forward_backward again, and "
+                                       "scale through lr / max_grad_norm, not on the returned tensors")
             if rest:
                 self.opt.accumulate(rest)
-            self._sunk = set()
+            self._sunk = {}
             norm = self.opt.step()
             self.step_count = self.opt.step_count
             self.bw.refresh()

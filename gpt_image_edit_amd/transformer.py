@@ -43,12 +43,14 @@ OVERLAP_MLP = {"0": False, "1": True, "auto": "auto"}.get(os.environ.get("FK_OVE
 
 
 def rope_tables(ids, axes_dim=(16, 56, 56), theta=10000.0):
-    """Host-side FluxPosEmbed (step-invariant, computed once per call shape): ids [S,3] -> cos, sin
-    fp32 [S, sum(axes_dim)], frequencies in fp64 like diffusers."""
-    pos = ids.detach().to("cpu", torch.float32)
+    """FluxPosEmbed (step-invariant, computed once per call shape): ids [S,3] -> cos, sin fp32 [S, sum(axes_dim)],
+    frequencies in fp64 like diffusers.  Runs on the device the ids live on -- a handful of
+    tiny fp64 kernels, no host round trip: the reference's training loop builds ``txt_ids`` afresh every step
+    (``modeling_univa_denoise_tower.py:73-75``), and a ``.cpu()`` here would synchronise the device each time."""
+    pos = ids.detach().to(torch.float32)
     cos_parts, sin_parts = [], []
     for i, d in enumerate(axes_dim):
-        inv = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64) / d))
+        inv = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64, device=pos.device) / d))
         ang = pos[:, i].to(torch.float64)[:, None] * inv[None, :]
         cos_parts.append(torch.repeat_interleave(torch.cos(ang), 2, dim=1).float())
         sin_parts.append(torch.repeat_interleave(torch.sin(ang), 2, dim=1).float())
@@ -148,6 +150,7 @@ class HipFluxTransformer2DModel(ParamTreeMixin, nn.Module):
         for t, names in pk.copies:
             if any(n in changed for n in names):
                 torch.cat([self.p(n).data for n in names], out=t)
+        pk.versions = self.param_versions(pk.sources)        # `changed` is everything that was rewritten: current again
 
     def pack_weights(self):
         c, D = self.config, self.inner_dim
@@ -241,9 +244,9 @@ class HipFluxTransformer2DModel(ParamTreeMixin, nn.Module):
         if hit is None:
             t2 = txt_ids[0] if txt_ids.dim() == 3 else txt_ids
             i2 = img_ids[0] if img_ids.dim() == 3 else img_ids
-            ids = torch.cat([t2.float().cpu(), i2.float().cpu()], dim=0)
-            cos, sin = rope_tables(ids, self.config.axes_dims_rope)
-            hit = (cos.to(self.device), sin.to(self.device), txt_ids, img_ids, ops.pack_rope(cos, sin).to(self.device))
+            ids = torch.cat([t2.float().to(self.device), i2.float().to(self.device)], dim=0)
+            cos, sin = rope_tables(ids, self.config.axes_dims_rope)           # on the device: no host sync
+            hit = (cos, sin, txt_ids, img_ids, ops.pack_rope(cos, sin, check=False))
             self._rope_cache = {key: hit}
         return hit[4] if packed else (hit[0], hit[1])
 
@@ -296,8 +299,10 @@ class HipFluxTransformer2DModel(ParamTreeMixin, nn.Module):
         p_all = pooled.repeat(N, 1).contiguous()
         mod = e(M, pk.mod_total)
         self._conditioning(ts.view(M), g_all, p_all, e(M, 256), e(M, D), e(M, D), e(M, D), e(M, D), e(M, D), e(M, D), mod)
+        sources = [n for n in self._names if n.startswith("time_text_embed.")] + list(pk.mod_sources)
         self._cond = SimpleNamespace(ts=ts, N=N, B=B, step_bytes=B * ts.element_size(), guidance=guidance,
-                                     pooled=pooled_projections, mod=mod.view(N, B, pk.mod_total))
+                                     pooled=pooled_projections, mod=mod.view(N, B, pk.mod_total), sources=sources,
+                                     versions=self.param_versions(sources))
 
     def _cached_modulation(self, timestep, guidance, pooled_in):
         cd = self._cond
@@ -307,6 +312,9 @@ class HipFluxTransformer2DModel(ParamTreeMixin, nn.Module):
         if off < 0 or off % cd.step_bytes or off // cd.step_bytes >= cd.N or guidance is not cd.guidance:
             return None
         if pooled_in is not cd.pooled and pooled_in.data_ptr() != cd.pooled.data_ptr():
+            return None
+        if cd.versions != self.param_versions(cd.sources):
+            self._cond = None          # an embedder / modulation weight was rewritten since (an optimiser step): stale
             return None
         return cd.mod[off // cd.step_bytes]
 

@@ -39,8 +39,9 @@ def backward_order(names):
     """Names sorted by when ``backward.FluxBackward.backward`` finishes their gradients: single blocks 37 .. 0, double
     blocks 18 .. 0, then everything else (the ``denoise_projector``, fed by the gradient of ``prompt_embeds``)."""
     def inner(n):
-        # q, k, v of one projection side by side in that order (weights, then biases): in the flat buffer they ARE the
-        # fused [3D, D] / [3D] operands of the QKV GEMM, which the model then aliases instead of re-packing every step
+        # q, k, v of one projection side by side in that order (the three biases first, then the three weights -- "bias"
+        # sorts before "weight"; each trio is contiguous, which is all the aliasing needs): in the flat buffer they ARE
+        # the fused [3D] / [3D, D] operands of the QKV GEMM, which the model then aliases instead of re-packing every step
         for trio, tag in ((("to_q", "to_k", "to_v"), "attn.0qkv"), (("add_q_proj", "add_k_proj", "add_v_proj"), "attn.0qkv_added")):
             for i, t in enumerate(trio):
                 for wb in ("weight", "bias"):
@@ -112,11 +113,14 @@ class FlatLayout:
 
 class ShardedAdamW:
     def __init__(self, params, lr=1e-6, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, kernels=None,
-                 group=None, order=None, bucket_numel=DEFAULT_BUCKET, stage_always=False):
+                 group=None, order=None, bucket_numel=DEFAULT_BUCKET, stage_always=False, average_micro_batches=True):
         """``params``: dict name -> bf16 tensor (the trainable subset, e.g. ``training.trainable_names``).  After
         construction ``self.params`` holds views of ONE flat bf16 buffer that replace them in the model.  ``order``:
         the names in the order their gradients become available (``backward_order``); default: sorted.
-        ``stage_always``: keep the staging buffers on one rank too (tests of the multi-rank intake on one process)."""
+        ``stage_always``: keep the staging buffers on one rank too (tests of the multi-rank intake on one process).
+        ``average_micro_batches``: with gradient accumulation (``begin_micro_batch`` between backward passes, the
+        reference's ``gradient_accumulation_steps``) the step uses the MEAN over the micro-batches, as
+        ``accelerator.backward`` does by dividing every loss by the accumulation count; False: their sum."""
         self.group = group
         on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if on else 1
@@ -144,14 +148,51 @@ class ShardedAdamW:
         self.staging = [torch.zeros(L.max_bucket, dtype=torch.float32, device=dev) for _ in range(n_stage)]
         self.step_count = 0
         self.last_grad_norm = None
+        self.average_micro_batches = average_micro_batches
+        self._acc_tmp = []            # world > 1, micro-batch >= 2: reduce-scatter targets that are then ADDED to grad_slice
         self._begin()
 
     # ---- gradient intake ---------------------------------------------------------------------------------------------
     def _begin(self):
+        self._micro = 0            # micro-batches whose gradients are already part of grad_slice
+        self._begin_pass()
+
+    def _begin_pass(self):
         self._seen = [set() for _ in self.layout.buckets]
         self._launched = [False] * len(self.layout.buckets)
-        self._work = {}            # bucket -> async work handle of its reduce-scatter
+        self._work = {}            # bucket -> (async work handle of its reduce-scatter, accumulation temp or None)
         self._stage_owner = [None] * len(self.staging)
+
+    def begin_micro_batch(self):
+        """Call before every backward pass.  The first one of a step is a no-op; a later one (gradient accumulation, the
+        reference's ``gradient_accumulation_steps`` > 1) closes the previous pass -- buckets it left incomplete are
+        reduced with zeros for the tensors that got no gradient -- and makes the next pass ADD to this rank's gradient
+        chunks instead of overwriting them (DeepSpeed ZeRO-2 likewise reduces every micro-batch into the partition)."""
+        if not any(self._seen) and not any(self._launched):
+            return
+        self._flush()
+        self._micro += 1
+        self._begin_pass()
+
+    def _finish(self, b):
+        """Wait for bucket b's reduce-scatter; an accumulating pass then adds its temporary into the gradient chunk."""
+        w = self._work.pop(b, None)
+        if w is None:
+            return
+        handle, tmp = w
+        if handle is not None:
+            handle.wait()
+        if tmp is not None:
+            bk = self.layout.buckets[b]
+            self.grad_slice[bk["state_offset"]: bk["state_offset"] + bk["chunk"]].add_(tmp[: bk["chunk"]])
+
+    def _flush(self):
+        for b in range(len(self.layout.buckets)):        # buckets with tensors that received no gradient this pass (zeros)
+            if not self._launched[b]:
+                self._stage_for(b)
+                self._reduce(b)
+        for b in sorted(self._work):
+            self._finish(b)
 
     def _stage_for(self, b):
         """Staging buffer of bucket b (waits for the reduction of the bucket that used it before)."""
@@ -163,11 +204,10 @@ class ShardedAdamW:
         if owner != b:
             if owner is not None:
                 if not self._launched[owner]:
-                    raise RuntimeError(f"bucket {b} needs the staging buffer of bucket {owner}, which is still incomplete: "
-                                       "gradients must arrive in the layout's order (order=backward_order(names))")
-                w = self._work.pop(owner, None)
-                if w is not None:
-                    w.wait()
+                    # an older bucket that will never complete in this pass (a trainable tensor without a gradient, a
+                    # custom arrival order): reduce it now, unseen tensors as zeros -- what step() does at the end anyway
+                    self._reduce(owner)
+                self._finish(owner)
             self._stage_owner[slot] = b
             self.staging[slot][: self.layout.buckets[b]["size"]].zero_()       # padding and absent tensors count as zero
         return self.staging[slot]
@@ -187,8 +227,15 @@ class ShardedAdamW:
         for n in sorted((n for n in grads if n in L.offsets), key=lambda n: L.offsets[n][0]):
             b = L.bucket_of[n]
             if self._launched[b]:
-                raise RuntimeError(f"gradient of {n} arrived after its bucket was reduced (order= does not match the backward pass)")
-            self.grad_view(n).copy_(grads[n])
+                raise RuntimeError(f"gradient of {n} arrived after its bucket was reduced: a second backward pass before "
+                                   "step() must be announced with begin_micro_batch() (gradient accumulation), and within a "
+                                   "pass a tensor's gradient may arrive only once per bucket flush")
+            if self.direct and self._micro:                   # accumulating pass on one rank: straight into the chunk
+                if n in self._seen[b]:
+                    raise RuntimeError(f"gradient of {n} arrived twice in one accumulating pass")
+                self.grad_view(n).add_(grads[n])
+            else:
+                self.grad_view(n).copy_(grads[n])
             self._seen[b].add(n)
             if len(self._seen[b]) == len(L.buckets[b]["names"]):
                 self._reduce(b)
@@ -198,11 +245,26 @@ class ShardedAdamW:
         stage = self._stage_for(b)[: bk["size"]]
         dst = self.grad_slice[bk["state_offset"]: bk["state_offset"] + bk["chunk"]]
         if self.world > 1:
-            self._work[b] = dist.reduce_scatter_tensor(dst, stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            tmp = None
+            if self._micro:                                   # accumulating pass: reduce into a temporary, add on completion
+                while len(self._acc_tmp) < 2:
+                    self._acc_tmp.append(torch.empty(max(k["chunk"] for k in self.layout.buckets), dtype=torch.float32,
+                                                     device=self.grad_slice.device))
+                other = [t for _, t in self._work.values() if t is not None]
+                tmp = next((t for t in self._acc_tmp if all(t is not o for o in other)), None)
+                if tmp is None:                               # both temporaries on the wire: finish the older one
+                    self._finish(min(k for k, (_, t) in self._work.items() if t is not None))
+                    other = [t for _, t in self._work.values() if t is not None]
+                    tmp = next(t for t in self._acc_tmp if all(t is not o for o in other))
+                dst = tmp[: bk["chunk"]]
+            self._work[b] = (dist.reduce_scatter_tensor(dst, stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True), tmp)
         elif self.direct:   # `stage` IS `dst`; tensors that received no gradient this step count as zero (the padding never changes)
-            for n in bk["names"]:
-                if n not in self._seen[b]:
-                    self.grad_view(n).zero_()
+            if not self._micro:
+                for n in bk["names"]:
+                    if n not in self._seen[b]:
+                        self.grad_view(n).zero_()
+        elif self._micro:
+            dst.add_(stage[: bk["chunk"]])
         else:
             dst.copy_(stage[: bk["chunk"]])
         self._launched[b] = True
@@ -226,17 +288,13 @@ class ShardedAdamW:
     def step(self):
         """Finish the gradient exchange, update this rank's chunks, refresh ``self.params`` on every rank."""
         L = self.layout
-        for b in range(len(L.buckets)):        # buckets with tensors that received no gradient this step (zeros)
-            if not self._launched[b]:
-                self._stage_for(b)
-                self._reduce(b)
-        for b in sorted(self._work):
-            self._work[b].wait()
-        self._work = {}
+        self._flush()
         sumsq = self.k.sumsq(self.grad_slice)            # fp64 [1] over the SUMS; padding elements are zero
         if self.world > 1:
             dist.all_reduce(sumsq, op=dist.ReduceOp.SUM, group=self.group)
         scale = 1.0 / self.world                          # mean over the data-parallel ranks, like DDP / DeepSpeed
+        if self.average_micro_batches:
+            scale /= self._micro + 1                      # ... and over the accumulated micro-batches (accelerate)
         self.last_grad_norm = sumsq.sqrt() * scale
         self.step_count += 1
         works = []

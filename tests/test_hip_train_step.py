@@ -202,3 +202,80 @@ def test_k_major_operands_give_the_same_gradients(monkeypatch):
                     assert torch.equal(res[0][1][k], res[level][1][k]), f"K_MAJOR {level}, B {B}: {k}"
     finally:
         ops.gemm_set_plan(3)
+
+
+def test_sharded_gradient_accumulation_and_modified_gradient_error():
+    """with sharded=True a second forward_backward before optimizer_step is a further micro-batch
+    (the reference's gradient_accumulation_steps) -- its gradients are ADDED to the optimiser's chunks and the step uses
+    their mean, which equals the per-tensor path stepped on the summed-and-halved gradients; gradients that were
+    modified after forward_backward sank them are refused instead of silently ignored."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd.train_step import DenoiserTrainStep
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    cfg, sd_bf, batch, trainable = _setup(B=1, S_txt=40, h=8, w=12, seed=5)
+    b1 = {k: v.cuda() for k, v in batch.items()}
+    b2 = dict(b1, noise=torch.randn(1, 16, 8, 12, generator=torch.Generator().manual_seed(9)).cuda(),
+              sigmas=torch.tensor([0.5]).cuda())
+    res = []
+    for sharded in (False, True):
+        model = HipFluxTransformer2DModel(cfg, device="cuda")
+        model.load_state_dict(sd_bf)
+        ts = DenoiserTrainStep(model, lr=1e-3, sharded=sharded)
+        l1, g1, _ = ts.forward_backward(**b1)
+        g1 = {k: v.clone() for k, v in g1.items()}
+        l2, g2, _ = ts.forward_backward(**b2)
+        if sharded:
+            ts.optimizer_step(g2)                       # both passes already sit in the optimiser: mean of the two
+        else:
+            ts.optimizer_step({k: ((g1[k].float() + g2[k].float()) / 2).contiguous() for k in g2})
+        res.append((l1.item(), l2.item(), {k: model.p(k).detach().float().cpu() for k in trainable}))
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and res[0][0] != res[0][1]
+    for k in trainable:   # one path sums fp32 casts of bf16 gradients in the chunk, the other on the caller's side: same values
+        assert (res[0][2][k] - res[1][2][k]).abs().max().item() <= 2.0 ** -8 * res[0][2][k].abs().max().item() + 1e-6, k
+    # a gradient the caller scaled after forward_backward had handed it to the buckets
+    model = HipFluxTransformer2DModel(cfg, device="cuda")
+    model.load_state_dict(sd_bf)
+    ts = DenoiserTrainStep(model, lr=1e-3, sharded=True)
+    _, g, _ = ts.forward_backward(**b1)
+    next(iter(g.values())).mul_(0.5)
+    with pytest.raises(RuntimeError, match="not the one forward_backward already handed"):
+        ts.optimizer_step(g)
+
+
+def test_prepared_conditioning_notices_an_optimiser_step():
+    """the prepared all-steps modulation is keyed on the tensors it was prepared from AND on the
+    version stamps of the embedder / modulation weights, so a caller that keeps the prepared timesteps across an optimiser
+    step (torch's, or fk_adamw_step writing through raw pointers) gets fresh conditioning, not the stale rows."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd import flux_spec, ops
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    from test_hip_mmdit import _inputs
+    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=1, num_single_layers=1)
+    m = HipFluxTransformer2DModel(cfg, device="cuda", init="synthetic", seed=5)
+    hs, enc, pooled, _, gd, img_ids, txt_ids = (x.cuda() for x in _inputs(1, 40, 6, 8, cfg, seed=3))
+    steps = torch.tensor([[1.0], [0.5]]).to(BF).cuda()
+    kw = dict(hidden_states=hs, encoder_hidden_states=enc, pooled_projections=pooled, guidance=gd, txt_ids=txt_ids,
+              img_ids=img_ids, return_dict=False)
+    m.prepare_conditioning(steps, gd, pooled)
+    before = m(timestep=steps[1], **kw)[0].clone()
+    assert m._cond is not None
+    w = m.p("single_transformer_blocks.0.norm.linear.weight")
+    with torch.no_grad():
+        w.mul_(1.5)                                     # what a torch optimiser does: an in-place write, version bumped
+    after = m(timestep=steps[1], **kw)[0].clone()
+    assert m._cond is None and not torch.equal(before, after)
+    fresh = m(timestep=steps[1].clone(), **kw)[0]        # on-the-fly conditioning with the new weight
+    assert torch.equal(after, fresh)
+    # the same through fk_adamw_step's raw-pointer write of the bf16 copy
+    m.prepare_conditioning(steps, gd, pooled)
+    assert torch.equal(m(timestep=steps[1], **kw)[0], after) and m._cond is not None
+    b = m.p("single_transformer_blocks.0.norm.linear.bias")
+    master = b.detach().float().contiguous()
+    ops.adamw_step(master, torch.ones_like(master), torch.zeros_like(master), torch.zeros_like(master), 1, 0.5,
+                   param_bf16=b.data, grad_sumsq=None)
+    moved = m(timestep=steps[1], **kw)[0]
+    assert m._cond is None and not torch.equal(moved, after)
+    # ids built afresh every call (the reference's training loop, modeling_univa_denoise_tower.py:73-75) give the same bits
+    assert torch.equal(m(timestep=steps[1].clone(), **dict(kw, txt_ids=txt_ids.clone(), img_ids=img_ids.clone()))[0], moved)

@@ -184,3 +184,45 @@ def test_chat_loop_bookkeeping(tmp_path, monkeypatch):
     assert seen["templates"][1] == [dict(role="user", n=2), dict(role="assistant", n=1), dict(role="user", n=1)]
     assert len(seen["processor"][1][1]) == 2
     assert len(pipe.calls) == 1                                                                       # routed to text
+
+
+def test_chat_accepts_the_processors_second_resize(tmp_path, monkeypatch):
+    """A 4:3 input: ``process_vision_info`` makes it 364 x 504 (area below the 448^2 budget), and the REAL Qwen2-VL image
+    processor -- loaded with min_pixels = max_pixels = 448 * 448 like the reference (cli.py:30-35) -- then scales it up
+    again to 392 x 532 (grid 28 x 38).  The reference goes on silently with that grid; so must this loop."""
+    from transformers import Qwen2VLImageProcessor
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(cli.torch, "Generator", StubGenerator)
+    p1 = _png(tmp_path / "in43.png", 800, 600, 9)
+    image_proc = Qwen2VLImageProcessor(min_pixels=448 * 448, max_pixels=448 * 448)
+    grids = []
+
+    class Batch(dict):
+        __getattr__ = dict.get
+
+        def to(self, device):
+            return self
+
+    class Proc:
+        def apply_chat_template(self, conversation, tokenize=False, add_generation_prompt=True):
+            return "<|im_start|>system\nx<|im_end|>\n<|im_start|>user\ncontent<|im_end|>\n<|im_start|>assistant\n"
+
+        def __call__(self, text, images, padding, return_tensors):
+            assert [im.size for im in images] == [(504, 364)]                   # what vision_inputs hands over
+            feats = image_proc(images=images, return_tensors="pt")
+            grids.append(feats["image_grid_thw"].tolist())
+            return Batch(input_ids=torch.tensor([[5, 6, 7]]), image_grid_thw=feats["image_grid_thw"])
+
+    monkeypatch.setattr(cli, "load_main_model_and_processor",
+                        lambda path, device: (types.SimpleNamespace(vlm=None), object(), Proc()))
+    import gpt_image_edit_amd.prompt_embedding as pe_mod
+    import gpt_image_edit_amd.qwen_adaptor as qa_mod
+    monkeypatch.setattr(qa_mod, "encode_edit_prompt", lambda m, head, inputs, t5, joint_with_t5=True: dict(
+        generate=True, task_logits=None, prompt_embeds=torch.zeros(1, 9, 4)))
+    monkeypatch.setattr(pe_mod, "encode_prompt", lambda enc, toks, text, n, device, k: (torch.zeros(1, n, 4), torch.zeros(1, 8)))
+    answers = iter(["make it night", p1, "", ""])
+    monkeypatch.setattr("builtins.input", lambda prompt="": next(answers))
+    pipe = StubPipe()
+    cli.chat(_args(height=512, width=512), pipe, [None, None], [None, None], "cpu")
+    assert grids == [[[1, 28, 38]]]                                             # 392 x 532: the processor resized again
+    assert len(pipe.calls) == 1 and os.path.isfile(tmp_path / "generate_image_0.png")

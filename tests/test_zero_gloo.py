@@ -77,6 +77,26 @@ def _worker(rank, world, port, q):
         bn = float(bopt.step())                           # the norm is summed chunk by chunk in fp64: other chunks, other order
         assert abs(bn - norms[-1]) <= 1e-12 * norms[-1]
     same = all(torch.equal(opt.params[n], bopt.params[n]) for n in SHAPES)
+    # gradient accumulation (the reference's gradient_accumulation_steps): two backward passes per step, every pass
+    # reduce-scattered and ADDED to the rank's chunks, the step taken on their mean -- equal to one pass of the mean
+    aopt = ShardedAdamW(_params(), max_grad_norm=1.0, kernels=TorchKernels, order=order, bucket_numel=400, **HP)
+    mopt = ShardedAdamW(_params(), max_grad_norm=1.0, kernels=TorchKernels, order=order, bucket_numel=400, **HP)
+    for step in range(2):
+        ga, gb = _grads(rank, step), _grads(rank + 7, step)
+        aopt.begin_micro_batch()                           # first pass of a step: no-op
+        for n in order:
+            aopt.accumulate({n: ga[n]})
+        aopt.begin_micro_batch()
+        for n in order[:-1]:                               # the last tensor gets no gradient in the second pass
+            aopt.accumulate({n: gb[n]})
+        na = float(aopt.step())
+        for n in order:
+            mopt.accumulate({n: (ga[n] + (gb[n] if n != order[-1] else 0)) / 2})
+        nm = float(mopt.step())
+        assert abs(na - nm) <= 1e-6 * nm, (na, nm)
+    for n in SHAPES:
+        torch.testing.assert_close(aopt.params[n].float(), mopt.params[n].float(), rtol=0, atol=2 ** -8 * 0.1)
+        same = same and float((aopt.params[n] == mopt.params[n]).float().mean()) > 0.97
     q.put((rank, {n: p.clone() for n, p in opt.params.items()}, norms, opt.state_bytes(), opt.layout.slice_numel, same))
     dist.barrier()
     dist.destroy_process_group()
@@ -152,8 +172,11 @@ def test_flat_layout_single_process():
     import pytest
     o2.accumulate({order[0]: torch.ones(100, 7)})          # half of bucket 0
     o2.accumulate({order[2]: torch.ones(100, 7), order[3]: torch.ones(100, 7)})   # all of bucket 1: reduced
-    with pytest.raises(RuntimeError, match="incomplete"):
-        o2.accumulate({order[4]: torch.ones(100, 7)})      # bucket 2 wants bucket 0's staging buffer
+    o2.accumulate({order[4]: torch.ones(100, 7)})          # bucket 2 wants bucket 0's staging buffer: bucket 0 is flushed
+    assert o2._launched == [True, True, True]              # ... with zeros for the tensor that never came
+    with pytest.raises(RuntimeError, match="arrived after its bucket was reduced"):
+        o2.accumulate({order[1]: torch.ones(100, 7)})      # too late for this pass
+    o2.step()
     # one rank without staging: gradients are cast straight into the optimiser's gradient chunk; any arrival order, absent
     # tensors count as zero, and the result equals the staged intake bit for bit
     def run(feed, **kw):
@@ -172,3 +195,32 @@ def test_flat_layout_single_process():
         assert torch.equal(staged.params[n], direct.params[n]) and torch.equal(direct.params[n], shuffled.params[n])
     assert torch.equal(direct.params[order[4]], torch.full((100, 7), 0.25, dtype=BF))      # zero gradient: two steps of weight decay stay below bf16 resolution
     assert not torch.equal(direct.params[order[0]], torch.full((100, 7), 0.25, dtype=BF))
+    # gradient accumulation on one rank: the second pass adds into the gradient chunk (direct) / the staged intake adds
+    # the pass's bucket; both equal ONE pass of the summed gradients with average_micro_batches=False
+    def run_acc(two_passes, **kw):
+        o = ShardedAdamW({n: torch.full((100, 7), 0.25, dtype=BF) for n in names}, kernels=TorchKernels, order=order,
+                         bucket_numel=1500, average_micro_batches=False, **kw, **HP)
+        g1 = {n: torch.full((100, 7), 0.5 + i, dtype=torch.float32) for i, n in enumerate(order)}
+        g2 = {n: torch.full((100, 7), -0.125 * (i + 1), dtype=torch.float32) for i, n in enumerate(order[:3])}
+        if two_passes:
+            o.begin_micro_batch()
+            for n in order:
+                o.accumulate({n: g1[n]})
+            o.begin_micro_batch()
+            for n in order[:3]:
+                o.accumulate({n: g2[n]})
+        else:
+            for n in order:
+                o.accumulate({n: g1[n] + g2.get(n, 0)})
+        o.step()
+        assert o._micro == 0
+        return o
+    one = run_acc(False)
+    for o in (run_acc(True), run_acc(True, stage_always=True)):
+        for n in names:
+            assert torch.equal(o.params[n], one.params[n])
+    with pytest.raises(RuntimeError, match="begin_micro_batch"):
+        o = run_acc(False)
+        for n in order:
+            o.accumulate({n: torch.ones(100, 7)})
+        o.accumulate({order[0]: torch.ones(100, 7)})       # a second pass that was not announced
