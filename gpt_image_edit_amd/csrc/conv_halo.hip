@@ -74,7 +74,10 @@ FK_DEV void barrier_keep_dma() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool GN, bool RES>
+// F32OUT (parity build of the same kernel, fk_conv3x3_halo_f32_debug): y = fp32(acc + bias), written straight from the
+// accumulator registers, so the main loop -- halo staging, GroupNorm prologue, tap order -- can be held to an fp32
+// reference at rtol 1e-3 / atol 1e-4 (one bf16 rounding of the output alone is 2^-9 relative).
+template <bool GN, bool RES, bool F32OUT = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -244,6 +247,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloArgs p) 
     barrier_keep_dma();
   }
 
+  if constexpr (F32OUT) {
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 64 + nf * 32 + 8 * q + 4 * fhalf;
+        const u32x2_t bw = *(const u32x2_t*)(p.bias + min(n, p.Cout - 4));
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) {
+          const int pix = wm * 64 + mf * 32 + frow;
+          const int oy = y0 + (pix >> 4), ox = x0 + (pix & 15);
+          if (oy < p.H && ox < p.W && n < p.Cout)
+            *(f32x4_t*)((float*)p.y + (((int64_t)b * p.H + oy) * p.W + ox) * p.Cout + n) =
+                f32x4_t{acc[nf][mf][4 * q + 0] + bf_lo(bw[0]), acc[nf][mf][4 * q + 1] + bf_hi(bw[0]),
+                        acc[nf][mf][4 * q + 2] + bf_lo(bw[1]), acc[nf][mf][4 * q + 3] + bf_hi(bw[1])};
+        }
+      }
+    return;
+  }
   // ---- epilogue: bias -> bf16 -> LDS C tile -> (+ residual) -> 16-byte NHWC rows ---------------------------------------------
   bf16_t* ct = (bf16_t*)smem;   // aliases the halo buffers: every wave is past the last step's barrier
 #pragma unroll
@@ -284,9 +306,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloArgs p) 
   }
 }
 
-template <bool GN, bool RES>
+template <bool GN, bool RES, bool F32OUT = false>
 int launch_halo(const HaloArgs& p, hipStream_t stream) {
-  auto kern = conv3x3_halo_kernel<GN, RES>;
+  auto kern = conv3x3_halo_kernel<GN, RES, F32OUT>;
   FK_ENSURE_MAX_LDS(kern, SMEM_BYTES, "fk_conv3x3_halo_bf16");
   const int grid = p.B * p.tiles_y * p.tiles_x * p.tiles_n;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SMEM_BYTES, stream, p);
@@ -296,8 +318,8 @@ int launch_halo(const HaloArgs& p, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int fk_conv3x3_halo_bf16(const fk_conv_args* args, const float* gn_stats, const void* gn_gamma,
-                                    const void* gn_beta, int32_t gn_groups, int32_t gn_silu, fk_stream_t stream_) {
+static int conv3x3_halo_entry(const fk_conv_args* args, const float* gn_stats, const void* gn_gamma, const void* gn_beta,
+                              int32_t gn_groups, int32_t gn_silu, bool f32out, fk_stream_t stream_) {
   FK_CHECK_ARG(args != nullptr, "fk_conv3x3_halo_bf16: null args");
   const fk_conv_args& a = *args;
   FK_CHECK_ARG(a.x && a.w && a.y && a.bias, "fk_conv3x3_halo_bf16: null x / w / bias / y");
@@ -326,6 +348,20 @@ extern "C" int fk_conv3x3_halo_bf16(const fk_conv_args* args, const float* gn_st
   p.ldw = (9 * a.Cin + 63) / 64 * 64;
   FK_CHECK_ARG((int64_t)BN * p.ldw * 2 < (1ll << 31), "fk_conv3x3_halo_bf16: weight slice too large");
   hipStream_t stream = (hipStream_t)stream_;
+  if (f32out) {
+    FK_CHECK_ARG(!a.res, "fk_conv3x3_halo_f32_debug: no residual in the parity build");
+    return gn ? launch_halo<true, false, true>(p, stream) : launch_halo<false, false, true>(p, stream);
+  }
   if (gn) return a.res ? launch_halo<true, true>(p, stream) : launch_halo<true, false>(p, stream);
   return a.res ? launch_halo<false, true>(p, stream) : launch_halo<false, false>(p, stream);
+}
+
+extern "C" int fk_conv3x3_halo_bf16(const fk_conv_args* args, const float* gn_stats, const void* gn_gamma,
+                                    const void* gn_beta, int32_t gn_groups, int32_t gn_silu, fk_stream_t stream_) {
+  return conv3x3_halo_entry(args, gn_stats, gn_gamma, gn_beta, gn_groups, gn_silu, false, stream_);
+}
+
+extern "C" int fk_conv3x3_halo_f32_debug(const fk_conv_args* args, const float* gn_stats, const void* gn_gamma,
+                                         const void* gn_beta, int32_t gn_groups, int32_t gn_silu, fk_stream_t stream_) {
+  return conv3x3_halo_entry(args, gn_stats, gn_gamma, gn_beta, gn_groups, gn_silu, true, stream_);
 }

@@ -65,6 +65,10 @@ FK_DEV int64_t fk_row_offset(const fk_rows& r, int64_t m) {
   return b * r.batch_stride + (m - b * r.rows_per_batch) * r.ld;
 }
 
+// internal epilogue of the large-tile GEMM kernels: fk_gemm_args.out_fp32 == 2 (parity build of the SAME main loops:
+// C = fp32(acc + bias), written straight from the accumulator registers; tests hold it to rtol 1e-3 / atol 1e-4)
+constexpr int FK_EPI_F32DBG = 64;
+
 // internal: returned by fk_gemm2_launch when a 256-row tile's rows are not addressable with 32-bit byte offsets
 constexpr int FK_E2BIG_STRIDES = -100;
 int fk_gemm2_launch(const fk_gemm_args* probs, int n, int bn_hint, hipStream_t stream);  // gemm_pingpong_bf16.hip

@@ -284,6 +284,11 @@ static int validate_gemm(const fk_gemm_args& p) {
   FK_CHECK_ARG(((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.W % 16 == 0) && ((uintptr_t)p.C % 16 == 0),
                "fk_gemm_bf16: A/W/C must be 16-byte aligned");
   FK_CHECK_ARG(p.a.rows_per_batch <= 0 || p.a.batch_stride % 8 == 0, "fk_gemm_bf16: A batch stride % 8");
+  if (p.out_fp32 == 2) {   // parity build of the large-tile kernels: fp32(acc + bias), 16-byte row pieces
+    FK_CHECK_ARG(p.epilogue == FK_EPI_NONE && p.layout == 0 && p.N % 8 == 0 && p.c.ld % 4 == 0 &&
+                     (p.c.rows_per_batch <= 0 || p.c.batch_stride % 4 == 0) && (!p.bias || ((uintptr_t)p.bias % 8 == 0)),
+                 "fk_gemm_bf16: out_fp32 = 2 needs epilogue none, layout 0, N %% 8 == 0 and ldc %% 4 == 0");
+  }
   if (!p.out_fp32) {
     FK_CHECK_ARG(p.N % 8 == 0, "fk_gemm_bf16: N=%d must be a multiple of 8 for bf16 output", p.N);
     FK_CHECK_ARG(p.c.ld % 8 == 0 && (p.c.rows_per_batch <= 0 || p.c.batch_stride % 8 == 0),
@@ -359,6 +364,14 @@ extern "C" int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream_) {
     const int rc2 = fk_gemm2_launch(&p, 1, 0, stream);
     if (rc2 == FK_E2BIG_STRIDES) {
       fk_set_error("fk_gemm_bf16: layout %d needs row strides that keep a 256-row tile within 2 GiB", p.layout);
+      return FK_EUNSUPPORTED;
+    }
+    return rc2;
+  }
+  if (p.out_fp32 == 2) {   // the large-tile kernels' own main loops with an fp32 epilogue (launch form: plan / set_variant)
+    const int rc2 = fk_gemm2_launch(&p, 1, gemm_bn_override(), stream);
+    if (rc2 == FK_E2BIG_STRIDES) {
+      fk_set_error("fk_gemm_bf16: out_fp32 = 2 needs row strides that keep a 256-row tile within 2 GiB");
       return FK_EUNSUPPORTED;
     }
     return rc2;

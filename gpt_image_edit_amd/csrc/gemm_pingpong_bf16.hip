@@ -201,6 +201,25 @@ FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& 
         }
     }
   }
+  if constexpr (EPI == FK_EPI_F32DBG) {
+    // parity build: fp32(acc + bias) straight from the accumulator registers (a lane owns 4 consecutive columns of a row)
+#pragma unroll
+    for (int nf = 0; nf < C::NF; ++nf)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + C::tile_col(wn, nf) + 8 * q + 4 * fhalf;
+        const float b[4] = {bf_lo(bw[nf][q][0]), bf_hi(bw[nf][q][0]), bf_lo(bw[nf][q][1]), bf_hi(bw[nf][q][1])};
+#pragma unroll
+        for (int mf = 0; mf < C::MF; ++mf) {
+          const int m = m0 + C::tile_row(wm, mf) + frow;
+          if (m < p.M && n < p.N)
+            *(f32x4_t*)((float*)p.C + fk_row_offset(p.c, m) + n) =
+                f32x4_t{acc[nf][mf][4 * q + 0] + b[0], acc[nf][mf][4 * q + 1] + b[1], acc[nf][mf][4 * q + 2] + b[2],
+                        acc[nf][mf][4 * q + 3] + b[3]};
+        }
+      }
+    return;
+  }
   __syncthreads();  // every wave is done reading the last stage before the C tile aliases it
   bf16_t* ct = (bf16_t*)smem;
 #pragma unroll
@@ -1076,7 +1095,8 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int variant_hint, hipStrea
   }
   g_last_variant = plan.variant;
   int rc;
-  switch (probs[0].epilogue) {
+  switch (probs[0].out_fp32 == 2 ? FK_EPI_F32DBG : probs[0].epilogue) {
+    case FK_EPI_F32DBG: rc = launch_variant<FK_EPI_F32DBG>(ga, probs, n, plan.variant, plan.big_cols, stream); break;
     case FK_EPI_NONE: rc = launch_variant<FK_EPI_NONE>(ga, probs, n, plan.variant, plan.big_cols, stream); break;
     case FK_EPI_GELU_TANH: rc = launch_variant<FK_EPI_GELU_TANH>(ga, probs, n, plan.variant, plan.big_cols, stream); break;
     case FK_EPI_SILU: rc = launch_variant<FK_EPI_SILU>(ga, probs, n, plan.variant, plan.big_cols, stream); break;

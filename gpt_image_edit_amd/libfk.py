@@ -92,6 +92,7 @@ SIGNATURES = {
     "fk_softmax_rows": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp]),
     "fk_conv2d_nhwc_bf16": (c_i32, [ctypes.POINTER(ConvArgs), c_vp]),
     "fk_conv3x3_halo_bf16": (c_i32, [ctypes.POINTER(ConvArgs), c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "fk_conv3x3_halo_f32_debug": (c_i32, [ctypes.POINTER(ConvArgs), c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "fk_groupnorm_ws_floats": (c_i64, [c_i32, c_i64, c_i32]),
     "fk_groupnorm_stats_nhwc_bf16": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_f32, c_vp]),
     "fk_groupnorm_apply_nhwc_bf16": (c_i32, [c_vp] * 5 + [c_i32, c_i64, c_i32, c_i32, c_i32, c_vp]),

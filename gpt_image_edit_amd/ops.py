@@ -119,7 +119,7 @@ def _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv=None, 
         args.gate_rows_per_batch = a.shape[1]
     args.M, args.N, args.K = M, N, K
     args.epilogue, args.out_fp32, args.alpha = epilogue, int(out_fp32), float(alpha)
-    if K >= 6144 and N % 256 == 0 and M <= 256 * SPLITK_SLOTS and not out_fp32 and layout == 0:   # the only shapes the planner may split
+    if K >= 6144 and N % 256 == 0 and M <= 256 * SPLITK_SLOTS and int(out_fp32) != 1 and layout == 0:   # the only shapes the planner may split
         ws, slots = splitk_workspace(a.device)
         args.splitk_ws, args.splitk_slots = ws.data_ptr(), slots
     if epilogue == FK_EPI_QKV:
@@ -136,6 +136,10 @@ def _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv=None, 
 
 def gemm(a, w, bias=None, out=None, epilogue=FK_EPI_NONE, res=None, gate=None, out_fp32=False, alpha=1.0, qkv=None, layout=0):
     """out = epilogue(a @ w.T + bias).  a: [M,K] / [B,R,K] view; w: [N,K]; out likewise (may alias res).
+
+    out_fp32: True / 1 = fp32(acc + bias) by the 128 x 128 register-staged kernel; 2 = the same from the LARGE-TILE kernels'
+    own main loops (256 x 256 / 256 x 128 / mixed / split-K, whichever the launch plan or ``gemm_set_variant`` selects) --
+    the parity build that holds the kernels carrying the FLOPs to rtol 1e-3 / atol 1e-4.
 
     layout (fk_gemm_args.layout): 1 = ``w`` is [K, N] and out = a @ w (the data gradient reads the weight as stored);
     2 = ``a`` is [K, M] / [B, R, M] and ``w`` [K, N] / [B, R, N], out [M, N] = a^T @ w (the weight gradient reads both
@@ -563,7 +567,7 @@ def group_norm_stats(x, eps=1e-6):
     return stats
 
 
-def conv3x3_halo(x, w_packed, bias, cout, upsample2x=False, res=None, gn=None, out=None):
+def conv3x3_halo(x, w_packed, bias, cout, upsample2x=False, res=None, gn=None, out=None, out_fp32=False):
     """3 x 3 / stride 1 / pad 1 convolution over NHWC bf16 by the LDS halo-tiled kernel (csrc/conv_halo.hip), optionally
     with GroupNorm(32) (+ SiLU) of the INPUT applied while the halo tile is staged: ``gn = (stats, gamma, beta, silu)``
     with ``stats`` from :func:`group_norm_stats`.  Cin % 64 == 0."""
@@ -571,7 +575,9 @@ def conv3x3_halo(x, w_packed, bias, cout, upsample2x=False, res=None, gn=None, o
     B, Hin, Win, Cin = x.shape
     Hout, Wout = (Hin * 2, Win * 2) if upsample2x else (Hin, Win)
     if out is None:
-        out = torch.empty((B, Hout, Wout, cout), device=x.device, dtype=BF16)
+        out = torch.empty((B, Hout, Wout, cout), device=x.device, dtype=torch.float32 if out_fp32 else BF16)
+    if out.dtype != (torch.float32 if out_fp32 else BF16) or not out.is_contiguous():
+        raise TypeError("conv3x3_halo: out must be a contiguous bf16 tensor (fp32 with out_fp32: the parity build)")
     if not x.is_contiguous() or (res is not None and not res.is_contiguous()):
         raise ValueError("conv3x3_halo needs contiguous NHWC tensors")
     a = libfk.ConvArgs()
@@ -582,8 +588,8 @@ def conv3x3_halo(x, w_packed, bias, cout, upsample2x=False, res=None, gn=None, o
     a.Hout, a.Wout = Hout, Wout
     stats, gamma, beta, silu = gn if gn is not None else (None, None, None, False)
     _need_cuda(stats, gamma, beta)
-    libfk.check(libfk.load().fk_conv3x3_halo_bf16(ctypes.byref(a), _ptr(stats), _ptr(gamma), _ptr(beta), 32, int(bool(silu)),
-                                                  _stream()), "fk_conv3x3_halo_bf16")
+    fn = libfk.load().fk_conv3x3_halo_f32_debug if out_fp32 else libfk.load().fk_conv3x3_halo_bf16
+    libfk.check(fn(ctypes.byref(a), _ptr(stats), _ptr(gamma), _ptr(beta), 32, int(bool(silu)), _stream()), "fk_conv3x3_halo_bf16")
     return out
 
 

@@ -76,7 +76,9 @@ typedef struct fk_gemm_args {
   const void* A; fk_rows a;
   const void* W; int64_t ldw;
   const void* bias;              /* bf16 [N] or NULL */
-  void* C; fk_rows c;            /* bf16, or fp32 when out_fp32 (debug/parity: acc + bias only) */
+  void* C; fk_rows c;            /* bf16, or fp32 when out_fp32 (debug/parity: acc + bias only; out_fp32 = 1: the 128 x 128
+                                  * register-staged kernel, 2: the large-tile kernels' own main loops -- 256 x 256, 256 x 128,
+                                  * mixed grid, split-K pairs, as the launch plan / fk_gemm_set_variant selects) */
   const void* res; fk_rows r;    /* FK_EPI_GATE_RES / FK_EPI_RES */
   const void* gate;              /* bf16, gate row b at gate + b*gate_batch_stride; b = m / gate_rows_per_batch */
   int64_t gate_batch_stride;
@@ -332,6 +334,10 @@ int fk_conv2d_nhwc_bf16(const fk_conv_args* args, fk_stream_t stream);
  * so the normalised activation is never written to memory.  args->res: y = bf16(res + y).  args->upsample2x as above. */
 int fk_conv3x3_halo_bf16(const fk_conv_args* args, const float* gn_stats, const void* gn_gamma, const void* gn_beta,
                          int32_t gn_groups, int32_t gn_silu, fk_stream_t stream);
+/* Parity build of the same kernel: args->y is fp32 [B, Hout, Wout, Cout] = acc + bias (no residual, no output rounding),
+ * so that the halo staging / GroupNorm prologue / tap loop can be held to an fp32 reference at rtol 1e-3 / atol 1e-4. */
+int fk_conv3x3_halo_f32_debug(const fk_conv_args* args, const float* gn_stats, const void* gn_gamma, const void* gn_beta,
+                              int32_t gn_groups, int32_t gn_silu, fk_stream_t stream);
 
 /* GroupNorm(32 groups, eps) statistics: stats[b, g] = (mean, rstd) fp32; ws: fp32 workspace of
  * fk_groupnorm_ws_floats(B, HW, C) floats. */

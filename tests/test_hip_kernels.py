@@ -59,6 +59,45 @@ def test_gemm_fp32_out(ops, M, N, K):
     torch.testing.assert_close(got.cpu(), ref, rtol=1e-3, atol=1e-4)
 
 
+# the five M = 2560 launch classes of the 512^2 edit + the M = 8704 MLP-up shape, on the kernels that carry the FLOPs
+HOT_SHAPES = [(2560, 9216, 3072, "fused QKV"), (2560, 12288, 3072, "MLP up"), (2560, 3072, 12288, "MLP down"),
+              (2560, 3072, 15360, "single proj_out"), (2560, 3072, 3072, "out projection"), (8704, 12288, 3072, "MLP up @1024^2")]
+
+
+@pytest.mark.parametrize("M,N,K,what", HOT_SHAPES)
+def test_hot_gemm_kernels_at_the_stated_tolerance(ops, M, N, K, what):
+    """BASELINE.json's tolerance (rtol 1e-3 / atol 1e-4) on the kernels that carry 99 % of the GEMM time: the fp32-output
+    build of gemm8 / gemm9 / gemm_mix / split-K gemm8 (fk_gemm_args.out_fp32 = 2: the SAME main loops, fp32(acc + bias)
+    stored from the accumulator registers) against a.float() @ w.float().T in fp64-accumulated fp32 on the host --
+    every launch form that applies to the shape, and the form the launch plan picks by itself."""
+    from gpt_image_edit_amd import libfk
+    lib = libfk.load()
+    a, w, bias = randn(M, K, seed=71), randn(N, K, seed=72, scale=0.05), randn(N, seed=73, scale=0.1)
+    ref = (a.double() @ w.double().T + bias.double()).float()
+    ad, wd, bd = a.cuda(), w.cuda(), bias.cuda()
+    seen = {}
+    try:
+        for force in (0, 128, 256, 384, 512):
+            lib.fk_gemm_set_variant(force)
+            got = ops.gemm(ad, wd, bd, out_fp32=2)
+            torch.cuda.synchronize()
+            v = lib.fk_gemm_last_variant()
+            if v in seen and force != 0:
+                continue                      # the forced form does not apply to this shape (fell back to one already checked)
+            d = report(f"hot gemm f32 [{what}] {M}x{N}x{K} force={force} -> variant {v}", got, ref)
+            torch.testing.assert_close(got.cpu(), ref, rtol=1e-3, atol=1e-4)
+            if v in seen:
+                assert torch.equal(got, seen[v])
+            seen.setdefault(v, got)
+    finally:
+        lib.fk_gemm_set_variant(0)
+    assert {128, 256} <= set(seen)
+    if K >= 6144:
+        assert 512 in seen                   # the split-K pair form ran (M = 2560, N = 3072: 120 tiles)
+    # 128 / 256 / mixed accumulate over K in the same order: identical fp32 bits; the split-K pair adds two half sums
+    assert torch.equal(seen[128], seen[256]) and (384 not in seen or torch.equal(seen[384], seen[256]))
+
+
 def test_gemm_layout_is_transpose_detecting(ops):
     # A = identity-like selector with an asymmetric W: catches row/col swaps of the MFMA C layout
     M = N = 128

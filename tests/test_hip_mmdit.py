@@ -64,10 +64,75 @@ def test_mmdit_forward_matches_oracle(n_double, n_single, B, S_txt, h, w):
     d_32 = report(tag + " vs fp32-oracle", out, ref32)
     d_ref = report(tag + " bf16-oracle vs fp32-oracle (round-off floor)", ref_bf, ref32)
     scale = ref32.abs().max().item()
-    # the HIP path must be as close to the exact result as the reference's own bf16 execution is
-    assert d_32.max().item() <= max(2.0 * d_ref.max().item(), 2e-2 * scale)
-    assert d_32.mean().item() <= max(2.0 * d_ref.mean().item(), 2e-3 * scale)
-    assert d_bf.max().item() <= 4e-2 * scale
+    # the HIP path must be as close to the exact result as the reference's own bf16 execution is -- relative to that
+    # floor only, no absolute arm (round 3 logs: mean within 1 % of the floor's, max 0.9-1.13 x the floor's)
+    assert d_32.max().item() <= 1.25 * d_ref.max().item()
+    assert d_32.mean().item() <= 1.1 * d_ref.mean().item()
+    assert d_bf.max().item() <= 1.25 * d_ref.max().item()       # and no further from the bf16 oracle than that is from fp32
+
+
+class _StreamedState:
+    """The oracle's state dict for a model too deep to copy: every access reads ONE tensor back from the HIP model's own
+    parameters (``model.state_dict()`` holds references to the device tensors) and converts it, so the host never holds
+    more than the tensors of the block being evaluated (fp32 full depth would be 47.6 GB)."""
+
+    def __init__(self, device_state, dtype):
+        self.sd, self.dtype = device_state, dtype
+
+    def __getitem__(self, k):
+        return self.sd[k].detach().to("cpu").to(self.dtype)
+
+    def get(self, k, default=None):
+        return self[k] if k in self.sd else default
+
+    def __contains__(self, k):
+        return k in self.sd
+
+
+def test_full_depth_mmdit_matches_block_streamed_oracle():
+    """the real 19 + 38-block HipFluxTransformer2DModel (full width, every block its own weights) at
+    S = 640 (128 text + 16 x 16 target + 16 x 16 condition tokens) against ``oracle.mmdit.flux_forward`` run block-streamed
+    on the host in fp32 (exact arithmetic on the bf16-rounded weights) and in bf16 (the reference's rounding points).
+    Error growth over 57 residual blocks is held to the bf16 oracle's own distance from fp32 -- no absolute arm.
+    Matches flux_pipeline.py:1067-1077 at full depth."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import time
+    from gpt_image_edit_amd import flux_spec
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    from oracle import mmdit
+    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG)
+    assert cfg["num_layers"] == 19 and cfg["num_single_layers"] == 38
+    model = HipFluxTransformer2DModel(cfg, device="cuda", init="synthetic", seed=17)
+    hs, enc, pooled, t, gd, img_ids, txt_ids = _inputs(1, 128, 16, 16, cfg, seed=6)
+    out = model(hidden_states=hs.cuda(), timestep=t.cuda(), guidance=gd.cuda(), pooled_projections=pooled.cuda(),
+                encoder_hidden_states=enc.cuda(), txt_ids=txt_ids.cuda(), img_ids=img_ids.cuda(),
+                joint_attention_kwargs={}, return_dict=False)[0]
+    out2 = model(hidden_states=hs.cuda(), timestep=t.cuda(), guidance=gd.cuda(), pooled_projections=pooled.cuda(),
+                 encoder_hidden_states=enc.cuda(), txt_ids=txt_ids.cuda(), img_ids=img_ids.cuda(), return_dict=False)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    out = out.cpu()
+    assert out.shape == (1, 512, 64) and torch.isfinite(out.float()).all()
+    dev_sd = model.state_dict()
+    t0 = time.time()
+    ref32, inter32 = mmdit.flux_forward(_StreamedState(dev_sd, torch.float32), hs.float(), enc.float(), pooled.float(), t,
+                                        img_ids, txt_ids, gd, config=cfg, return_intermediates=True)
+    t1 = time.time()
+    ref_bf, inter_bf = mmdit.flux_forward(_StreamedState(dev_sd, BF), hs, enc, pooled, t, img_ids, txt_ids, gd, config=cfg,
+                                          return_intermediates=True)
+    print(f"[parity] full-depth oracle on the host: fp32 {t1 - t0:.1f} s, bf16 {time.time() - t1:.1f} s", flush=True)
+    # how the bf16 execution drifts from the exact one over the 57 residual blocks (the floor the HIP path is held to)
+    for name in ("double0.h", "double9.h", "double18.h", "single0.s", "single18.s", "single37.s"):
+        a, b = inter_bf[name].float(), inter32[name]
+        print(f"[parity] floor growth {name:10s}: bf16-oracle vs fp32-oracle max {(a - b).abs().max().item():.3e} "
+              f"mean {(a - b).abs().mean().item():.3e} at scale {b.abs().max().item():.2f}", flush=True)
+    d_bf = report("mmdit d19s38 (full depth) vs bf16-oracle", out, ref_bf)
+    d_32 = report("mmdit d19s38 (full depth) vs fp32-oracle", out, ref32)
+    d_ref = report("mmdit d19s38 (full depth) bf16-oracle vs fp32-oracle (round-off floor)", ref_bf, ref32)
+    assert d_32.max().item() <= 1.25 * d_ref.max().item()
+    assert d_32.mean().item() <= 1.1 * d_ref.mean().item()
+    assert d_bf.max().item() <= 1.25 * d_ref.max().item() and d_bf.mean().item() <= 1.1 * d_ref.mean().item()
 
 
 def test_forward_outputs_do_not_alias():

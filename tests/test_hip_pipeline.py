@@ -52,10 +52,55 @@ def test_edit_matches_oracle_pipeline():
     d_i32 = report("edit image vs fp32-oracle", out.images, ref32["image"])
     fl_i = report("edit image bf16-oracle vs fp32-oracle (floor)", ref["image"], ref32["image"])
     assert out.images.shape == (B, 3, H, W)
-    sl, si = ref32["latents"].abs().max().item(), ref32["image"].abs().max().item()
-    assert d_l32.max().item() <= max(2.5 * fl_l.max().item(), 3e-2 * sl)
-    assert d_i32.max().item() <= max(2.5 * fl_i.max().item(), 5e-2 * si)
-    assert d_l.max().item() <= 6e-2 * sl
+    # relative to the bf16 oracle's own distance from the exact result only (no absolute arm)
+    assert d_l32.max().item() <= 1.25 * fl_l.max().item() and d_l32.mean().item() <= 1.1 * fl_l.mean().item()
+    assert d_i32.max().item() <= 1.25 * fl_i.max().item() and d_i32.mean().item() <= 1.1 * fl_i.mean().item()
+    assert d_l.max().item() <= 1.25 * fl_l.max().item()
+
+
+def test_28_step_edit_matches_oracle_pipeline():
+    """the reference's default step count (28, cli.py:278) through the whole HIP edit -- condition encode,
+    28 x (MMDiT + Euler) on a full-width 2 + 2-block model, decode -- against the oracle pipeline in fp32 and bf16: the
+    error accumulated over 28 Euler steps stays within the bf16 oracle's own distance from the exact result."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd import flux_spec
+    from gpt_image_edit_amd.pipeline import FluxKontextPipeline
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    from gpt_image_edit_amd.vae import HipAutoencoderKL
+    from oracle import pipeline as opipe
+    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=2, num_single_layers=2)
+    sd_f = {k: v.to(BF) for k, v in flux_spec.synthetic_state(flux_spec.flux_param_shapes(cfg), seed=31).items()}
+    sd_v = {k: v.to(BF) for k, v in flux_spec.synthetic_state(flux_spec.vae_param_shapes(), seed=32).items()}
+    tr = HipFluxTransformer2DModel(cfg, device="cuda"); tr.load_state_dict(sd_f)
+    vae = HipAutoencoderKL(device="cuda"); vae.load_state_dict(sd_v)
+    pipe = FluxKontextPipeline(tr, vae)
+    g = torch.Generator().manual_seed(11)
+    B, H, W, steps = 1, 128, 128, 28
+    cond = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    emb = torch.randn(B, 48, 4096, generator=g).to(BF)
+    pooled = torch.randn(B, 768, generator=g).to(BF)
+    noise = torch.randn(B, 16, H // 8, W // 8, generator=g).to(BF)
+    out = pipe(image=cond.cuda(), prompt_embeds=emb.cuda(), pooled_prompt_embeds=pooled.cuda(), height=H, width=W,
+               num_inference_steps=steps, guidance_scale=3.5, latents=pipe._pack_latents(noise, B, 16, H // 8, W // 8).cuda(),
+               output_type="pt_raw", max_area=H * W, _auto_resize=False)
+    ref = opipe.kontext_edit(sd_f, sd_v, cond, emb, pooled, noise, H, W, num_inference_steps=steps, guidance_scale=3.5,
+                             flux_config=cfg)
+    ref32 = opipe.kontext_edit({k: v.float() for k, v in sd_f.items()}, {k: v.float() for k, v in sd_v.items()},
+                               cond.to(BF).float(), emb.float(), pooled.float(), noise.float(), H, W,
+                               num_inference_steps=steps, guidance_scale=3.5, flux_config=cfg)
+    for i in (0, 6, 13, 20, 27):
+        a, b = ref["per_step"][i].float(), ref32["per_step"][i]
+        print(f"[parity] 28-step floor growth, step {i:2d}: bf16-oracle vs fp32-oracle max {(a - b).abs().max().item():.3e} "
+              f"mean {(a - b).abs().mean().item():.3e}", flush=True)
+    d_l = report("28-step edit latents vs bf16-oracle", out.latents, ref["latents"])
+    d_l32 = report("28-step edit latents vs fp32-oracle", out.latents, ref32["latents"])
+    fl_l = report("28-step edit latents bf16-oracle vs fp32-oracle (floor)", ref["latents"], ref32["latents"])
+    d_i32 = report("28-step edit image vs fp32-oracle", out.images, ref32["image"])
+    fl_i = report("28-step edit image bf16-oracle vs fp32-oracle (floor)", ref["image"], ref32["image"])
+    assert d_l32.max().item() <= 1.25 * fl_l.max().item() and d_l32.mean().item() <= 1.1 * fl_l.mean().item()
+    assert d_i32.max().item() <= 1.25 * fl_i.max().item() and d_i32.mean().item() <= 1.1 * fl_i.mean().item()
+    assert d_l.max().item() <= 1.25 * fl_l.max().item()
 
 
 def test_full_size_properties():

@@ -107,6 +107,37 @@ def test_conv3x3_halo(cin, cout, h, w, mode):
     assert (u2 > 1).float().mean().item() < 1e-3 and (u2 == 0).float().mean().item() > 0.9
 
 
+@pytest.mark.parametrize("cin,cout,h,w,mode", [(512, 512, 32, 32, "gn"), (512, 512, 16, 16, "up"), (256, 128, 40, 24, "gn"),
+                                               (128, 128, 64, 64, "plain")])
+def test_conv3x3_halo_at_the_stated_tolerance(cin, cout, h, w, mode):
+    """The fp32-output build of conv3x3_halo_kernel (fk_conv3x3_halo_f32_debug: same halo staging, GroupNorm + SiLU
+    prologue and tap loop, fp32(acc + bias) stored from the accumulator registers) against F.conv2d in fp64 on the SAME
+    bf16 normalised activation: rtol 1e-3 / atol 1e-4 (BASELINE.json) on the VAE decoder's channel widths."""
+    _skip()
+    from gpt_image_edit_amd import ops
+    from gpt_image_edit_amd.vae import _pack_conv
+    B = 1
+    x = (randn(B, cin, h, w, seed=21, scale=1.3).float() + torch.linspace(-1, 1, cin)[None, :, None, None]).to(BF)
+    wt = randn(cout, cin, 3, 3, seed=22, scale=0.02)
+    bias = randn(cout, seed=23, scale=0.1)
+    gamma, beta = (1 + randn(cin, seed=24, scale=0.1).float()).to(BF), randn(cin, seed=25, scale=0.1)
+    gn, up = "gn" in mode, "up" in mode
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = _pack_conv(wt.cuda())
+    gn_arg = (ops.group_norm_stats(x_nhwc), gamma.cuda(), beta.cuda(), True) if gn else None
+    got = ops.conv3x3_halo(x_nhwc, wp, bias.cuda(), cout, upsample2x=up, gn=gn_arg, out_fp32=True)
+    # the operand the kernel multiplies: the HIP GroupNorm-apply kernel's output (parity-tested on its own, same rounding points)
+    xn = ops.group_norm_nhwc(x_nhwc, gamma.cuda(), beta.cuda(), True) if gn else x_nhwc
+    torch.cuda.synchronize()
+    xin = xn.permute(0, 3, 1, 2).cpu().double()
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, wt.double(), bias.double(), padding=1).float()
+    g = got.permute(0, 3, 1, 2).cpu()
+    report(f"conv3x3_halo f32 {mode} {cin}->{cout} {h}x{w}", g, ref)
+    torch.testing.assert_close(g, ref, rtol=1e-3, atol=1e-4)
+
+
 @pytest.mark.parametrize("C,hw,silu", [(128, 33 * 17, True), (512, 64, False), (256, 4096, True)])
 def test_group_norm(C, hw, silu):
     _skip()
