@@ -68,7 +68,7 @@ def build_pipeline(device, n_double=19, n_single=38):
     cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=n_double, num_single_layers=n_single)
     tr = HipFluxTransformer2DModel(cfg, device=device, init="synthetic", seed=0)
     vae = HipAutoencoderKL(device=device, init="synthetic", seed=1)
-    return FluxKontextPipeline(tr, vae)
+    return FluxKontextPipeline(tr, vae)      # FK_GRAPH=1: the denoise loop of every edit as one hipGraph launch
 
 
 def make_inputs(workload, device, seed, batch=None):
@@ -98,6 +98,7 @@ def instrumented_edit(pipe, inp):
     against the roofline -- when nothing else shares the chip with it."""
     from gpt_image_edit_amd import ops, transformer
     overlap, transformer.OVERLAP_MLP = transformer.OVERLAP_MLP, False
+    use_graph, pipe.use_graph = pipe.use_graph, False      # per-launch brackets need the eager loop
     rec = {"gemm": [], "attention": [], "conv": []}
     st = torch.cuda.current_stream()
 
@@ -142,6 +143,7 @@ def instrumented_edit(pipe, inp):
     finally:
         ops.gemm, ops.gemm_grouped, ops.attention, ops.conv2d_nhwc, ops.conv3x3_halo = orig
         transformer.OVERLAP_MLP = overlap
+        pipe.use_graph = use_graph
     out = {}
     for fam, lst in rec.items():
         ms = sum(e0.elapsed_time(e1) for _, e0, e1 in lst)
@@ -385,6 +387,7 @@ def timed_edits(pipe, inp, steps, warmup, world, device, backend):
     t0 = time.perf_counter()
     for _ in range(steps):
         out = one_step()
+    timed_edits.host_enqueue_s = (time.perf_counter() - t0) / steps   # the host is done enqueueing; the GPU may still be working
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -458,6 +461,9 @@ def main():
                    "height": inp["H"], "width": inp["W"], "S_txt": inp["S_txt"], "S_tgt": inp["S_tgt"],
                    "S_cond": inp["S_cond"], "seq_len": S, "num_inference_steps": 28, "guidance_scale": 3.5,
                    "blocks": "19 double + 38 single", "parallelism": f"dp{world}"},
+        "host": {"enqueue_ms_per_step": timed_edits.host_enqueue_s * 1e3, "denoise_loop_as_hipgraph": bool(pipe.use_graph),
+                 "note": "wall time the host needs to enqueue one edit (it runs ahead of the GPU unless the launch queue is full); "
+                         "FK_GRAPH=1 replaces the ~5 400 launches of the denoise loop by one graph launch"},
         "dist": {"world_size": dist.get_world_size() if world > 1 else 1,
                  "backend": (dist.get_backend() + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else "none (single process)",
                  "collective": "one all_gather_into_tensor of the packed final latents per step" if world > 1 else None},

@@ -16,6 +16,7 @@ Pixels either side of the path: ``image_processo
 diffusers helper the reference pipeline calls; uint8 pixels (PIL / numpy / uint8 tensors) take two fused HIP kernels
 (normalise + nearest resize + cast in front of the VAE encoder, clamp + quantise behind the decoder).
 """
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -33,7 +34,13 @@ class FluxPipelineOutput(SimpleNamespace):
 
 class FluxKontextPipeline:
     def __init__(self, transformer, vae, scheduler=None, text_encoder=None, tokenizer=None,
-                 text_encoder_2=None, tokenizer_2=None):
+                 text_encoder_2=None, tokenizer_2=None, use_graph=None):
+        """use_graph (default: FK_GRAPH=1 in the environment): run the conditioning pass + the whole denoise loop of an
+        edit as ONE hipGraph launch (captured once per call shape, replayed afterwards; bit-identical to the eager loop).
+        The loop allocates nothing and never synchronises, so the capture is a plain stream capture; what it buys is the
+        host: ~5 400 ctypes launches per edit become one graph launch -- insurance for 8 ranks sharing one host."""
+        self.use_graph = (os.environ.get("FK_GRAPH", "0") == "1") if use_graph is None else bool(use_graph)
+        self._loop_graph = None       # (key, static tensors, torch.cuda.CUDAGraph) of the latest call shape
         self.transformer = transformer
         self.vae = vae
         self.scheduler = scheduler or FlowMatchEulerDiscreteScheduler()
@@ -292,29 +299,18 @@ class FluxKontextPipeline:
         if self.transformer.config.guidance_embeds:
             guidance = torch.full([model_batch], guidance_scale, device=device, dtype=torch.float32)
         self.scheduler.set_begin_index(0)
-        if hasattr(self.transformer, "prepare_conditioning"):  # all steps' modulation vectors in one pass
-            self.transformer.prepare_conditioning(t_model, guidance, model_pooled)
         model_tokens = torch.empty((model_batch, *tokens.shape[1:]), device=device, dtype=BF16) if do_true_cfg else tokens
 
         # 6. denoising loop: no allocation, no host sync
-        for i in range(len(timesteps)):
-            if self._interrupt:
-                continue
-            if do_true_cfg:
-                model_tokens[:batch_size].copy_(tokens)
-                model_tokens[batch_size:].copy_(tokens)
-            noise_pred = self.transformer(
-                hidden_states=model_tokens, timestep=t_model[i], guidance=guidance,
-                pooled_projections=model_pooled, encoder_hidden_states=model_embeds,
-                txt_ids=text_ids, img_ids=latent_ids, joint_attention_kwargs=joint_attention_kwargs or {},
-                return_dict=False)[0]
-            if do_true_cfg:
-                noise_pred = ops.true_cfg(noise_pred[:batch_size], noise_pred[batch_size:], true_cfg_scale)
-            ops.euler_step(tokens, noise_pred, S_tgt, self.scheduler.dsigma(i))
-            if callback_on_step_end is not None:
-                out = callback_on_step_end(self, i, timesteps[i], {"latents": tokens[:, :S_tgt]})
-                if out and "latents" in out:
-                    tokens[:, :S_tgt].copy_(out["latents"])
+        L = SimpleNamespace(tokens=tokens, model_tokens=model_tokens, t_model=t_model, guidance=guidance, pooled=model_pooled,
+                            embeds=model_embeds, text_ids=text_ids, latent_ids=latent_ids, S_tgt=S_tgt, batch_size=batch_size,
+                            do_true_cfg=do_true_cfg, true_cfg_scale=true_cfg_scale, jak=joint_attention_kwargs or {},
+                            geom=(height, width, None if image is None else tuple(image.shape[-2:])),
+                            dsigma=[self.scheduler.dsigma(i) for i in range(len(timesteps))])
+        if self.use_graph and callback_on_step_end is None and not joint_attention_kwargs:
+            tokens = self._denoise_graph(L)
+        else:
+            self._denoise(L, callback_on_step_end, timesteps)
 
         latents = tokens[:, :S_tgt]
         if output_type == "latent":
@@ -327,6 +323,65 @@ class FluxKontextPipeline:
         if not return_dict:
             return (image_out,)
         return FluxPipelineOutput(images=image_out, latents=latents)  # .latents: packed final latents (DP gather)
+
+    def _denoise(self, L, callback_on_step_end=None, timesteps=None):
+        """Conditioning of all steps in one pass, then the loop (flux_pipeline.py:1052-1120) over the persistent buffers."""
+        if hasattr(self.transformer, "prepare_conditioning"):  # all steps' modulation vectors in one pass
+            self.transformer.prepare_conditioning(L.t_model, L.guidance, L.pooled)
+        tokens, B = L.tokens, L.batch_size
+        for i in range(len(L.dsigma)):
+            if self._interrupt:
+                continue
+            if L.do_true_cfg:
+                L.model_tokens[:B].copy_(tokens)
+                L.model_tokens[B:].copy_(tokens)
+            noise_pred = self.transformer(
+                hidden_states=L.model_tokens, timestep=L.t_model[i], guidance=L.guidance,
+                pooled_projections=L.pooled, encoder_hidden_states=L.embeds,
+                txt_ids=L.text_ids, img_ids=L.latent_ids, joint_attention_kwargs=L.jak,
+                return_dict=False)[0]
+            if L.do_true_cfg:
+                noise_pred = ops.true_cfg(noise_pred[:B], noise_pred[B:], L.true_cfg_scale)
+            ops.euler_step(tokens, noise_pred, L.S_tgt, L.dsigma[i])
+            if callback_on_step_end is not None:
+                out = callback_on_step_end(self, i, timesteps[i], {"latents": tokens[:, :L.S_tgt]})
+                if out and "latents" in out:
+                    tokens[:, :L.S_tgt].copy_(out["latents"])
+
+    _GRAPH_INPUTS = ("tokens", "t_model", "guidance", "pooled", "embeds", "text_ids", "latent_ids")
+
+    def _denoise_graph(self, L):
+        """The same work as ONE graph launch.  The captured kernels read and write fixed buffers, so the call's tensors
+        are copied into the graph's own (a few MB); everything the host decides during an eager pass -- launch plans,
+        cached RoPE tables, the rows of the prepared conditioning, the Euler step sizes -- is frozen into the graph and
+        therefore part of its key.  Returns the token buffer the graph updates."""
+        key = (tuple(L.tokens.shape), tuple(L.embeds.shape), tuple(L.latent_ids.shape), L.geom, L.do_true_cfg,
+               float(L.true_cfg_scale), tuple(L.dsigma), L.guidance is None, L.S_tgt,
+               getattr(self.transformer, "_pack_serial", 0))
+        cur = torch.cuda.current_stream()
+        if self._loop_graph is None or self._loop_graph[0] != key:
+            self._loop_graph = None
+            G = SimpleNamespace(**vars(L))
+            for n in self._GRAPH_INPUTS:
+                t = getattr(L, n)
+                setattr(G, n, None if t is None else t.clone())
+            G.model_tokens = torch.empty_like(L.model_tokens) if L.do_true_cfg else G.tokens
+            side = torch.cuda.Stream(device=L.tokens.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):       # eager warm-up off the capture: kernel attributes, workspaces, RoPE cache
+                self._denoise(G)
+            cur.wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._denoise(G)
+            self._loop_graph = (key, G, graph)
+        _, G, graph = self._loop_graph
+        for n in self._GRAPH_INPUTS:
+            t = getattr(L, n)
+            if t is not None:
+                getattr(G, n).copy_(t)
+        graph.replay()
+        return G.tokens
 
     @staticmethod
     def postprocess(image, output_type="pil"):
