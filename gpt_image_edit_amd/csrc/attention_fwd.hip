@@ -42,11 +42,15 @@ struct AttnParams {
   int64_t o_ld, o_bs;
   float scale_log2;    // scale * log2(e)
   float* lse;          // optional [B, H, S]: log2-domain log-sum-exp of every row (saved for the backward pass)
-  // The (b, h, 256-row block) list: blocks [0, n_full) are one workgroup each (8 waves x 32 rows); every later block is
-  // cut into `light_subs` (4 / 2) "light" workgroups in which all 8 waves keep loading K / V tiles but only the first
-  // 8 / light_subs waves own query rows (see attention_entry).  light_subs = 0: no light workgroups.
-  int n_full, light_subs;
+  // Work list: n_items = B * H * ceil(S / 256) (b, h, 256-row block) items of nkt = ceil(S / 64) KV tiles each.
+  // Plain launch: one workgroup per item.  Stream-K launch (attention_fwd_kernel<.., STREAMK = true>): a persistent grid
+  // of G workgroups; workgroup `pos` works off the contiguous range [cut(pos), cut(pos + 1)) of the n_items * nkt KV-tile
+  // units, i.e. the tail of one item, whole items, the head of another (see the kernel).
+  int n_items, min_part;
+  float* sk_partials;  // stream-K workspace: per cut (G slots) the fp32 partial of one item part ...
+  unsigned* sk_ctl;    // ... and its (ticket, flag) word pair
 };
+constexpr int PART_FLOATS = 256 * 128 + 2 * 512;   // O^T accumulators of 8 waves x 32 rows + (l, m_ref) per lane
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
@@ -81,9 +85,11 @@ FK_DEV void wait_vmcnt() {
 // the probabilities enter the PV product as TWO bf16 terms (p = hi + lo, 16 mantissa bits instead of 8), so that
 // the result can be held against an fp32 reference at rtol 1e-3 / atol 1e-4 -- with one bf16 term the rounding of
 // P alone (2^-9 per term) sits above that tolerance whatever the kernel does.
-template <int NW, int STAGES, bool F32OUT, bool ILV>
+template <int NW, bool F32OUT, bool ILV, bool STREAMK>
 __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel(const AttnParams p) {
+  constexpr int STAGES = 3;           // K / V ring: one barrier per tile, tile kt + 2 requested when tile kt is published
   constexpr int QBLK = NW * 32;
+  static_assert(QBLK == 256, "the item list and the stream-K partial layout assume 256 query rows per workgroup");
   constexpr int LOADS = 32 / NW;      // DMA instructions per wave per tile (16 K pieces + 16 V pieces / NW)
   constexpr int KL = LOADS / 2;       // K pieces per wave (same number of V pieces)
   constexpr int PF = STAGES - 1;
@@ -94,29 +100,63 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
   const int ql = lane & 31;   // query row inside the wave / operand row
   const int hh = lane >> 5;   // half
 
-  // XCD-aware block order: workgroups of one (b, h) -- which share K / V -- stay on one XCD's L2
-  constexpr int QSPAN = 256;                // query rows per entry of the block list (QBLK * p.subs)
-  const int nqb = (p.S + QSPAN - 1) / QSPAN;
-  int t;
+  // XCD-aware order: consecutive positions -- items of one (b, h), which share K / V -- stay on one XCD's L2
+  const int nqb = (p.S + QBLK - 1) / QBLK;
+  const int nkt = (p.S + KVBLK - 1) / KVBLK;
+  int pos;
   {
     const int nwg = gridDim.x;
     const int q8 = nwg >> 3, r8 = nwg & 7;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    pos = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   }
-  int tb = t, sub = 0, nact = NW;           // nact: waves of this workgroup that own query rows
-  if (t >= p.n_full) {
-    const int l = t - p.n_full;
-    tb = p.n_full + l / p.light_subs;
-    sub = l - (l / p.light_subs) * p.light_subs;
-    nact = NW / p.light_subs;
+  // ---- the workgroup's range of KV-tile units --------------------------------------------------------------------------
+  // Plain launch: the one item `pos`.  Stream-K: with U = n_items * nkt units and G workgroups, cut j lies at
+  // floor(U * j / G), moved onto the item boundary when it would leave a part shorter than min_part tiles (a seam costs
+  // about two tiles' time); the launcher guarantees U / G >= nkt + 2 * min_part, so an item is cut at most once.
+  // The two parts of a cut item meet through workspace slot j (below, after the pass).
+  int u = 0, u_end = 0;                     // fit 32 bits: the launcher checks n_items * nkt < 2^31
+  if constexpr (STREAMK) {
+    const unsigned U = (unsigned)p.n_items * (unsigned)nkt, G = gridDim.x;
+    const unsigned qU = U / G, rU = U - qU * G;
+    auto cut = [&](unsigned j) __attribute__((always_inline)) {
+      unsigned c = qU * j + (rU * j) / G;                      // floor(U * j / G) without a 64-bit product
+      const unsigned r = c % (unsigned)nkt;
+      if (r != 0 && r < (unsigned)p.min_part) c -= r;
+      else if (r != 0 && (unsigned)nkt - r < (unsigned)p.min_part) c += (unsigned)nkt - r;
+      return (int)c;
+    };
+    u = cut(pos);
+    u_end = cut(pos + 1);
+    if (u >= u_end) return;
   }
-  const int qb = tb % nqb;
-  const int bh = tb / nqb;
+
+  const int prow = lane >> 4, pslot = lane & 15;   // LDS-DMA pieces: one instruction = 4 key rows x 256 B
+  // V^T operand via transpose read: lane supplies the 8-byte piece V[key0 + j][32 df + 16 dhalf + 4 q4 ..]
+  const int tj = (lane & 15) >> 2, tq = lane & 3, tdh = (lane >> 4) & 1;
+  const int v_rd = K_TILE_BYTES + (4 * hh + tj) * 256 + tdh * 32 + tq * 8;  // + (16 st + 8 part)*256 + ((df ^ tj) << 6)
+  // K operand (A of S^T): row key = 32 kb + ql, chunk 2kk + hh, swizzled by key & 15 (= ql & 15)
+  const int k_rd = ql * 256;           // + kb*8192 + (((2kk + hh) ^ (ql & 15)) << 4)
+  const int k_sw = ql & 15;
+#if FK_ATTN_PRIO
+  // Two waves share every SIMD (waves w and w + NW/2); the later-dispatched one loses the VALU arbitration (priority,
+  // then age) at the head of every segment.  ONE static priority raise for that half, no per-segment flips.  The
+  // condition must be provably wave-uniform: s_setprio ignores EXEC.
+  if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
+
+  for (;;) {   // one pass per (item, KV-tile range); a plain launch makes exactly one
+  int item = pos, kt0 = 0, kt1 = nkt;                   // this pass: KV tiles [kt0, kt1) of the item
+  if constexpr (STREAMK) {
+    item = (unsigned)u / (unsigned)nkt;
+    kt0 = u - item * nkt;
+    kt1 = min(nkt, kt0 + (u_end - u));
+    u += kt1 - kt0;
+  }
+  const int qb = item % nqb;
+  const int bh = item / nqb;
   const int b = bh / p.H, h = bh - b * p.H;
-  const int q_row0 = qb * QSPAN + sub * nact * 32;
-  if (q_row0 >= p.S) return;                // ragged last block: nothing for this light workgroup
-  const bool active = wave < nact;          // wave-uniform; the other waves only feed the K / V ring and keep the barriers
+  const int q_row0 = qb * QBLK;
 
   const bf16_t* Kg = p.k + (int64_t)bh * p.S * HD;
   const bf16_t* Vg = p.v + (int64_t)b * p.v_bs + h * HD;
@@ -131,7 +171,6 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
   }
 
   // ---- LDS-DMA pieces: one instruction = 4 key rows x 256 B; lane -> (row = lane/16, 16-byte slot = lane%16)
-  const int prow = lane >> 4, pslot = lane & 15;
   // Buffer form of the LDS-DMA load: descriptor in SGPRs, ONE 32-bit offset VGPR per piece (constant over the
   // tiles), the tile offset in an SGPR.  Rows >= S lie beyond num_records and are fetched as zeros (they are masked).
   const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, p.S * HD * 2, 0x00020000);
@@ -146,7 +185,9 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
     v_voff[i] = (int)((r * p.v_ld + vcol) * 2);
   }
   const int k_tile_bytes = KVBLK * HD * 2, v_tile_bytes = (int)(KVBLK * p.v_ld * 2);
-  auto issue_tile = [&](int kt, int stage) {
+  // (every lambda of the kernel is force-inlined: a tile body left as an out-of-line call takes its captures by address and
+  //  the accumulator arrays land in private memory -- 25x slower; tests/test_kernel_resources.py watches for it)
+  auto issue_tile = [&](int kt, int stage) __attribute__((always_inline)) {
     char* sb = smem + stage * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < KL; ++i) {
@@ -154,14 +195,6 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
       buffer_lds16(rs_v, sb + K_TILE_BYTES + (wave * KL + i) * 1024, v_voff[i], kt * v_tile_bytes);
     }
   };
-
-  // ---- operand read addresses ------------------------------------------------------------------------
-  // K operand (A of S^T): row key = 32 kb + ql, chunk 2kk + hh, swizzled by key & 15 (= ql & 15)
-  const int k_rd = ql * 256;           // + kb*8192 + (((2kk + hh) ^ (ql & 15)) << 4)
-  const int k_sw = ql & 15;
-  // V^T operand via transpose read: lane supplies the 8-byte piece V[key0 + j][32 df + 16 dhalf + 4 q4 ..]
-  const int tj = (lane & 15) >> 2, tq = lane & 3, tdh = (lane >> 4) & 1;
-  const int v_rd = K_TILE_BYTES + (4 * hh + tj) * 256 + tdh * 32 + tq * 8;  // + (16 st + 8 part)*256 + ((df ^ tj) << 6)
 
   f32x16_t o[4];
   // Exponent reference.  The textbook online softmax rescales O by exp(m_old - m_new) on every tile (64 multiplies
@@ -179,50 +212,34 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
   float m_ref = 0.f, l_run = 0.f;
   bool overflow = false;         // wave-uniform
 
-  const int nkt = (p.S + KVBLK - 1) / KVBLK;
-  // STAGES == 3: one barrier per tile, tile kt + 2 requested when tile kt is published.
-  // STAGES == 4 ("pairs"): ONE barrier per TWO tiles -- at every even tile the wave waits for the pair (kt, kt + 1),
-  // passes the barrier and requests the pair (kt + 2, kt + 3) into the two stages the previous pair has just left.
-  // Measured (profiles/r03_attention_variants.txt): 1-3 % SLOWER at every shape, isolated and inside the edits -- the
-  // per-tile barrier is not the cost the parked-wave counter suggests; it keeps the eight waves' K / V reads together.
-  // Kept as a switch (fk_attention_set_ring), not the default.
-  constexpr bool PAIRS = STAGES == 4;
   int st_cur = 0, st_pf = PF;
-  auto fill = [&]() {
+  auto fill = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int s = 0; s < (PAIRS ? 2 : PF); ++s)
-      if (s < nkt) issue_tile(s, s);
+    for (int s = 0; s < PF; ++s)
+      if (kt0 + s < kt1) issue_tile(kt0 + s, s);
     st_cur = 0;
-    st_pf = PAIRS ? 2 : PF;
+    st_pf = PF;
   };
-  // ring bookkeeping shared by the main loop and the pre-pass: wait for tile kt, publish it, request the tile(s) ahead
-  auto acquire_tile = [&](int kt) {
-    if constexpr (PAIRS) {
-      if ((kt & 1) == 0) {
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nkt) issue_tile(kt + 2, st_pf);
-        if (kt + 3 < nkt) issue_tile(kt + 3, st_pf == STAGES - 1 ? 0 : st_pf + 1);
-      }
-    } else {
-      if (kt + PF - 1 < nkt) wait_vmcnt<(PF - 1) * LOADS>();
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      if (kt + PF < nkt) issue_tile(kt + PF, st_pf);
-    }
+  // ring bookkeeping shared by the main loop and the pre-pass: wait for tile kt, publish it, request the tile ahead
+  // (a four-stage ring with one barrier per two tiles was measured 1-3 % slower at every shape in round 3 and is gone)
+  auto acquire_tile = [&](int kt) __attribute__((always_inline)) {
+    if (kt + PF - 1 < kt1) wait_vmcnt<(PF - 1) * LOADS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + PF < kt1) issue_tile(kt + PF, st_pf);
     return smem + st_cur * STAGE_BYTES;
   };
-  auto release_tile = [&]() {
+  auto release_tile = [&]() __attribute__((always_inline)) {
     st_cur = (st_cur == STAGES - 1) ? 0 : st_cur + 1;
     st_pf = (st_pf == STAGES - 1) ? 0 : st_pf + 1;
   };
   // Operand fragments.  The reads are issued PF_DEPTH MFMAs ahead of their use and the order is pinned
   // (sched_group_barrier: one DS read, then one MFMA): left alone, hipcc issues every ds_read right in front of
   // its MFMA and the wave waits for an LDS round trip 32 times per tile.
-  auto k_frag = [&](const char* sb, int kb, int kk) {
+  auto k_frag = [&](const char* sb, int kb, int kk) __attribute__((always_inline)) {
     return *(const bf16x8_t*)(sb + k_rd + kb * 8192 + (((2 * kk + hh) ^ k_sw) << 4));
   };
-  auto v_frag = [&](const char* sb, int st, int df) {   // keys 16 st + {0, 8} + 4 hh + 0..3, d block df
+  auto v_frag = [&](const char* sb, int st, int df) __attribute__((always_inline)) {   // keys 16 st + {0, 8} + 4 hh + 0..3, d block df
     const char* vp = sb + v_rd + st * 4096 + ((df ^ tj) << 6);
     const s16x4_t lo = lds_tr16(vp);
     const s16x4_t hi = lds_tr16(vp + 2048);
@@ -232,7 +249,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
     return vf;
   };
   // S^T block kb (32 keys x 32 queries) of the tile at sb, masked beyond S in the ragged last tile
-  auto scores = [&](const char* sb, int kb, int kt, auto mask_tag) {
+  auto scores = [&](const char* sb, int kb, int kt, auto mask_tag) __attribute__((always_inline)) {
     constexpr bool MASK = decltype(mask_tag)::value;
     f32x16_t s;
     bf16x8_t kf[3];
@@ -255,7 +272,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
     }
     return s;
   };
-  auto block_max = [&](const f32x16_t& s) {   // row maximum over one 32-key block, in log2 units
+  auto block_max = [&](const f32x16_t& s) __attribute__((always_inline)) {   // row maximum over one 32-key block, in log2 units
     float mx = s[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
@@ -273,11 +290,10 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
   // (profiles/r02_attention_variants.txt), so the launcher chooses.
   // MASK = the tile holds keys >= S (only ever the last tile), FIRST = tile 0 of the first attempt (sets the
   // exponent reference): compiled as separate copies so the steady-state loop carries no selects.
-  auto do_tile = [&](int kt, auto mask_tag, auto first_tag) {
+  auto do_tile = [&](int kt, auto mask_tag, auto first_tag) __attribute__((always_inline)) {
     if constexpr (!ILV) {
       constexpr bool FIRST = decltype(first_tag)::value;
       const char* sb = acquire_tile(kt);
-      if (!active) { release_tile(); return; }
       float psum = 0.f;
   #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -333,13 +349,12 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
       constexpr bool FIRST = decltype(first_tag)::value;
       constexpr bool MASK = decltype(mask_tag)::value;
       const char* sb = acquire_tile(kt);
-      if (!active) { release_tile(); return; }
       float psum = 0.f;
       f32x16_t s0 = scores(sb, 0, kt, mask_tag);
       if constexpr (FIRST) m_ref = block_max(s0) + REF_BIAS;   // reference = row maximum over the first 32 keys + bias
       const float nm = -m_ref;
       // softmax numerators of two scores (log2 domain; raw v_exp_f32, denormal results may flush)
-      auto expo2 = [&](f32x16_t& s, int r) {
+      auto expo2 = [&](f32x16_t& s, int r) __attribute__((always_inline)) {
   #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const float pv = __builtin_amdgcn_exp2f(fmaf(s[r + e], p.scale_log2, nm));
@@ -347,7 +362,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
           psum += pv;
         }
       };
-      auto pack8 = [&](const f32x16_t& s, int r0, bf16x8_t& pf, bf16x8_t& pf_lo) {
+      auto pack8 = [&](const f32x16_t& s, int r0, bf16x8_t& pf, bf16x8_t& pf_lo) __attribute__((always_inline)) {
         u32x4_t pw;
         pw[0] = pack_bf2(s[r0 + 0], s[r0 + 1]);
         pw[1] = pack_bf2(s[r0 + 2], s[r0 + 3]);
@@ -425,27 +440,33 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
 
   using TT = std::true_type;
   using FF = std::false_type;
-#if FK_ATTN_PRIO
-  // Two waves share every SIMD (waves w and w + NW/2); the later-dispatched one loses the VALU arbitration (priority,
-  // then age) at the head of every segment.  ONE static priority raise for that half, no per-segment flips.  The
-  // condition must be provably wave-uniform: s_setprio ignores EXEC.
-  if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
   const bool ragged = p.S % KVBLK != 0;
+  const bool last_masked = ragged && kt1 == nkt;     // the pass ends with the item's ragged tile
   int* const wg_flag = (int*)(smem + STAGES * STAGE_BYTES);   // one word past the ring (allocated by the launcher)
+  // tiles [kt0, kt1): the first one sets the exponent reference (attempt 0), only the item's last one can need the mask
+  auto run_tiles = [&](auto first_tag) __attribute__((always_inline)) {
+    const int last = kt1 - 1;
+    if (kt0 == last) {
+      if (last_masked) do_tile(kt0, TT{}, first_tag);
+      else do_tile(kt0, FF{}, first_tag);
+      return;
+    }
+    do_tile(kt0, FF{}, first_tag);
+    for (int kt = kt0 + 1; kt < last; ++kt) do_tile(kt, FF{}, FF{});
+    if (last_masked) do_tile(last, TT{}, FF{});
+    else do_tile(last, FF{}, FF{});
+  };
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (attempt == 1) {
-      // exact row maxima: K-only pre-pass over all tiles (V rides along in the ring)
+      // exact row maxima: K-only pre-pass over the pass's tiles (V rides along in the ring)
       fill();
       m_ref = -3.0e38f;
-      for (int kt = 0; kt < nkt; ++kt) {
+      for (int kt = kt0; kt < kt1; ++kt) {
         const char* sb = acquire_tile(kt);
-        if (active) {
 #pragma unroll
-          for (int kb = 0; kb < 2; ++kb) {
-            if (ragged && kt == nkt - 1) m_ref = fmaxf(m_ref, block_max(scores(sb, kb, kt, TT{})));
-            else m_ref = fmaxf(m_ref, block_max(scores(sb, kb, kt, FF{})));
-          }
+        for (int kb = 0; kb < 2; ++kb) {
+          if (last_masked && kt == kt1 - 1) m_ref = fmaxf(m_ref, block_max(scores(sb, kb, kt, TT{})));
+          else m_ref = fmaxf(m_ref, block_max(scores(sb, kb, kt, FF{})));
         }
         release_tile();
       }
@@ -458,22 +479,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
     for (int df = 0; df < 4; ++df)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[df][r] = 0.f;
-    if (attempt == 0) {
-      if (nkt == 1) {
-        if (ragged) do_tile(0, TT{}, TT{});
-        else do_tile(0, FF{}, TT{});
-      } else {
-        do_tile(0, FF{}, TT{});
-      }
-    } else {
-      if (nkt == 1 && ragged) do_tile(0, TT{}, FF{});
-      else do_tile(0, FF{}, FF{});
-    }
-    for (int kt = 1; kt < nkt - 1; ++kt) do_tile(kt, FF{}, FF{});
-    if (nkt > 1) {
-      if (ragged) do_tile(nkt - 1, TT{}, FF{});
-      else do_tile(nkt - 1, FF{}, FF{});
-    }
+    if (attempt == 0) run_tiles(TT{});
+    else run_tiles(FF{});
     // the waves share the K/V ring and its barriers: they repeat the pass together or not at all
     if (attempt == 0) {
       // Did some row outgrow the exponent range?  No per-tile maximum is kept for this (that was ~1 VALU instruction
@@ -494,7 +501,74 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
     }
   }
 
-  if (!active) return;
+  // ---- stream-K seam: the two parts of a cut item ------------------------------------------------------------------------
+  // Each part holds, per query row, unnormalised sums against its OWN exponent reference: (O^T, l, m_ref).  Whoever
+  // finishes FIRST (ticket = an agent-scope fetch-add on the cut's counter word: even -> first) writes its triple to the
+  // cut's workspace slot with write-through stores, drains them, publishes flag = ticket + 1 and goes on to its next item;
+  // the SECOND (odd ticket) waits for flag == its ticket, acquires, rescales both triples to the larger reference,
+  //   O = O_self * 2^(m_self - m) + O_other * 2^(m_other - m)        (two rounded products, one rounded sum: symmetric)
+  // and finalises.  The result does not depend on which part arrives second.  The wait is only ever for a workgroup that
+  // has already drawn its ticket -- resident and microseconds from publishing -- so no dispatch order is assumed; counter
+  // and flag are monotonic (every launch adds exactly two tickets per cut it uses): nothing is reset between launches
+  // or graph replays.  Recipe: cdna_hip_programming.md Guideline 16 R1, as the split-K GEMM pairs use it.
+  if constexpr (STREAMK) {
+    if (kt0 > 0 || kt1 < nkt) {                     // workgroup-uniform
+      typedef __attribute__((address_space(1))) unsigned gu32;
+      const int slot = kt1 < nkt ? pos + 1 : pos;   // the cut's index, 1 .. G - 1
+      gu32* const ctl = (gu32*)(p.sk_ctl + 2 * (size_t)slot);
+      const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.sk_partials + (size_t)slot * PART_FLOATS), 0, PART_FLOATS * 4, 0x00020000);
+      __syncthreads();   // every wave is done with the ring: its first word now carries the ticket
+      if (tid == 0) *(volatile unsigned*)smem = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const unsigned ticket = __builtin_amdgcn_readfirstlane(*(volatile unsigned*)smem);
+      constexpr int LM_OFF = 16 * 512 * 16;         // (l, m_ref) pairs behind the 16 x 512 accumulator pieces
+      if ((ticket & 1u) == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const f32x16_t& a = o[r >> 2];
+          const int q4 = r & 3;
+          const u32x4_t v = {__float_as_uint(a[4 * q4]), __float_as_uint(a[4 * q4 + 1]), __float_as_uint(a[4 * q4 + 2]),
+                             __float_as_uint(a[4 * q4 + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs_p, tid * 16, r * (512 * 16), /*sc1: write through*/ 16);
+        }
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(l_run), __float_as_uint(m_ref)}, rs_p, LM_OFF + tid * 8, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its own stores
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(ctl + 1, ticket + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                                   // the ring is refilled by the next pass
+        if (u >= u_end) break;
+        continue;
+      }
+      if (tid == 0) {
+        while (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket) __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+      const u32x2_t lm = __builtin_amdgcn_raw_buffer_load_b64(rs_p, LM_OFF + tid * 8, 0, /*sc1*/ 16);
+      const float l_o = __uint_as_float(lm[0]), m_o = __uint_as_float(lm[1]);
+      const float m_new = fmaxf(m_ref, m_o);
+      const float w_s = m_ref == m_new ? 1.0f : __builtin_amdgcn_exp2f(m_ref - m_new);
+      const float w_o = m_o == m_new ? 1.0f : __builtin_amdgcn_exp2f(m_o - m_new);
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += 4) {
+        u32x4_t v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, tid * 16, (r0 + e) * (512 * 16), /*sc1*/ 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f32x16_t& a = o[(r0 + e) >> 2];
+          const int q4 = (r0 + e) & 3;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            a[4 * q4 + j] = __fadd_rn(__fmul_rn(a[4 * q4 + j], w_s), __fmul_rn(__uint_as_float(v[e][j]), w_o));
+        }
+      }
+      l_run = __fadd_rn(__fmul_rn(l_run, w_s), __fmul_rn(l_o, w_o));
+      m_ref = m_new;
+    }
+  }
+
   // ---- finalize: O = O^T / l ; lane (q = ql) holds d = 32 df + 8 g + 4 hh + (0..3), g = r >> 2 -------------
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
@@ -537,6 +611,12 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
         }
       }
   }
+  if constexpr (!STREAMK) break;
+  else {
+    if (u >= u_end) break;
+    __syncthreads();   // every wave is done with the ring and the ticket word before the next pass
+  }
+  }   // passes
 }
 
 // One-wave-per-SIMD schedules (round 1, git history: two query blocks per wave half a tile apart; one block with the
@@ -562,39 +642,33 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
 // barrier (timing probe): +1..6 %.  Counters at B = 4, S = 8704: matrix pipe 52 % busy at 1.86 GHz, waves 37 % parked,
 // 32 % issue-stalled, LDS array ~26 % busy, no bank conflicts.
 
-template <int NW, int STAGES, bool F32OUT, bool ILV>
-int launch(AttnParams p, hipStream_t stream, int n_full, int n_light_blocks, int light_subs) {
-  constexpr int SMEM = STAGES * STAGE_BYTES + 16;   // ring + the restart flag word
-  auto kern = attention_fwd_kernel<NW, STAGES, F32OUT, ILV>;
+template <int NW, bool F32OUT, bool ILV, bool STREAMK>
+int launch(const AttnParams& p, int grid, hipStream_t stream) {
+  constexpr int SMEM = 3 * STAGE_BYTES + 16;   // ring + the restart flag word
+  auto kern = attention_fwd_kernel<NW, F32OUT, ILV, STREAMK>;
   FK_ENSURE_MAX_LDS(kern, SMEM, "fk_attention_fwd_bf16");
-  p.n_full = n_full;
-  p.light_subs = light_subs;
-  hipLaunchKernelGGL(kern, dim3(n_full + n_light_blocks * light_subs), dim3(NW * 64), SMEM, stream, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), SMEM, stream, p);
   FK_CHECK_LAUNCH("fk_attention_fwd_bf16");
   return FK_OK;
 }
 
-// The last, partly filled round of a grid.  One workgroup (8 waves x 32 query rows) per CU means the grid runs in
-// rounds of #CUs blocks; at batch 1 and S = 8704 that is 816 blocks = 3 full rounds + 48 blocks that hold 48 CUs for a
-// whole fourth round while 208 idle.  Those tail blocks can be run as FOUR (or two) "light" workgroups each, at the end
-// of the same launch: all 8 waves of a light workgroup keep issuing their share of the K / V LDS-DMA requests (the
-// request issue, ~60 cycles apiece, is what a wave cannot afford to do alone: a 2-wave workgroup that loads for itself
-// measured SLOWER in the edit), but only 2 (4) waves own query rows -- one computing wave per SIMD instead of two, so
-// each runs faster and the tail spreads over 192 CUs.  Every query row's arithmetic is the same whichever workgroup
-// shape carries it: bit-identical output (tests/test_hip_cfg3.py).  MEASURED, BOTH FORMS, AND OFF BY DEFAULT
-// (profiles/r03_attention_variants.txt): isolated the light workgroups gain 1.5-3 % at S = 8704 / 5632 as a second launch of
-// 2-wave workgroups and lose 2 % inside the launch; inside the 1024^2 edit both forms LOSE (1492 -> 1524 ms and
-// 1634 -> 1695 ms of attention per edit): a lone wave per SIMD does not run enough faster than two sharing one to pay
-// for the extra workgroups' prologues, and the idle CUs of the plain grid's last round are not wasted -- they hand
-// their power budget to the busy ones.  fk_attention_set_tail(1) / FK_ATTN_TAIL=1 select it for measurements.
-static int g_attn_tail = -2;
-static int g_attn_ring = -1;
-static int attn_tail_mode() {
-  if (g_attn_tail == -2) {
-    const char* e = getenv("FK_ATTN_TAIL");
-    g_attn_tail = e ? atoi(e) : 0;
+// ---- the grid ----------------------------------------------------------------------------------------------------------
+// One workgroup (8 waves x 32 query rows) per CU means a plain grid runs in rounds of #CUs items: at batch 1 and S = 8704
+// that is 816 items = 3 full rounds + 48 items that hold 48 CUs for a whole fourth round while 208 idle (S = 5632: 528
+// items, 2.06 rounds -> 3).  Round 3 measured two ways of thinning that last round (light workgroups, in a second launch
+// and inside the launch) and both lost inside the edit; they are gone (git history, profiles/r03_attention_variants.txt).
+// Round 4: STREAM-K.  A persistent grid of one workgroup per CU; the n_items * nkt KV-tile units are dealt out as G equal
+// contiguous ranges, so every CU works the same time and an item that straddles two CUs is finished by whichever of the
+// two arrives second (kernel, "stream-K seam").  Used when the plain grid would waste >= 4 % of its rounds and the items
+// are long enough that each is cut at most once.  An item's bits then depend on WHERE it is cut, i.e. on the grid:
+// fk_attention_set_split(0) / FK_ATTN_SPLIT=0 ("batch-invariant", like fk_gemm_set_plan(1)) keeps the plain grid.
+static int g_attn_split = -1;
+static int attn_split_mode() {
+  if (g_attn_split < 0) {
+    const char* e = getenv("FK_ATTN_SPLIT");
+    g_attn_split = e ? (atoi(e) < 0 ? 0 : atoi(e)) : 1;
   }
-  return g_attn_tail;
+  return g_attn_split;
 }
 static int attn_cu_count() {
   static int cus = 0;
@@ -606,7 +680,7 @@ static int attn_cu_count() {
   }
   return cus;
 }
-
+constexpr int ATTN_MIN_PART = 8;           // KV tiles: the shortest part a cut may leave
 
 // FK_ATTN_ILV=0|1 forces the instruction order of the main loop (A/B measurement); default: by grid size.
 static bool use_interleaved(const AttnParams& p) {
@@ -619,13 +693,12 @@ static bool use_interleaved(const AttnParams& p) {
   // Measured (profiles/r02_attention_variants.txt): isolated, the interleaved order is +3-4 % on grids of many rounds
   // (B = 4, S = 8704: 1157 vs 1114 TF/s) and -2 % on 1-3 round grids; inside an edit, where the kernel runs at the
   // clock the neighbouring GEMMs leave it, it is +1.7 % at S = 8704, B = 1 and even at S = 2560 (240 workgroups).
-  const int64_t nwg = (int64_t)((p.S + 255) / 256) * p.H * p.B;
-  return nwg >= 512;
+  return p.n_items >= 512;
 }
 
 int attention_entry(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H, int32_t S, int64_t v_ld,
                     int64_t v_batch_stride, int64_t o_ld, int64_t o_batch_stride, float scale, bool f32out,
-                    hipStream_t stream, float* lse = nullptr) {
+                    hipStream_t stream, float* lse = nullptr, void* ws = nullptr, int64_t ws_bytes = 0) {
   FK_CHECK_ARG(q && k && v && o, "fk_attention_fwd_bf16: null pointer");
   FK_CHECK_ARG(B > 0 && H > 0 && S > 0, "fk_attention_fwd_bf16: bad B/H/S %d %d %d", B, H, S);
   FK_CHECK_ARG(o_ld % 4 == 0 && o_batch_stride % 4 == 0 && ((uintptr_t)o % (f32out ? 16 : 8) == 0),
@@ -638,44 +711,45 @@ int attention_entry(const void* q, const void* k, const void* v, void* o, int32_
                    (int64_t)(S + KVBLK) * v_ld * 2 < (1ll << 31),
                "fk_attention_fwd_bf16: S = %d with v_ld = %lld exceeds the 2 GiB a (batch, head)'s K / V may span", S,
                (long long)v_ld);
+  const int64_t n_items = (int64_t)((S + 255) / 256) * H * B, nkt = (S + KVBLK - 1) / KVBLK;
+  FK_CHECK_ARG(n_items * nkt < (1ll << 31), "fk_attention_fwd_bf16: B * H * S^2 too large for 32-bit tile counters");
   AttnParams p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o;
   p.B = B; p.H = H; p.S = S; p.v_ld = v_ld; p.v_bs = v_batch_stride; p.o_ld = o_ld; p.o_bs = o_batch_stride;
   p.scale_log2 = scale * 1.4426950408889634f;
   p.lse = lse;
-  const int nblk = ((S + 255) / 256) * H * B;
-  if (f32out) return launch<8, 3, true, false>(p, stream, nblk, 0, 0);
-  const int G = attn_cu_count();
-  int tail = 0, subs = 0;                          // blocks handed to light workgroups, light workgroups per block
-  if (attn_tail_mode() && nblk > G && nblk % G != 0) {
-    const int rem = nblk % G;
-    if (4 * rem <= G) { tail = rem; subs = 4; }
-    else if (2 * rem <= G) { tail = rem; subs = 2; }
+  p.n_items = (int)n_items;
+  p.min_part = ATTN_MIN_PART;
+  p.sk_partials = nullptr;
+  p.sk_ctl = nullptr;
+  if (f32out) return launch<8, true, false, false>(p, (int)n_items, stream);
+  const int mode = attn_split_mode();   // 0: never; 1: where it pays; >= 2 (test hook): a persistent grid of `mode` workgroups
+  const int G = mode >= 2 ? (mode < attn_cu_count() ? mode : attn_cu_count()) : attn_cu_count();
+  const int64_t rounds = (n_items + G - 1) / G;
+  const bool wasteful = mode >= 2 || (n_items > G && (rounds * G - n_items) * 25 >= rounds * G);   // >= 4 % of the rounds' CU time idle
+  const bool cut_once = n_items * nkt >= (int64_t)G * (nkt + 2 * ATTN_MIN_PART);       // every range spans more than an item
+  const int64_t need = (int64_t)G * (PART_FLOATS * 4 + 8);
+  if (mode && wasteful && cut_once && ws && ws_bytes >= need) {
+    FK_CHECK_ARG((uintptr_t)ws % 16 == 0, "fk_attention_fwd_ws_bf16: workspace must be 16-byte aligned");
+    p.sk_partials = (float*)ws;
+    p.sk_ctl = (unsigned*)((char*)ws + (size_t)G * PART_FLOATS * 4);
+    return use_interleaved(p) ? launch<8, false, true, true>(p, G, stream) : launch<8, false, false, true>(p, G, stream);
   }
-  if (g_attn_ring < 0) {                            // FK_ATTN_RING=4: 4-stage ring, one barrier per two KV tiles
-    const char* e = getenv("FK_ATTN_RING");
-    g_attn_ring = e ? atoi(e) : 3;
-  }
-  if (g_attn_ring == 4)
-    return use_interleaved(p) ? launch<8, 4, false, true>(p, stream, nblk - tail, tail, subs)
-                              : launch<8, 4, false, false>(p, stream, nblk - tail, tail, subs);
-  return use_interleaved(p) ? launch<8, 3, false, true>(p, stream, nblk - tail, tail, subs)
-                            : launch<8, 3, false, false>(p, stream, nblk - tail, tail, subs);
+  return use_interleaved(p) ? launch<8, false, true, false>(p, (int)n_items, stream)
+                            : launch<8, false, false, false>(p, (int)n_items, stream);
 }
 
 }  // namespace
 
-extern "C" int fk_attention_set_ring(int32_t stages) {
-  FK_CHECK_ARG(stages == 3 || stages == 4, "fk_attention_set_ring: %d is not 3 (a barrier per KV tile) or 4 (a barrier per two)", stages);
-  g_attn_ring = stages;
+extern "C" int fk_attention_set_split(int32_t mode) {
+  FK_CHECK_ARG(mode >= 0, "fk_attention_set_split: %d is not 0 (one workgroup per 256-row block, always), 1 (stream-K grids where they "
+               "pay) or a workgroup count >= 2 (test hook: a persistent grid of that size whenever every item is cut at most once)", mode);
+  g_attn_split = mode;
   return FK_OK;
 }
 
-extern "C" int fk_attention_set_tail(int32_t mode) {
-  FK_CHECK_ARG(mode == 0 || mode == 1, "fk_attention_set_tail: %d is not 0 (plain grid) or 1 (light workgroups for the last round)", mode);
-  g_attn_tail = mode;
-  return FK_OK;
-}
+// one slot per cut of the persistent grid (= per CU of the current device): the fp32 partial + its (ticket, flag) pair
+extern "C" int64_t fk_attention_ws_bytes(void) { return (int64_t)attn_cu_count() * (PART_FLOATS * 4 + 8); }
 
 extern "C" int fk_attention_fwd_bf16(const void* q, const void* k, const void* v, void* o, int32_t B,
                                      int32_t H, int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld,
@@ -690,6 +764,13 @@ extern "C" int fk_attention_fwd_lse_bf16(const void* q, const void* k, const voi
   FK_CHECK_ARG(lse != nullptr, "fk_attention_fwd_lse_bf16: null lse");
   return attention_entry(q, k, v, o, B, H, S, v_ld, v_batch_stride, o_ld, o_batch_stride, scale, false,
                          (hipStream_t)stream_, lse);
+}
+
+extern "C" int fk_attention_fwd_ws_bf16(const void* q, const void* k, const void* v, void* o, float* lse, int32_t B, int32_t H,
+                                        int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld, int64_t o_batch_stride,
+                                        float scale, void* ws, int64_t ws_bytes, fk_stream_t stream_) {
+  return attention_entry(q, k, v, o, B, H, S, v_ld, v_batch_stride, o_ld, o_batch_stride, scale, false,
+                         (hipStream_t)stream_, lse, ws, ws_bytes);
 }
 
 extern "C" int fk_attention_fwd_f32_debug(const void* q, const void* k, const void* v, float* o, int32_t B,

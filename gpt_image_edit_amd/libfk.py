@@ -60,8 +60,9 @@ SIGNATURES = {
     "fk_ln_modulate2_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "fk_qkv_post_bf16": (c_i32, [c_vp] * 9 + [c_i32] * 4 + [c_f32, c_vp]),
     "fk_attention_fwd_bf16": (c_i32, [c_vp] * 4 + [c_i32] * 3 + [c_i64] * 4 + [c_f32, c_vp]),
-    "fk_attention_set_tail": (c_i32, [c_i32]),
-    "fk_attention_set_ring": (c_i32, [c_i32]),
+    "fk_attention_fwd_ws_bf16": (c_i32, [c_vp] * 5 + [c_i32] * 3 + [c_i64] * 4 + [c_f32, c_vp, c_i64, c_vp]),
+    "fk_attention_ws_bytes": (c_i64, []),
+    "fk_attention_set_split": (c_i32, [c_i32]),
     "fk_attention_fwd_f32_debug": (c_i32, [c_vp] * 4 + [c_i32] * 3 + [c_i64] * 4 + [c_f32, c_vp]),
     "fk_attention_fwd_lse_bf16": (c_i32, [c_vp] * 5 + [c_i32] * 3 + [c_i64] * 4 + [c_f32, c_vp]),
     "fk_attention_bwd_set_mode": (c_i32, [c_i32]),

@@ -224,23 +224,44 @@ def qkv_post(qkv, q_out, k_out, wq_img, wk_img, wq_txt, wk_txt, cos, sin, s_txt,
                 "fk_qkv_post_bf16")
 
 
-def attention(q, k, v, out, scale=None):
+_ATTN_WS = {}
+
+
+def attention_workspace(device):
+    """Stream-K workspace of the attention forward for the current stream of ``device`` (fk_attention_ws_bytes(), zeroed
+    once: monotonic tickets afterwards)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    ws = _ATTN_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(libfk.load().fk_attention_ws_bytes(), device=device, dtype=torch.uint8)
+        _ATTN_WS[key] = ws
+    return ws
+
+
+def attention_set_split(mode):
+    """fk_attention_set_split: 1 = stream-K grids where the plain grid wastes a round (default), 0 = never (batch-invariant)."""
+    libfk.check(libfk.load().fk_attention_set_split(int(mode)), "fk_attention_set_split")
+
+
+def attention(q, k, v, out, scale=None, lse=None):
     """out[b, s, h*128:(h+1)*128] = softmax(q k^T * scale) v.
 
     q, k: [B,H,S,128] contiguous; v: [B,S,H*128] view with contiguous last dim (e.g. qkv[:, :, 2D:]);
-    out: [B,S,>=H*128] view."""
-    _need_cuda(q, k, v, out)
+    out: [B,S,>=H*128] view; lse: optional fp32 [B,H,S] (log2 domain, for :func:`attention_bwd`)."""
+    _need_cuda(q, k, v, out, lse)
     B, H, S, hd = q.shape
     if hd != 128:
         raise ValueError("head_dim must be 128")
     if v.dim() != 3 or v.shape[-1] != H * 128 or v.stride(2) != 1:
         raise ValueError("v must be a [B, S, H*128] view with a contiguous last dimension")
+    if lse is not None and (lse.dtype != torch.float32 or lse.shape != (B, H, S) or not lse.is_contiguous()):
+        raise ValueError("lse must be a contiguous fp32 [B,H,S] tensor")
     if scale is None:
         scale = hd ** -0.5
-    lib = libfk.load()
-    libfk.check(lib.fk_attention_fwd_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, S, v.stride(1), v.stride(0),
-                                          out.stride(1), out.stride(0), scale, _stream()),
-                "fk_attention_fwd_bf16")
+    ws = attention_workspace(q.device)
+    libfk.check(libfk.load().fk_attention_fwd_ws_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, H, S, v.stride(1),
+                                                     v.stride(0), out.stride(1), out.stride(0), scale, _ptr(ws), ws.numel(),
+                                                     _stream()), "fk_attention_fwd_bf16")
     return out
 
 
@@ -361,15 +382,9 @@ def attn_view(t, head_major):
 
 def attention_lse(q, k, v, out, lse, scale=None):
     """:func:`attention` that also writes lse [B,H,S] fp32 (log2 domain) for :func:`attention_bwd`."""
-    _need_cuda(q, k, v, out, lse)
-    B, H, S, hd = q.shape
-    if lse.dtype != torch.float32 or lse.shape != (B, H, S) or not lse.is_contiguous():
-        raise ValueError("lse must be a contiguous fp32 [B,H,S] tensor")
-    libfk.check(libfk.load().fk_attention_fwd_lse_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, H, S, v.stride(1),
-                                                      v.stride(0), out.stride(1), out.stride(0),
-                                                      hd ** -0.5 if scale is None else scale, _stream()),
-                "fk_attention_fwd_lse_bf16")
-    return out
+    if lse is None:
+        raise ValueError("attention_lse needs an lse tensor")
+    return attention(q, k, v, out, scale=scale, lse=lse)
 
 
 def rowdot(a, c, heads, out=None):

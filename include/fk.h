@@ -166,14 +166,23 @@ int fk_qkv_post_bf16(const void* qkv, void* q_out, void* k_out, const void* wq_i
 int fk_attention_fwd_bf16(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H,
                           int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld,
                           int64_t o_batch_stride, float scale, fk_stream_t stream);
-/* Measurement hook: 1 = the blocks of a grid's last, partly filled round of CUs run as four / two "light" workgroups
- * (all 8 waves load K / V, 2 / 4 own query rows) so that they spread over the idle CUs; 0 (default; FK_ATTN_TAIL
- * overrides) = plain grid -- the light form measured slower inside an edit (profiles/r03_attention_variants.txt).  Same
- * results bit for bit: a query row's arithmetic does not depend on the workgroup shape that carries it. */
-int fk_attention_set_tail(int32_t mode);
-/* Measurement hook: K / V ring of the forward kernel: 3 stages = one workgroup barrier per 64-key tile (default;
- * FK_ATTN_RING overrides), 4 stages = one barrier per two tiles.  Same results bit for bit. */
-int fk_attention_set_ring(int32_t stages);
+/* The same with a caller-owned stream-K workspace (fk_attention_ws_bytes() bytes, 16-byte aligned, zeroed ONCE at
+ * allocation: its control words are monotonic tickets afterwards; launches that share it must be ordered, i.e. one
+ * workspace per stream) and an optional lse output ([B, H, S] fp32, log2 domain; NULL: none).  With the workspace, a grid
+ * that would leave >= 4 % of its rounds of one-workgroup-per-CU idle (B = 1: S = 8704 is 816 blocks = 3.19 rounds,
+ * S = 5632 2.06) runs as a PERSISTENT grid: the KV tiles of all (b, h, 256-row block) items are dealt out as equal
+ * contiguous ranges, one per CU, and a block whose keys straddle two CUs is finished by whichever arrives second
+ * (fp32 partials through the workspace, agent-scope ticket + flag; deterministic: the merge is symmetric).  ws = NULL or
+ * fk_attention_set_split(0): always one workgroup per block. */
+int fk_attention_fwd_ws_bf16(const void* q, const void* k, const void* v, void* o, float* lse, int32_t B, int32_t H,
+                             int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld, int64_t o_batch_stride,
+                             float scale, void* ws, int64_t ws_bytes, fk_stream_t stream);
+int64_t fk_attention_ws_bytes(void);
+/* 1 (default; FK_ATTN_SPLIT overrides): stream-K grids where they pay; 0: never ("batch-invariant": where a block's keys
+ * are cut depends on the grid, so with 1 a sample computed inside a batch may differ in the last bits from the same
+ * sample computed alone -- like fk_gemm_set_plan's split-K bit).  mode >= 2 (test hook): a persistent grid of `mode`
+ * workgroups whenever every item would be cut at most once, whatever the grid's waste. */
+int fk_attention_set_split(int32_t mode);
 
 /* Parity / debug build of the SAME kernel (same tiling, LDS layouts, softmax, key <-> MFMA k-slot binding): the output
  * is fp32 (o_ld / o_batch_stride in fp32 elements, 16-byte aligned) and every probability enters the PV product as

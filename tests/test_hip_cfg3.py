@@ -158,56 +158,85 @@ def test_vae_decode_512sq_matches_fp32_oracle():
     assert d.max().item() <= 5e-2 * scale and d.mean().item() <= 5e-3 * scale
 
 
-@pytest.mark.parametrize("B,H,S", [(1, 24, 8704), (1, 24, 5632), (1, 24, 3500), (2, 18, 2200)])
-def test_attention_tail_workgroups_give_the_same_bits(B, H, S):
-    """The optional "light workgroup" form of the last, partly filled round of CUs (csrc/attention_fwd.hip; off by
-    default): 816 blocks = 3 rounds + 48 -> 192 light workgroups of 64 rows; 528 = 2 rounds + 16; 336 = 1 round + 80 ->
-    160 of 128 rows with a ragged last block; 324 = 1 round + 68.  A query row's arithmetic does not depend on the
-    workgroup carrying it."""
+@pytest.mark.parametrize("B,H,S,split", [(1, 24, 8704, 1), (1, 24, 5632, 1), (1, 24, 3500, 1), (2, 18, 2200, 1),
+                                         (1, 2, 2048, 5), (2, 3, 1000, 7), (1, 4, 4100, 3)])
+def test_attention_stream_k_grid(B, H, S, split):
+    """Round 4: the attention forward as a persistent stream-K grid (csrc/attention_fwd.hip): the KV tiles of all
+    (b, h, 256-row block) items dealt out as equal contiguous ranges, one per CU; an item whose keys straddle two CUs is
+    finished by whichever arrives second (fp32 partials + agent-scope ticket / flag through the workspace, symmetric merge).
+    Chosen by itself (split = 1) at 816 items (3.19 rounds of 256 CUs), 528 (2.06) and 336 (1.31, ragged last tile), not at
+    324 items of 35 tiles (ranges shorter than an item + two minimum parts); forced small grids (split >= 2: the test hook)
+    put cuts into short sequences, a ragged tile and batch > 1.  Against the plain grid: deterministic, every row that is
+    not cut bit-identical, cut rows within bf16 rounding, lse to 1e-5; and against fp32 SDPA for the last head."""
     _skip()
-    from gpt_image_edit_amd import libfk, ops
+    from gpt_image_edit_amd import ops
     q, k = _randn(B, H, S, 128, seed=140).cuda(), _randn(B, H, S, 128, seed=141).cuda()
     qkv = _randn(B, S, 3 * H * 128, seed=142).cuda()
-    lib = libfk.load()
     outs = []
     try:
-        for mode in (0, 1, 1):
-            libfk.check(lib.fk_attention_set_tail(mode), "fk_attention_set_tail")
+        for mode in (0, split, split):
+            ops.attention_set_split(mode)
             o = torch.full((B, S, H * 128), 7.0, dtype=BF, device="cuda")
             lse = torch.empty(B, H, S, device="cuda", dtype=torch.float32)
             ops.attention_lse(q, k, qkv[:, :, 2 * H * 128:], o, lse)
             outs.append((o, lse))
     finally:
-        lib.fk_attention_set_tail(0)
+        ops.attention_set_split(1)
     torch.cuda.synchronize()
-    assert torch.isfinite(outs[0][0].float()).all()
-    for o, lse in outs[1:]:
-        assert torch.equal(o, outs[0][0]) and torch.equal(lse, outs[0][1])
-    # and against the fp32 reference for one head (the light kernels are instantiations no other test reaches)
+    (o0, l0), (o1, l1), (o2, l2) = outs
+    assert torch.isfinite(o1.float()).all() and torch.isfinite(l1).all()
+    assert torch.equal(o1, o2) and torch.equal(l1, l2), "stream-K grid is not deterministic"
+    n_items, nkt, G = B * H * ((S + 255) // 256), (S + 63) // 64, 256 if split == 1 else split
+    expect_split = n_items * nkt >= G * (nkt + 16) and (split > 1 or (n_items > G and -n_items % G * 25 >= (n_items + -n_items % G)))
+    same_rows = (o0.view(B, S, H, 128) == o1.view(B, S, H, 128)).all(dim=-1)       # [B, S, H]
+    frac_same = same_rows.float().mean().item()
+    print(f"[parity] stream-K B{B} H{H} S{S} split={split}: {n_items} items x {nkt} tiles on {G} workgroups; rows bit-identical "
+          f"to the plain grid: {frac_same:.4f}; max |d| {(o0.float() - o1.float()).abs().max().item():.3e}; "
+          f"lse max |d| {(l0 - l1).abs().max().item():.3e}", flush=True)
+    if not expect_split:
+        assert torch.equal(o0, o1) and torch.equal(l0, l1)
+    else:
+        assert frac_same < 1.0, "the stream-K grid did not run"
+        assert frac_same >= 1.0 - (G - 1) * 256 / (B * H * S) - 1e-9           # at most one cut item (256 rows) per workgroup boundary
+        scale = o0.float().abs().max().item()
+        assert (o0.float() - o1.float()).abs().max().item() <= 2 ** -7 * scale  # both are bf16 roundings of nearby fp32 values
+        assert (l0 - l1).abs().max().item() <= 5e-4
+    # and against the fp32 reference for one head (the stream-K kernels are instantiations no other test reaches)
     h = H - 1
     v = qkv[:, :, 2 * H * 128:].reshape(B, S, H, 128)[:, :, h].float().cpu()
     ref = F.scaled_dot_product_attention(q[:, h].float().cpu()[:, None], k[:, h].float().cpu()[:, None], v[:, None])[:, 0]
-    d = report(f"attention tail B{B} H{H} S{S} (last head)", outs[1][0][:, :, h * 128:(h + 1) * 128], ref)
-    assert d.max().item() <= 1e-2 * ref.abs().max().item()
+    d = report(f"attention stream-K B{B} H{H} S{S} (last head)", o1[:, :, h * 128:(h + 1) * 128], ref)
+    assert d.max().item() <= 1e-2 * ref.abs().max().item() and d.mean().item() <= 1e-3 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("B,H,S", [(1, 3, 8704), (2, 2, 2500), (1, 2, 64), (1, 2, 100)])
-def test_attention_ring_of_four_gives_the_same_bits(B, H, S):
-    """fk_attention_set_ring(4): one workgroup barrier per TWO KV tiles (4-stage ring) instead of one per tile -- the same
-    arithmetic behind other synchronisation; odd / even / single tile counts and a ragged last tile."""
+def test_attention_stream_k_parts_restart_on_exponent_overflow():
+    """The exact-maximum restart (a row outgrows its fixed exponent reference by more than fp32's range) inside PARTS of a
+    cut item: one outlier key in the second half of the sequence (the part that holds it restarts, the other does not, the
+    merge rescales both to the larger reference) and one in the first tile."""
     _skip()
-    from gpt_image_edit_amd import libfk, ops
-    q, k = _randn(B, H, S, 128, seed=150).cuda(), _randn(B, H, S, 128, seed=151).cuda()
-    qkv = _randn(B, S, 3 * H * 128, seed=152).cuda()
-    lib = libfk.load()
-    outs = []
+    from gpt_image_edit_amd import ops
+    B, H, S = 1, 2, 2048
+    q, k = _randn(B, H, S, 128, seed=160), _randn(B, H, S, 128, seed=161)
+    qkv = _randn(B, S, 3 * H * 128, seed=162)
+    k[0, 0, 1500] = q[0, 0, 300] * 24.0      # q.k / sqrt(128) * log2(e) ~ +400 log2 units for query 300 (and large for others)
+    k[0, 1, 3] = q[0, 1, 900] * 24.0
     try:
-        for ring in (3, 4, 4):
-            libfk.check(lib.fk_attention_set_ring(ring), "fk_attention_set_ring")
-            o = torch.full((B, S, H * 128), 7.0, dtype=BF, device="cuda")
-            ops.attention(q, k, qkv[:, :, 2 * H * 128:], o)
-            outs.append(o)
+        ops.attention_set_split(5)
+        o = torch.empty(B, S, H * 128, dtype=BF, device="cuda")
+        lse = torch.empty(B, H, S, device="cuda", dtype=torch.float32)
+        ops.attention_lse(q.cuda(), k.cuda(), qkv.cuda()[:, :, 2 * H * 128:], o, lse)
+        ops.attention_set_split(0)
+        o0 = torch.empty_like(o)
+        ops.attention(q.cuda(), k.cuda(), qkv.cuda()[:, :, 2 * H * 128:], o0)
     finally:
-        lib.fk_attention_set_ring(3)
+        ops.attention_set_split(1)
     torch.cuda.synchronize()
-    assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    v = qkv[:, :, 2 * H * 128:].reshape(B, S, H, 128).transpose(1, 2).float()
+    ref = F.scaled_dot_product_attention(q.float(), k.float(), v).transpose(1, 2).reshape(B, S, H * 128)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    d = report("attention stream-K with outlier keys", o, ref)
+    d0 = report("attention plain grid with outlier keys", o0, ref)
+    scale = ref.abs().max().item()
+    assert d.max().item() <= 1e-2 * scale and d0.max().item() <= 1e-2 * scale
+    ref_lse = torch.logsumexp(torch.einsum("bhqd,bhkd->bhqk", q.float(), k.float()) * 128 ** -0.5, dim=-1) * 1.4426950408889634
+    assert (lse.cpu() - ref_lse).abs().max().item() <= 2e-2

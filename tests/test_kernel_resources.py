@@ -23,7 +23,9 @@ BUDGET = {
     # K loop (at most 8 stores + 8 loads per workgroup); every other instantiation keeps everything in registers
     "gemm_pingpong_bf16.hip": [("gemm8_kernelILi", 0), ("gemm9_kernel", 0), ("gemm_mix_kernel", 0)],
 }
-EXCEPTIONS = {"gemm8_kernelILi": ("Lb1ELi0EEE", 136, 32)}   # key -> (name fragment, max scratch bytes, max spilled VGPRs)
+# key -> [(name fragment, max scratch bytes, max spilled VGPRs)]; the fp32-output parity build of the split-K form (epilogue
+# 64 = FK_EPI_F32DBG, test-only) keeps its bias quads live across the rendezvous as well: more of the same, still outside the K loop
+EXCEPTIONS = {"gemm8_kernelILi": [("ILi64ELi256ELb1ELi0EEE", 320, 72), ("Lb1ELi0EEE", 136, 32)]}
 
 
 @pytest.mark.parametrize("src", sorted(BUDGET))
@@ -43,15 +45,12 @@ def test_hot_kernels_keep_their_accumulators_in_registers(src, tmp_path):
         for key, max_scratch in BUDGET[src]:
             if key in name:
                 seen += 1
-                # two waves per SIMD -> 256 registers each; the light attention workgroups (2 / 4 waves = one wave per
-                # SIMD, launched for the last partial round only) may take the whole 512-entry file
-                light = "attention_fwd_kernelILi2E" in name or "attention_fwd_kernelILi4E" in name
-                assert int(vgprs) <= (512 if light else 256), f"{name}: {vgprs} VGPRs"
-                frag, relaxed, max_spills = EXCEPTIONS.get(key, (None, 0, 16))
-                if frag and frag in name:
-                    max_scratch = relaxed
-                else:
-                    max_spills = 16
+                assert int(vgprs) <= 256, f"{name}: {vgprs} VGPRs"      # two waves per SIMD -> 256 registers each
+                max_spills = 16
+                for frag, relaxed, relaxed_spills in EXCEPTIONS.get(key, []):
+                    if frag in name:
+                        max_scratch, max_spills = relaxed, relaxed_spills
+                        break
                 assert int(scratch) <= max_scratch, f"{name}: {scratch} B of scratch per lane (arrays in private memory?)"
                 assert int(spills) <= max_spills, f"{name}: {spills} spilled VGPRs"
     assert seen >= len(BUDGET[src]), f"expected kernels {BUDGET[src]} in {src}"

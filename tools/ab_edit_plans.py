@@ -2,8 +2,7 @@
 once per round (1 warm-up + `edits` timed edits), medians over the rounds are printed, then one instrumented edit per arm
 (per-family HIP-event sums, as bench.py).  An arm = comma-separated switches:
     plan=<0..3>   fk_gemm_set_plan (bit 0 mixed grids, bit 1 split-K pairs)
-    tail=<0|1>    fk_attention_set_tail (light workgroups for the attention grid's last round)
-    ring=<3|4>    fk_attention_set_ring (one barrier per KV tile / per two tiles)
+    split=<0|1>   fk_attention_set_split (stream-K attention grids where the plain grid wastes a round)
     side=<0|1|auto>  transformer.OVERLAP_MLP (single blocks' MLP-up GEMM on a second stream)
 
     AB_ARMS="plan=0;plan=1;plan=3" python tools/ab_edit_plans.py [workload] [rounds] [edits]
@@ -30,17 +29,14 @@ DEFAULT_SIDE = transformer.OVERLAP_MLP
 
 def apply(arm):
     ops.gemm_set_plan(3)
-    lib.fk_attention_set_tail(0)
-    lib.fk_attention_set_ring(3)
+    lib.fk_attention_set_split(1)
     transformer.OVERLAP_MLP = DEFAULT_SIDE
     for kv in arm.split(","):
         k, v = kv.split("=")
         if k == "plan":
             ops.gemm_set_plan(int(v))
-        elif k == "tail":
-            lib.fk_attention_set_tail(int(v))
-        elif k == "ring":
-            lib.fk_attention_set_ring(int(v))
+        elif k == "split":
+            lib.fk_attention_set_split(int(v))
         elif k == "side":
             transformer.OVERLAP_MLP = {"0": False, "1": True}.get(v, "auto")
         else:
