@@ -45,6 +45,7 @@ sys.path.insert(0, ROOT)
 
 BF = torch.bfloat16
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak, MI355X_MICROARCH.md
+PEAK_HBM_GBPS = 8000.0     # HBM3E peak (spec), MI355X_MICROARCH.md; a float4 copy reaches 6.29 TB/s
 WORKLOADS = {
     # name: (batch per GPU, height, width, cond_h, cond_w, S_txt)
     "cfg2_single_512x512_28step": (1, 512, 512, 512, 512, 512),
@@ -55,9 +56,8 @@ WORKLOADS = {
     "cfg4_slice4_1024x1024_28step": (4, 1024, 1024, 1024, 1024, 512),
 }
 EXTRA_WORKLOAD = "single_1024x1024_28step"
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
-if not os.path.exists(TRAFFIC_FILE):
-    TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"))
+                     if os.path.exists(f)), os.path.join(ROOT, "profiles", "r04_traffic.json"))
 
 
 def build_pipeline(device, n_double=19, n_single=38):
@@ -102,15 +102,24 @@ def instrumented_edit(pipe, inp):
     rec = {"gemm": [], "attention": [], "conv": []}
     st = torch.cuda.current_stream()
 
-    def wrap(fn, fam, flops_of):
+    def wrap(fn, fam, flops_of, bytes_of=None):
         def inner(*a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
             out = fn(*a, **k)
             e1.record(st)
-            rec[fam].append((flops_of(a, k, out), e0, e1))
+            rec[fam].append((flops_of(a, k, out), e0, e1, bytes_of(a, k, out) if bytes_of else 0.0))
             return out
         return inner
+
+    # ALGORITHMIC bytes per launch: every operand read once, the output written once
+    def attn_bytes(a, k, out):
+        B, H, S, hd = a[0].shape
+        return 4.0 * B * H * S * hd * 2              # Q, K, V read + O written, bf16
+
+    def conv_bytes(a, k, out):                       # conv2d_nhwc / conv3x3_halo (x, w_packed, bias, cout, ...): input + weights + output
+        res = k.get("res")
+        return (a[0].numel() + a[1].numel() + out.numel() + (res.numel() if res is not None else 0)) * 2.0
 
     def gemm_flops(a, k, out):
         A, Wt = a[0], a[1]
@@ -135,8 +144,8 @@ def instrumented_edit(pipe, inp):
     orig = (ops.gemm, ops.gemm_grouped, ops.attention, ops.conv2d_nhwc, ops.conv3x3_halo)
     ops.gemm, ops.gemm_grouped, ops.attention, ops.conv2d_nhwc, ops.conv3x3_halo = (
         wrap(ops.gemm, "gemm", gemm_flops), wrap(ops.gemm_grouped, "gemm", grouped_flops),
-        wrap(ops.attention, "attention", attn_flops), wrap(ops.conv2d_nhwc, "conv", conv_flops),
-        wrap(ops.conv3x3_halo, "conv", halo_flops))
+        wrap(ops.attention, "attention", attn_flops, attn_bytes), wrap(ops.conv2d_nhwc, "conv", conv_flops, conv_bytes),
+        wrap(ops.conv3x3_halo, "conv", halo_flops, conv_bytes))
     try:
         run_edit(pipe, inp)
         torch.cuda.synchronize()
@@ -146,9 +155,11 @@ def instrumented_edit(pipe, inp):
         pipe.use_graph = use_graph
     out = {}
     for fam, lst in rec.items():
-        ms = sum(e0.elapsed_time(e1) for _, e0, e1 in lst)
-        fl = sum(f for f, _, _ in lst)
-        out[fam] = dict(launches=len(lst), ms=ms, flops=fl, tflops=(fl / (ms * 1e-3) / 1e12) if ms > 0 else 0.0)
+        ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in lst)
+        fl = sum(f for f, _, _, _ in lst)
+        by = sum(b for _, _, _, b in lst)
+        out[fam] = dict(launches=len(lst), ms=ms, flops=fl, tflops=(fl / (ms * 1e-3) / 1e12) if ms > 0 else 0.0,
+                        algorithmic_bytes=by, gbps=(by / (ms * 1e-3) / 1e9) if ms > 0 else 0.0)
     return out
 
 
@@ -170,8 +181,15 @@ def roofline_of(fam, workload):
         "bound": "mfma", "achieved": gm["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": gm["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
         "launches_per_edit": gm["launches"], "ms_per_edit": gm["ms"], "algorithmic_tflop_per_edit": gm["flops"] / 1e12,
-        "other_kernels": {k: {"ms_per_edit": v["ms"], "tflops": v["tflops"], "launches": v["launches"]}
+        # the other MFMA kernels of the path: rate against the MFMA peak AND achieved HBM GB/s on their algorithmic bytes
+        # (north star: "achieved HBM GB/s on the attention / VAE kernels"): both are far from bandwidth-bound by design
+        "other_kernels": {k: {"ms_per_edit": v["ms"], "tflops": v["tflops"], "launches": v["launches"],
+                              "frac_of_mfma_peak": v["tflops"] / PEAK_BF16_TFLOPS,
+                              "algorithmic_gb_per_edit": v["algorithmic_bytes"] / 1e9, "hbm_gbps_algorithmic": v["gbps"],
+                              "frac_of_hbm_peak": v["gbps"] / PEAK_HBM_GBPS}
                           for k, v in fam.items() if k != "gemm"},
+        "traffic_source": ("committed PMC passes (" + os.path.relpath(TRAFFIC_FILE, ROOT) + ", tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE in "
+                           "their own rocprofv3 passes, calibrated on a 1 GiB copy), per launch of the largest launch class; NOT counted in this run"),
     }
     if traffic_note:
         rl["traffic_note"] = traffic_note

@@ -30,7 +30,16 @@ def sep():
     ops.silu(torch.zeros(8, device="cuda", dtype=BF))
 
 
+SKIP = [t for t in os.environ.get("TRAFFIC_SKIP", "").split(",") if t]    # substrings of item names to leave out (saves box time)
+
+
+def skipped(name):
+    return any(t in name for t in SKIP)
+
+
 def item(name, kernel_substr, fn, alg_read, alg_write, flops=0.0, note=""):
+    if skipped(name):
+        return
     for _ in range(REPS):
         fn()
     sep()
@@ -49,6 +58,8 @@ def main():
     del src, dst
     D = 3072
     for B, S in ((1, 8704), (32, 8704)):
+        if skipped(f"ln_modulate B{B} S{S}"):
+            continue
         x, o = rnd(B, S, D), torch.empty(B, S, D, device="cuda", dtype=BF)
         mod = rnd(B, 6 * D, scale=0.3)
         item(f"ln_modulate B{B} S{S}", "ln_modulate", lambda: ops.ln_modulate(x, mod[:, :D], mod[:, D:2 * D], out=o),
@@ -61,6 +72,8 @@ def main():
                               (8704, 9216, 3072, 0, "qkv 1024^2"), (8704, 12288, 3072, 1, "mlp-up 1024^2 (GELU)"),
                               (8704, 3072, 15360, 0, "proj_out 1024^2 (K-long)"),
                               (278528, 3072, 3072, 0, "out-proj cfg3 (B=32)")):
+        if skipped(f"gemm {M}x{N}x{K} {tag}"):
+            continue
         a, w, b = rnd(M, K), rnd(N, K, scale=0.05), rnd(N)
         c = torch.empty(M, N, device="cuda", dtype=BF)
         item(f"gemm {M}x{N}x{K} {tag}", "gemm", lambda: ops.gemm(a, w, b, out=c, epilogue=epi),
@@ -69,6 +82,8 @@ def main():
     # ---- attention (algorithmic: Q, K, V read once, O written once = 4 * S * 128 * 2 B per head) ------------------
     H = 24
     for B, S in ((1, 2560), (1, 8704), (8, 8704)):
+        if skipped(f"attention B{B} S{S}"):
+            continue
         q, k, qkv = rnd(B, H, S, 128), rnd(B, H, S, 128), rnd(B, S, 3 * H * 128)
         o = torch.empty(B, S, H * 128, device="cuda", dtype=BF)
         item(f"attention B{B} S{S}", "attention_fwd", lambda: ops.attention(q, k, qkv[:, :, 2 * H * 128:], o),
@@ -76,10 +91,11 @@ def main():
              note="K/V of one head are re-read by every query block of that head (from L2 / MALL when they fit)")
         del q, k, qkv, o
     # ---- VAE decode at the 1024^2 size: conv (implicit GEMM) and GroupNorm kernels ---------------------------------
-    vae = HipAutoencoderKL(device="cuda", init="synthetic", seed=1)
-    z = rnd(4, 16, 128, 128)
-    vae.decode(z, return_dict=False)     # packs weights
-    sep()
+    if not skipped("vae.decode B4 128x128 latent"):
+        vae = HipAutoencoderKL(device="cuda", init="synthetic", seed=1)
+        z = rnd(4, 16, 128, 128)
+        vae.decode(z, return_dict=False)     # packs weights
+        sep()
     item("vae.decode B4 128x128 latent", "*", lambda: vae.decode(z, return_dict=False), 4 * 13.4e9 / 2, 4 * 13.4e9 / 2,
          flops=4 * 10.47e12, note="whole decoder (all its kernels summed): BASELINE.md quotes ~13.4 GB fused-ideal activation traffic per 1024^2 image")
     torch.cuda.synchronize()
