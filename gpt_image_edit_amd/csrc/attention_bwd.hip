@@ -66,7 +66,14 @@ struct BwdParams {
   int64_t o2_ld, o2_hs, o2_bs;
   int B, H, S;
   float scale, scale_log2;
+  // stream-K launch of the dQ pass (attention_fwd.hip has the scheme): sk_rounds whole rounds of one 256-row item per
+  // workgroup, then the remaining items' column tiles dealt out as G equal contiguous ranges; the two parts of a cut item
+  // add their fp32 accumulators through workspace slot j (ticket / flag pair sk_ctl[2 j], [2 j + 1])
+  int n_items, sk_rounds, min_part;
+  float* sk_partials;
+  unsigned* sk_ctl;
 };
+constexpr int PART_FLOATS = 256 * 128 + 2 * 512;   // the attention forward's slot layout (the (l, m) pairs are unused here)
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -90,7 +97,7 @@ FK_DEV void wait_vmcnt() {
 }
 FK_DEV int swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }   // slot XOR of LDS row r (header)
 
-template <int MODE>
+template <int MODE, bool STREAMK = false>
 __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p) {
   constexpr bool HAS_C = MODE != MODE_DV;          // second product (dp) and its streamed image
   constexpr bool COL_STATS = MODE != MODE_DQ;      // lse / D vary along the streamed dimension
@@ -109,8 +116,53 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     t0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   }
-  const int rb = t0 % nrb;
-  const int bh = t0 / nrb;
+  const int nt = (p.S + CBLK - 1) / CBLK;
+  const bool ragged = p.S % CBLK != 0;
+  // ---- work list (attention_fwd.hip, "the workgroup's work list"): plain launch = the one item t0 ---------------------------
+  int u = 0, u_end = 0, round = 0;
+  if constexpr (STREAMK) {
+    const unsigned G = gridDim.x;
+    const unsigned U = (unsigned)(p.n_items - p.sk_rounds * (int)G) * (unsigned)nt;
+    const unsigned qU = U / G, rU = U - qU * G;
+    auto cut = [&](unsigned j) __attribute__((always_inline)) {
+      unsigned c = qU * j + (rU * j) / G;
+      const unsigned r = c % (unsigned)nt;
+      if (r != 0 && r < (unsigned)p.min_part) c -= r;
+      else if (r != 0 && (unsigned)nt - r < (unsigned)p.min_part) c += (unsigned)nt - r;
+      return (int)c;
+    };
+    u = cut(t0);
+    u_end = cut(t0 + 1);
+  }
+  // operand read addresses (lane constants)
+  const int k_rd = ql * 256, k_sw = swz(ql);
+  const int tj = (lane & 15) >> 2, tq = lane & 3, tdh = (lane >> 4) & 1;
+  // transpose read of tile rows 16 st + 4 hh + tj (lo) and + 8 (hi): logical slot 4 df + 2 tdh + tq / 2, physical slot
+  // ^ swz(row) = 4 (df ^ tj) + ((2 tdh + tq / 2) ^ (hh + 2 hi))
+  const int t_lo = (4 * hh + tj) * 256 + (((2 * tdh + (tq >> 1)) ^ hh) << 4) + (tq & 1) * 8;
+  const int t_hi = (4 * hh + tj + 8) * 256 + (((2 * tdh + (tq >> 1)) ^ (hh + 2)) << 4) + (tq & 1) * 8;
+  const int prow = lane >> 4, pslot = lane & 15;
+  // waves w and w + 4 share a SIMD; the later-dispatched half loses the VALU arbitration at the head of every segment:
+  // one static priority raise for it (MI355X_MICROARCH.md, "Two waves per SIMD", item 4); the condition is wave-uniform
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+
+  for (;;) {   // one pass per (item, column-tile range); a plain launch makes exactly one
+  int item = t0, tb = 0, te = nt;                       // this pass: column tiles [tb, te) of the item
+  if constexpr (STREAMK) {
+    if (round < p.sk_rounds) {
+      item = round * (int)gridDim.x + t0;
+      ++round;
+    } else {
+      if (u >= u_end) break;
+      const int ti = (unsigned)u / (unsigned)nt;
+      item = p.sk_rounds * (int)gridDim.x + ti;
+      tb = u - ti * nt;
+      te = min(nt, tb + (u_end - u));
+      u += te - tb;
+    }
+  }
+  const int rb = item % nrb;
+  const int bh = item / nrb;
   const int b = bh / p.H, h = bh - b * p.H;
 
   // which tensors play which role: image 0 feeds the s product (row fragments), image 1 the dp product (row fragments) or,
@@ -146,18 +198,15 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
   for (int r = 0; r < 16; ++r) dini[r] = d_l;
 
   // ---- LDS-DMA of the streamed tiles: piece = 4 rows x 256 B, lane -> (row = lane / 16, 16-byte slot = lane % 16) ---
-  const int prow = lane >> 4, pslot = lane & 15;
-  auto rsrc_of = [&](const TView& t) {
+  auto rsrc_of = [&](const TView& t) __attribute__((always_inline)) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)(t.p + (int64_t)b * t.bs + (int64_t)h * t.hs), 0,
                                              (int)(((int64_t)(p.S - 1) * t.ld + HD) * 2), 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t rs_0 = rsrc_of(T0), rs_1 = rsrc_of(T1);
   const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lse + (int64_t)bh * p.S), 0, p.S * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dsum + (int64_t)bh * p.S), 0, p.S * 4, 0x00020000);
-  const int nt = (p.S + CBLK - 1) / CBLK;
-  const bool ragged = p.S % CBLK != 0;
   // byte offset of source row q for LDS row r: the swizzle follows the LDS row
-  auto voff = [&](const TView& t, int q, int r) { return (int)((q * t.ld + ((pslot ^ swz(r)) << 3)) * 2); };
+  auto voff = [&](const TView& t, int q, int r) __attribute__((always_inline)) { return (int)((q * t.ld + ((pslot ^ swz(r)) << 3)) * 2); };
   int v0[2], v1[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -165,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
     v0[i] = voff(T0, r, r);
     v1[i] = voff(T1, r, r);
   }
-  auto issue_tile = [&](int t, int stage) {
+  auto issue_tile = [&](int t, int stage) __attribute__((always_inline)) {
     char* sb = smem + stage * STAGE_BYTES;
     const int base_row = t * CBLK;
     int a0 = v0[0], a1 = v0[1], c0 = v1[0], c1 = v1[1], sl = lane * 4;
@@ -190,16 +239,10 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
   };
 
   // ---- operand reads -------------------------------------------------------------------------------------------------
-  const int k_rd = ql * 256, k_sw = swz(ql);
-  const int tj = (lane & 15) >> 2, tq = lane & 3, tdh = (lane >> 4) & 1;
-  // transpose read of tile rows 16 st + 4 hh + tj (lo) and + 8 (hi): logical slot 4 df + 2 tdh + tq / 2, physical slot
-  // ^ swz(row) = 4 (df ^ tj) + ((2 tdh + tq / 2) ^ (hh + 2 hi))
-  const int t_lo = (4 * hh + tj) * 256 + (((2 * tdh + (tq >> 1)) ^ hh) << 4) + (tq & 1) * 8;
-  const int t_hi = (4 * hh + tj + 8) * 256 + (((2 * tdh + (tq >> 1)) ^ (hh + 2)) << 4) + (tq & 1) * 8;
-  auto rowfrag = [&](const char* sb, int img, int kb, int kk) {
+  auto rowfrag = [&](const char* sb, int img, int kb, int kk) __attribute__((always_inline)) {
     return *(const bf16x8_t*)(sb + img * IMG + k_rd + kb * 8192 + (((2 * kk + hh) ^ k_sw) << 4));
   };
-  auto trfrag = [&](const char* sb, int st, int df) {   // columns 16 st + {0, 8} + 4 hh + 0..3, d block df
+  auto trfrag = [&](const char* sb, int st, int df) __attribute__((always_inline)) {   // columns 16 st + {0, 8} + 4 hh + 0..3, d block df
     const char* vp = sb + TR_IMG * IMG + st * 4096 + ((df ^ tj) << 6);
     const s16x4_t lo = lds_tr16(vp + t_lo);
     const s16x4_t hi = lds_tr16(vp + t_hi);
@@ -218,14 +261,11 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
   int st_cur = 0, st_pf = PF;
 #pragma unroll
   for (int s = 0; s < PF; ++s)
-    if (s < nt) issue_tile(s, s);
-  // waves w and w + 4 share a SIMD; the later-dispatched half loses the VALU arbitration at the head of every segment:
-  // one static priority raise for it (MI355X_MICROARCH.md, "Two waves per SIMD", item 4); the condition is wave-uniform
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (tb + s < te) issue_tile(tb + s, s);
 
   // one streamed tile; with the mask tag the ragged last one (w of the columns beyond S zeroed) -- two instantiations,
   // so the 135 full tiles of a 136-tile row do not carry the compare / select pairs
-  auto tile_body = [&](const char* sb, int t, auto mask_tag) {
+  auto tile_body = [&](const char* sb, int t, auto mask_tag) __attribute__((always_inline)) {
     constexpr bool MASK = decltype(mask_tag)::value;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -304,19 +344,68 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
     }
   };
 
-  auto acquire = [&](int t) {   // tile t has landed everywhere; the stage of tile t - 1 is free for tile t + PF
-    if (t + PF - 1 < nt) wait_vmcnt<(PF - 1) * LOADS>();
+  auto acquire = [&](int t) __attribute__((always_inline)) {   // tile t has landed everywhere; the stage of tile t - 1 is free for tile t + PF
+    if (t + PF - 1 < te) wait_vmcnt<(PF - 1) * LOADS>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (t + PF < nt) issue_tile(t + PF, st_pf);
+    if (t + PF < te) issue_tile(t + PF, st_pf);
     const char* sb = smem + st_cur * STAGE_BYTES;
     st_cur = (st_cur == STAGES - 1) ? 0 : st_cur + 1;
     st_pf = (st_pf == STAGES - 1) ? 0 : st_pf + 1;
     return sb;
   };
-  const int n_plain = ragged ? nt - 1 : nt;
-  for (int t = 0; t < n_plain; ++t) tile_body(acquire(t), t, std::false_type{});
-  if (ragged) tile_body(acquire(nt - 1), nt - 1, std::true_type{});   // after the loop: one accumulator live range each
+  const bool masked = ragged && te == nt;               // the pass ends with the item's ragged tile
+  const int n_plain = masked ? te - 1 : te;
+  for (int t = tb; t < n_plain; ++t) tile_body(acquire(t), t, std::false_type{});
+  if (masked) tile_body(acquire(nt - 1), nt - 1, std::true_type{});   // after the loop: one accumulator live range each
+
+  // ---- stream-K seam (attention_fwd.hip): the two parts of a cut item ADD their accumulators; whoever arrives second does it
+  if constexpr (STREAMK) {
+    if (tb > 0 || te < nt) {                        // workgroup-uniform
+      typedef __attribute__((address_space(1))) unsigned gu32;
+      const int slot = te < nt ? t0 + 1 : t0;       // the cut's index, 1 .. G - 1
+      gu32* const ctl = (gu32*)(p.sk_ctl + 2 * (size_t)slot);
+      const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.sk_partials + (size_t)slot * PART_FLOATS), 0, PART_FLOATS * 4, 0x00020000);
+      __syncthreads();   // every wave is done with the ring: its first word now carries the ticket
+      if (tid == 0) *(volatile unsigned*)smem = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const unsigned ticket = __builtin_amdgcn_readfirstlane(*(volatile unsigned*)smem);
+      if ((ticket & 1u) == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const f32x16_t& a = acc[r >> 2];
+          const int q4 = r & 3;
+          const u32x4_t v = {__float_as_uint(a[4 * q4]), __float_as_uint(a[4 * q4 + 1]), __float_as_uint(a[4 * q4 + 2]),
+                             __float_as_uint(a[4 * q4 + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs_p, tid * 16, r * (512 * 16), /*sc1: write through*/ 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(ctl + 1, ticket + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        continue;
+      }
+      if (tid == 0) {
+        while (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket) __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += 4) {
+        u32x4_t v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, tid * 16, (r0 + e) * (512 * 16), /*sc1*/ 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f32x16_t& a = acc[(r0 + e) >> 2];
+          const int q4 = (r0 + e) & 3;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[4 * q4 + j] += __uint_as_float(v[e][j]);   // fp32 addition commutes: symmetric
+        }
+      }
+    }
+  }
 
   // ---- store: lane (row = ql) holds d = 32 df + 8 g + 4 hh + (0..3) ------------------------------------------------
   if (row < p.S) {
@@ -332,6 +421,9 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
         *(u32x2_t*)(op + 32 * df + 8 * g) = pk;
       }
   }
+  if constexpr (!STREAMK) break;
+  else __syncthreads();   // every wave is done with the ring and the ticket word before the next pass
+  }   // passes
 }
 
 // ---- dK and dV in one launch: producer / consumer wave pairs (header) ---------------------------------------------------
@@ -596,16 +688,28 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
   }
 }
 
-template <int MODE>
-int launch_bwd(const BwdParams& p, hipStream_t stream) {
+template <int MODE, bool STREAMK = false>
+int launch_bwd(const BwdParams& p, hipStream_t stream, int grid = 0) {
   constexpr int SMEM = STAGES * STAGE_BYTES;
-  auto kern = attention_bwd_kernel<MODE>;
+  auto kern = attention_bwd_kernel<MODE, STREAMK>;
   FK_ENSURE_MAX_LDS(kern, SMEM, "fk_attention_bwd_bf16");
   const int nrb = (p.S + 255) / 256;
-  hipLaunchKernelGGL(kern, dim3(nrb * p.H * p.B), dim3(512), SMEM, stream, p);
+  hipLaunchKernelGGL(kern, dim3(STREAMK ? grid : nrb * p.H * p.B), dim3(512), SMEM, stream, p);
   FK_CHECK_LAUNCH("fk_attention_bwd_bf16");
   return FK_OK;
 }
+
+int bwd_cu_count() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    else return 256;
+  }
+  return cus;
+}
+constexpr int BWD_MIN_PART = 8;
 
 int launch_dkv(const BwdParams& p, hipStream_t stream) {
   constexpr int SMEM = STAGES * STAGE_BYTES + PBUF_BYTES;
@@ -635,10 +739,12 @@ TView tv(const fk_attn_view& v) { return TView{(const bf16_t*)v.p, v.ld, v.head_
 
 }  // namespace
 
-extern "C" int fk_attention_bwd_bf16(const fk_attn_view* q, const fk_attn_view* k, const fk_attn_view* v,
-                                     const fk_attn_view* dout, const float* lse, const float* dsum, const fk_attn_view* dq,
-                                     const fk_attn_view* dk, const fk_attn_view* dv, int32_t B, int32_t H, int32_t S,
-                                     float scale, fk_stream_t stream_) {
+int fk_attention_split_mode(void);   // attention_fwd.hip: fk_attention_set_split / FK_ATTN_SPLIT
+
+static int attention_bwd_entry(const fk_attn_view* q, const fk_attn_view* k, const fk_attn_view* v,
+                               const fk_attn_view* dout, const float* lse, const float* dsum, const fk_attn_view* dq,
+                               const fk_attn_view* dk, const fk_attn_view* dv, int32_t B, int32_t H, int32_t S,
+                               float scale, void* ws, int64_t ws_bytes, fk_stream_t stream_) {
   FK_CHECK_ARG(q && k && v && dout && lse && dsum && dq && dk && dv, "fk_attention_bwd_bf16: null pointer");
   FK_CHECK_ARG(B > 0 && H > 0 && S > 0, "fk_attention_bwd_bf16: bad B/H/S %d %d %d", B, H, S);
   const fk_attn_view* all[7] = {q, k, v, dout, dq, dk, dv};
@@ -655,7 +761,27 @@ extern "C" int fk_attention_bwd_bf16(const fk_attn_view* q, const fk_attn_view* 
     p.out = (bf16_t*)o.p; p.o_ld = o.ld; p.o_hs = o.head_stride; p.o_bs = o.batch_stride;
   };
   set_out(*dq);
-  int rc = launch_bwd<MODE_DQ>(p, stream);
+  // dQ pass: stream-K grid where one workgroup per 256-row item would waste >= 4 % of its rounds of CUs (attention_fwd.hip)
+  int rc;
+  {
+    const int64_t n_items = (int64_t)((S + 255) / 256) * H * B, nt = (S + CBLK - 1) / CBLK;
+    const int mode = fk_attention_split_mode();
+    const int G = mode >= 2 ? (mode < bwd_cu_count() ? mode : bwd_cu_count()) : bwd_cu_count();
+    const int64_t rounds = (n_items + G - 1) / G;
+    const bool wasteful = mode >= 2 || (n_items > G && (rounds * G - n_items) * 25 >= rounds * G);
+    int sk_rounds = (int)(n_items / G) - 1;
+    while (sk_rounds >= 0 && (n_items - (int64_t)sk_rounds * G) * nt < (int64_t)G * (nt + 2 * BWD_MIN_PART)) --sk_rounds;
+    const int64_t need = (int64_t)G * (PART_FLOATS * 4 + 8);
+    if (mode && wasteful && sk_rounds >= 0 && ws && ws_bytes >= need && n_items * nt < (1ll << 31)) {
+      FK_CHECK_ARG((uintptr_t)ws % 16 == 0, "fk_attention_bwd_ws_bf16: workspace must be 16-byte aligned");
+      p.n_items = (int)n_items; p.sk_rounds = sk_rounds; p.min_part = BWD_MIN_PART;
+      p.sk_partials = (float*)ws;
+      p.sk_ctl = (unsigned*)((char*)ws + (size_t)G * PART_FLOATS * 4);
+      rc = launch_bwd<MODE_DQ, true>(p, stream, G);
+    } else {
+      rc = launch_bwd<MODE_DQ>(p, stream);
+    }
+  }
   if (rc != FK_OK) return rc;
   if (bwd_mode() != 0) {
     set_out(*dk);
@@ -667,6 +793,20 @@ extern "C" int fk_attention_bwd_bf16(const fk_attn_view* q, const fk_attn_view* 
   if (rc != FK_OK) return rc;
   set_out(*dk);
   return launch_bwd<MODE_DK>(p, stream);
+}
+
+extern "C" int fk_attention_bwd_bf16(const fk_attn_view* q, const fk_attn_view* k, const fk_attn_view* v,
+                                     const fk_attn_view* dout, const float* lse, const float* dsum, const fk_attn_view* dq,
+                                     const fk_attn_view* dk, const fk_attn_view* dv, int32_t B, int32_t H, int32_t S,
+                                     float scale, fk_stream_t stream_) {
+  return attention_bwd_entry(q, k, v, dout, lse, dsum, dq, dk, dv, B, H, S, scale, nullptr, 0, stream_);
+}
+
+extern "C" int fk_attention_bwd_ws_bf16(const fk_attn_view* q, const fk_attn_view* k, const fk_attn_view* v,
+                                        const fk_attn_view* dout, const float* lse, const float* dsum, const fk_attn_view* dq,
+                                        const fk_attn_view* dk, const fk_attn_view* dv, int32_t B, int32_t H, int32_t S,
+                                        float scale, void* ws, int64_t ws_bytes, fk_stream_t stream_) {
+  return attention_bwd_entry(q, k, v, dout, lse, dsum, dq, dk, dv, B, H, S, scale, ws, ws_bytes, stream_);
 }
 
 extern "C" int fk_attention_bwd_set_mode(int32_t mode) {

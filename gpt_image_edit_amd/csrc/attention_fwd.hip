@@ -755,6 +755,8 @@ int attention_entry(const void* q, const void* k, const void* v, void* o, int32_
 
 }  // namespace
 
+int fk_attention_split_mode(void) { return attn_split_mode(); }   // for attention_bwd.hip
+
 extern "C" int fk_attention_set_split(int32_t mode) {
   FK_CHECK_ARG(mode >= 0, "fk_attention_set_split: %d is not 0 (one workgroup per 256-row block, always), 1 (stream-K grids where they "
                "pay) or a workgroup count >= 2 (test hook: a persistent grid of that size whenever every item is cut at most once)", mode);

@@ -67,6 +67,7 @@ SIGNATURES = {
     "fk_attention_fwd_lse_bf16": (c_i32, [c_vp] * 5 + [c_i32] * 3 + [c_i64] * 4 + [c_f32, c_vp]),
     "fk_attention_bwd_set_mode": (c_i32, [c_i32]),
     "fk_attention_bwd_bf16": (c_i32, [ctypes.POINTER(AttnView)] * 4 + [c_vp, c_vp] + [ctypes.POINTER(AttnView)] * 3 + [c_i32] * 3 + [c_f32, c_vp]),
+    "fk_attention_bwd_ws_bf16": (c_i32, [ctypes.POINTER(AttnView)] * 4 + [c_vp, c_vp] + [ctypes.POINTER(AttnView)] * 3 + [c_i32] * 3 + [c_f32, c_vp, c_i64, c_vp]),
     "fk_bwd_ws_floats": (c_i64, []),
     "fk_ln_modulate_bwd_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_i64, c_i64, c_vp, Rows, c_vp, Rows, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_f32, c_vp]),
     "fk_gate_res_bwd_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_i64, c_i64, c_vp, Rows, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp]),

@@ -410,8 +410,9 @@ def attention_bwd(q, k, v, dout, lse, dsum, dq, dk, dv, scale=None):
     views = [attn_view(q, True), attn_view(k, True), attn_view(v, False), attn_view(dout, False),
              attn_view(dq, True), attn_view(dk, True), attn_view(dv, False)]
     r = [ctypes.byref(x) for x in views]
-    libfk.check(libfk.load().fk_attention_bwd_bf16(r[0], r[1], r[2], r[3], _ptr(lse), _ptr(dsum), r[4], r[5], r[6], B, H, S,
-                                                  hd ** -0.5 if scale is None else scale, _stream()),
+    ws = attention_workspace(q.device)      # the forward's stream-K workspace: the dQ pass uses the same scheme
+    libfk.check(libfk.load().fk_attention_bwd_ws_bf16(r[0], r[1], r[2], r[3], _ptr(lse), _ptr(dsum), r[4], r[5], r[6], B, H, S,
+                                                     hd ** -0.5 if scale is None else scale, _ptr(ws), ws.numel(), _stream()),
                 "fk_attention_bwd_bf16")
 
 

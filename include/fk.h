@@ -209,6 +209,13 @@ typedef struct fk_attn_view {
 int fk_attention_bwd_bf16(const fk_attn_view* q, const fk_attn_view* k, const fk_attn_view* v, const fk_attn_view* dout,
                           const float* lse, const float* dsum, const fk_attn_view* dq, const fk_attn_view* dk,
                           const fk_attn_view* dv, int32_t B, int32_t H, int32_t S, float scale, fk_stream_t stream);
+/* The same with the attention forward's stream-K workspace (fk_attention_ws_bytes(); shared with the forward on one stream):
+ * the dQ pass then runs as a persistent grid where one workgroup per 256-row block would waste part of a round of CUs
+ * (the parts of a cut block ADD their fp32 accumulators through the workspace: symmetric, deterministic). */
+int fk_attention_bwd_ws_bf16(const fk_attn_view* q, const fk_attn_view* k, const fk_attn_view* v, const fk_attn_view* dout,
+                             const float* lse, const float* dsum, const fk_attn_view* dq, const fk_attn_view* dk,
+                             const fk_attn_view* dv, int32_t B, int32_t H, int32_t S, float scale, void* ws, int64_t ws_bytes,
+                             fk_stream_t stream);
 /* Measurement / parity hook for fk_attention_bwd_bf16: 1 = two launches, the dQ pass and one pass in which wave pairs
  * produce dK and dV together (7 tile products, default; FK_ATTN_BWD overrides), 0 = three launches (dQ, dV, dK: 8 tile
  * products).  dQ and dV are the same bit for bit in both; dK differs in the last bf16 bit (mode 1 forms

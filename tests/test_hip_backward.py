@@ -172,3 +172,43 @@ def test_attention_backward(ops, B, H, S):
     close_bf16(f"attention_bwd dk (three passes) B{B} H{H} S{S}", dk3, kr.grad, tol=2e-2)
     scale_k = kr.grad.abs().max().item()
     assert (dk.float() - dk3.float()).abs().max().item() <= 2.0 ** -6 * scale_k
+
+
+@pytest.mark.parametrize("B,H,S,split", [(1, 2, 2048, 5), (2, 3, 1000, 7), (1, 4, 4100, 3)])
+def test_attention_backward_stream_k_dq_pass(ops, B, H, S, split):
+    """Round 4: the dQ pass as a stream-K grid (whole rounds + dealt-out tail of column tiles; the two parts of a cut 256-row
+    block ADD their fp32 accumulators through the workspace).  Forced small grids (fk_attention_set_split(n >= 2), the test
+    hook) against the plain grid: dK / dV untouched (bit for bit), dQ deterministic, bit-identical for every block that is
+    not cut and within bf16 rounding for the cut ones, and against fp32 autograd."""
+    D = H * 128
+    q, k = randn(B, H, S, 128, seed=40), randn(B, H, S, 128, seed=41)
+    qkv = randn(B, S, 3 * D, seed=42)
+    dout = randn(B, S, D, seed=43)
+    qr, kr = q.float().requires_grad_(True), k.float().requires_grad_(True)
+    vr = qkv[:, :, 2 * D:].float().reshape(B, S, H, 128).transpose(1, 2).detach().requires_grad_(True)
+    F.scaled_dot_product_attention(qr, kr, vr).backward(dout.float().reshape(B, S, H, 128).transpose(1, 2))
+    qd, kd, qkvd, doutd = q.cuda(), k.cuda(), qkv.cuda(), dout.cuda()
+    o = torch.empty(B, S, D, device="cuda", dtype=BF)
+    lse = torch.empty(B, H, S, device="cuda", dtype=torch.float32)
+    res = []
+    try:
+        ops.attention_set_split(0)
+        ops.attention_lse(qd, kd, qkvd[:, :, 2 * D:], o, lse)
+        dsum = ops.rowdot(doutd, o, H)
+        for mode in (0, split, split):
+            ops.attention_set_split(mode)
+            dq, dk, dqkv = torch.empty_like(qd), torch.empty_like(kd), torch.zeros_like(qkvd)
+            ops.attention_bwd(qd, kd, qkvd[:, :, 2 * D:], doutd, lse, dsum, dq, dk, dqkv[:, :, 2 * D:])
+            res.append((dq, dk, dqkv))
+    finally:
+        ops.attention_set_split(1)
+    torch.cuda.synchronize()
+    (dq0, dk0, dv0), (dq1, dk1, dv1), (dq2, dk2, dv2) = res
+    assert torch.equal(dk0, dk1) and torch.equal(dv0, dv1) and torch.equal(dq1, dq2) and torch.equal(dk1, dk2)
+    same = (dq0 == dq1).all(dim=-1)                    # [B, H, S]
+    frac = same.float().mean().item()
+    print(f"[parity] stream-K dQ B{B} H{H} S{S} on {split} workgroups: rows bit-identical to the plain grid {frac:.4f}, "
+          f"max |d| {(dq0.float() - dq1.float()).abs().max().item():.3e}", flush=True)
+    assert frac < 1.0 and frac >= 1.0 - (split - 1) * 256 / (B * H * S) - 1e-9
+    assert (dq0.float() - dq1.float()).abs().max().item() <= 2.0 ** -7 * dq0.float().abs().max().item()
+    close_bf16(f"attention_bwd stream-K dq B{B} H{H} S{S}", dq1, qr.grad, tol=2e-2)
