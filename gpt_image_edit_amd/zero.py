@@ -111,6 +111,13 @@ class FlatLayout:
         return flat[bk["offset"]: bk["offset"] + bk["size"]]
 
 
+class _Done:
+    """Work handle of a collective that has already completed (host-staged exchange)."""
+
+    def wait(self):
+        return True
+
+
 class ShardedAdamW:
     def __init__(self, params, lr=1e-6, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, kernels=None,
                  group=None, order=None, bucket_numel=DEFAULT_BUCKET, stage_always=False, average_micro_batches=True):
@@ -149,6 +156,10 @@ class ShardedAdamW:
         self.step_count = 0
         self.last_grad_norm = None
         self.average_micro_batches = average_micro_batches
+        # gloo cannot exchange device tensors: with it and parameters on a GPU (two ranks SHARING one GPU -- the only way to
+        # run the multi-rank code path on a one-GPU box; RCCL refuses duplicate devices) every collective is staged through
+        # the host, synchronously.  nccl (= RCCL) and the CPU tests take the direct path.
+        self._host_staged = self.world > 1 and dev.type == "cuda" and dist.get_backend(group) == "gloo"
         self._acc_tmp = []            # world > 1, micro-batch >= 2: reduce-scatter targets that are then ADDED to grad_slice
         self._begin()
 
@@ -257,7 +268,7 @@ class ShardedAdamW:
                     other = [t for _, t in self._work.values() if t is not None]
                     tmp = next(t for t in self._acc_tmp if all(t is not o for o in other))
                 dst = tmp[: bk["chunk"]]
-            self._work[b] = (dist.reduce_scatter_tensor(dst, stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True), tmp)
+            self._work[b] = (self._reduce_scatter(dst, stage), tmp)
         elif self.direct:   # `stage` IS `dst`; tensors that received no gradient this step count as zero (the padding never changes)
             if not self._micro:
                 for n in bk["names"]:
@@ -268,6 +279,22 @@ class ShardedAdamW:
         else:
             dst.copy_(stage[: bk["chunk"]])
         self._launched[b] = True
+
+    def _reduce_scatter(self, dst, src):
+        if not self._host_staged:
+            return dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        h_src, h_dst = src.cpu(), torch.empty(dst.shape, dtype=dst.dtype)
+        dist.reduce_scatter_tensor(h_dst, h_src, op=dist.ReduceOp.SUM, group=self.group)
+        dst.copy_(h_dst)
+        return _Done()
+
+    def _all_gather(self, out, mine):
+        if not self._host_staged:
+            return dist.all_gather_into_tensor(out, mine, group=self.group, async_op=True)
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h_out, mine.cpu(), group=self.group)
+        out.copy_(h_out)
+        return _Done()
 
     # ---- compatibility: whole-gradient views (tests, small models) ------------------------------------------------------
     @property
@@ -291,7 +318,12 @@ class ShardedAdamW:
         self._flush()
         sumsq = self.k.sumsq(self.grad_slice)            # fp64 [1] over the SUMS; padding elements are zero
         if self.world > 1:
-            dist.all_reduce(sumsq, op=dist.ReduceOp.SUM, group=self.group)
+            if self._host_staged:
+                h = sumsq.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                sumsq.copy_(h)
+            else:
+                dist.all_reduce(sumsq, op=dist.ReduceOp.SUM, group=self.group)
         scale = 1.0 / self.world                          # mean over the data-parallel ranks, like DDP / DeepSpeed
         if self.average_micro_batches:
             scale /= self._micro + 1                      # ... and over the accumulated micro-batches (accelerate)
@@ -307,7 +339,7 @@ class ShardedAdamW:
                               max_grad_norm=self.max_grad_norm if self.max_grad_norm is not None else 0.0,
                               param_bf16=mine, grad_scale=scale, **self.hp)
             if self.world > 1:   # in place: `mine` IS the rank's chunk of the bucket being gathered
-                works.append(dist.all_gather_into_tensor(L.bucket_view(self.flat_param, b), mine, group=self.group, async_op=True))
+                works.append(self._all_gather(L.bucket_view(self.flat_param, b), mine))
         for w in works:
             w.wait()
         self._begin()
