@@ -363,11 +363,11 @@ def train_step_bench(device, steps=3, warmup=2, world=1, e2e=True):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    t0, c0 = time.perf_counter(), time.process_time()
+    t0, c0 = time.perf_counter(), time.thread_time()
     for _ in range(steps):
         out = ts.step(**batch)
     t_host = (time.perf_counter() - t0) / steps      # the host is done enqueueing; the GPU may still be working
-    t_cpu = (time.process_time() - c0) / steps       # CPU seconds of this process per step: an UPPER bound on the pure host work
+    t_cpu = (time.thread_time() - c0) / steps       # CPU seconds of the enqueueing thread per step: an UPPER bound on the pure host work
     torch.cuda.synchronize()                         # (it still counts whatever the runtime spins while the launch queue is full)
     if world > 1:
         dist.barrier()
@@ -386,7 +386,7 @@ def train_step_bench(device, steps=3, warmup=2, world=1, e2e=True):
             "loss": float(out["loss"].item()), "trainable_params": n_train, "seq_len": S,
             "peak_memory_gb": torch.cuda.max_memory_allocated(device) / 1e9, "host_enqueue_ms_per_step": t_host * 1e3,
             "host_work_ms_per_step": t_cpu * 1e3,
-            "host_work_note": "process CPU time per step (time.process_time): upper bound on the pure host work of enqueueing a step; "
+            "host_work_note": "CPU time of the enqueueing thread per step (time.thread_time): upper bound on the pure host work of enqueueing a step; "
                               "`host_enqueue_ms_per_step` is the WALL time of the enqueue loop, which also waits on the full launch queue",
             "T_step_e2e": e2e_res,
             "zero2_buckets": len(ts.opt.layout.buckets),

@@ -387,10 +387,16 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
         continue;
       }
       if (tid == 0) {
-        while (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket) __builtin_amdgcn_s_sleep(4);
+        int spins = 0;    // bounded (attention_fwd.hip): a corrupted workspace ends in NaN rows, not in a hung device
+        while (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket && spins < (1 << 22)) {
+          __builtin_amdgcn_s_sleep(8);
+          ++spins;
+        }
+        *(volatile unsigned*)smem = spins >= (1 << 22);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
       __syncthreads();
+      const bool gave_up = *(volatile unsigned*)smem != 0;
 #pragma unroll
       for (int r0 = 0; r0 < 16; r0 += 4) {
         u32x4_t v[4];
@@ -404,6 +410,9 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
           for (int j = 0; j < 4; ++j) a[4 * q4 + j] += __uint_as_float(v[e][j]);   // fp32 addition commutes: symmetric
         }
       }
+      if (gave_up)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = __builtin_nanf("");
     }
   }
 
@@ -710,6 +719,7 @@ int bwd_cu_count() {
   return cus;
 }
 constexpr int BWD_MIN_PART = 8;
+constexpr int BWD_CTL_BYTES = 16384;   // = ATTN_CTL_BYTES of attention_fwd.hip
 
 int launch_dkv(const BwdParams& p, hipStream_t stream) {
   constexpr int SMEM = STAGES * STAGE_BYTES + PBUF_BYTES;
@@ -771,12 +781,12 @@ static int attention_bwd_entry(const fk_attn_view* q, const fk_attn_view* k, con
     const bool wasteful = mode >= 2 || (n_items > G && (rounds * G - n_items) * 25 >= rounds * G);
     int sk_rounds = (int)(n_items / G) - 1;
     while (sk_rounds >= 0 && (n_items - (int64_t)sk_rounds * G) * nt < (int64_t)G * (nt + 2 * BWD_MIN_PART)) --sk_rounds;
-    const int64_t need = (int64_t)G * (PART_FLOATS * 4 + 8);
-    if (mode && wasteful && sk_rounds >= 0 && ws && ws_bytes >= need && n_items * nt < (1ll << 31)) {
+    const int64_t need = BWD_CTL_BYTES + (int64_t)G * PART_FLOATS * 4;
+    if (mode && wasteful && sk_rounds >= 0 && ws && ws_bytes >= need && G <= BWD_CTL_BYTES / 8 && n_items * nt < (1ll << 31)) {
       FK_CHECK_ARG((uintptr_t)ws % 16 == 0, "fk_attention_bwd_ws_bf16: workspace must be 16-byte aligned");
       p.n_items = (int)n_items; p.sk_rounds = sk_rounds; p.min_part = BWD_MIN_PART;
-      p.sk_partials = (float*)ws;
-      p.sk_ctl = (unsigned*)((char*)ws + (size_t)G * PART_FLOATS * 4);
+      p.sk_ctl = (unsigned*)ws;                                   // the forward's layout: control words first (16 KiB)
+      p.sk_partials = (float*)((char*)ws + BWD_CTL_BYTES);
       rc = launch_bwd<MODE_DQ, true>(p, stream, G);
     } else {
       rc = launch_bwd<MODE_DQ>(p, stream);

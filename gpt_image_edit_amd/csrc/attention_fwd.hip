@@ -552,10 +552,18 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
         continue;
       }
       if (tid == 0) {
-        while (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket) __builtin_amdgcn_s_sleep(4);
+        // bounded spin (~seconds): the partner has drawn its ticket, so it is resident and microseconds from publishing; a
+        // corrupted workspace must end in NaN rows (below), not in a hung device
+        int spins = 0;
+        while (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket && spins < (1 << 22)) {
+          __builtin_amdgcn_s_sleep(8);
+          ++spins;
+        }
+        *(volatile unsigned*)smem = spins >= (1 << 22);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
       __syncthreads();
+      const bool gave_up = *(volatile unsigned*)smem != 0;
       const u32x2_t lm = __builtin_amdgcn_raw_buffer_load_b64(rs_p, LM_OFF + tid * 8, 0, /*sc1*/ 16);
       const float l_o = __uint_as_float(lm[0]), m_o = __uint_as_float(lm[1]);
       const float m_new = fmaxf(m_ref, m_o);
@@ -576,6 +584,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
         }
       }
       l_run = __fadd_rn(__fmul_rn(l_run, w_s), __fmul_rn(l_o, w_o));
+      if (gave_up) l_run = __builtin_nanf("");
       m_ref = m_new;
     }
   }
@@ -689,6 +698,7 @@ static int attn_cu_count() {
   return cus;
 }
 constexpr int ATTN_MIN_PART = 8;           // KV tiles: the shortest part a cut may leave
+constexpr int ATTN_CTL_BYTES = 16384;      // head of the workspace: (ticket, flag) pairs of up to 2048 cuts
 
 // FK_ATTN_ILV=0|1 forces the instruction order of the main loop (A/B measurement); default: by grid size.
 static bool use_interleaved(const AttnParams& p) {
@@ -741,12 +751,14 @@ int attention_entry(const void* q, const void* k, const void* v, void* o, int32_
   int sk_rounds = (int)(n_items / G) - 1;
   while (sk_rounds >= 0 && (n_items - (int64_t)sk_rounds * G) * nkt < (int64_t)G * (nkt + 2 * ATTN_MIN_PART)) --sk_rounds;
   const bool cut_once = sk_rounds >= 0;
-  const int64_t need = (int64_t)G * (PART_FLOATS * 4 + 8);
-  if (mode && wasteful && cut_once && ws && ws_bytes >= need) {
+  const int64_t need = ATTN_CTL_BYTES + (int64_t)G * PART_FLOATS * 4;
+  if (mode && wasteful && cut_once && ws && ws_bytes >= need && G <= ATTN_CTL_BYTES / 8) {
     p.sk_rounds = sk_rounds;
     FK_CHECK_ARG((uintptr_t)ws % 16 == 0, "fk_attention_fwd_ws_bf16: workspace must be 16-byte aligned");
-    p.sk_partials = (float*)ws;
-    p.sk_ctl = (unsigned*)((char*)ws + (size_t)G * PART_FLOATS * 4);
+    // control words FIRST, at a place that does not depend on the grid (a test-hook grid of 7 workgroups would otherwise
+    // read its tickets from what a 256-workgroup launch used as partial storage), partials behind them
+    p.sk_ctl = (unsigned*)ws;
+    p.sk_partials = (float*)((char*)ws + ATTN_CTL_BYTES);
     return use_interleaved(p) ? launch<8, false, true, true>(p, G, stream) : launch<8, false, false, true>(p, G, stream);
   }
   return use_interleaved(p) ? launch<8, false, true, false>(p, (int)n_items, stream)
@@ -765,7 +777,7 @@ extern "C" int fk_attention_set_split(int32_t mode) {
 }
 
 // one slot per cut of the persistent grid (= per CU of the current device): the fp32 partial + its (ticket, flag) pair
-extern "C" int64_t fk_attention_ws_bytes(void) { return (int64_t)attn_cu_count() * (PART_FLOATS * 4 + 8); }
+extern "C" int64_t fk_attention_ws_bytes(void) { return ATTN_CTL_BYTES + (int64_t)attn_cu_count() * PART_FLOATS * 4; }
 
 extern "C" int fk_attention_fwd_bf16(const void* q, const void* k, const void* v, void* o, int32_t B,
                                      int32_t H, int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld,

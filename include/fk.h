@@ -168,7 +168,7 @@ int fk_attention_fwd_bf16(const void* q, const void* k, const void* v, void* o, 
                           int64_t o_batch_stride, float scale, fk_stream_t stream);
 /* The same with a caller-owned stream-K workspace (fk_attention_ws_bytes() bytes, 16-byte aligned, zeroed ONCE at
  * allocation: its control words are monotonic tickets afterwards; launches that share it must be ordered, i.e. one
- * workspace per stream) and an optional lse output ([B, H, S] fp32, log2 domain; NULL: none).  With the workspace, a grid
+ * workspace per stream; layout: 16 KiB of (ticket, flag) pairs, then one fp32 partial slot per CU) and an optional lse output ([B, H, S] fp32, log2 domain; NULL: none).  With the workspace, a grid
  * that would leave >= 4 % of its rounds of one-workgroup-per-CU idle (B = 1: S = 8704 is 816 blocks = 3.19 rounds,
  * S = 5632 2.06) runs as a PERSISTENT grid: the KV tiles of all (b, h, 256-row block) items are dealt out as equal
  * contiguous ranges, one per CU, and a block whose keys straddle two CUs is finished by whichever arrives second

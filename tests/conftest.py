@@ -14,6 +14,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # A GPU test that hangs the device (a deadlocked inter-workgroup hand-off) must end the run, not sit in it until the
+    # box's own limit: pytest-timeout's thread method (a blocked hipDeviceSynchronize never returns to the interpreter).
+    if config.pluginmanager.hasplugin("timeout"):
+        for item in items:
+            if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+                item.add_marker(pytest.mark.timeout(600, method="thread"))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -71,14 +71,18 @@ def per_item(rows, items):
 
 def main(d, out_stem):
     items = json.load(open(os.path.join(d, "items.json")))
-    passes = {p: per_item(load(os.path.join(d, p + ".txt")), items) for p in ("time", "fetch", "write", "hit", "req")}
+    passes = {p: per_item(load(os.path.join(d, p + ".txt")), items) for p in ("time", "fetch", "write", "hit")}
+    try:   # the request-counter pass is optional (PMC_PASSES of tools/pmc_traffic.sh); it only feeds the calibration note
+        passes["req"] = per_item(load(os.path.join(d, "req.txt")), items)
+    except Exception:
+        passes["req"] = None
     cal = items[0]
     f_cal = passes["fetch"][0]["ctr"]["FETCH_SIZE"]
     w_cal = passes["write"][0]["ctr"]["WRITE_SIZE"]
     # the calibration kernel (torch's vectorised `src * 1`, 16 B per lane) reads and writes exactly 1 GiB per launch
     kf = cal["alg_read_bytes"] / f_cal          # bytes per FETCH_SIZE unit
     kw = cal["alg_write_bytes"] / w_cal
-    rq = passes["req"][0]["ctr"]
+    rq = passes["req"][0]["ctr"] if passes["req"] else {"(request-counter pass not run this round; round 3": 0, "TCC_EA0_RDREQ = bytes / 128)": 0}
     lines = ["# HBM traffic of the path's kernels from rocprofv3 PMC passes", "",
              "Command: `bash tools/pmc_traffic.sh` (one TCC counter group per pass, `--kernel-trace` only; target "
              "`tools/traffic_target.py`: every item launched 3x back to back, separated by a one-wave kernel). Raw "

@@ -28,7 +28,9 @@ def main(stem):
     out = {"source": "profiles/" + stem.split("/")[-1] + ".md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_traffic.sh)",
            "gemm": {}, "attention": {}, "ln_modulate": {}}
     for wl, (prefix, what) in GEMM_OF.items():
-        name = next(k for k in items if k.startswith(prefix))
+        name = next((k for k in items if k.startswith(prefix)), None)
+        if name is None:      # item left out of this round's passes (TRAFFIC_SKIP of tools/traffic_target.py)
+            continue
         it = items[name]
         b = it["hbm_read_bytes"] + it["hbm_write_bytes"]
         out["gemm"][wl] = dict(
