@@ -153,12 +153,12 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
       item = round * (int)gridDim.x + t0;
       ++round;
     } else {
-      if (u >= u_end) break;
-      const int ti = (unsigned)u / (unsigned)nt;
+      if (u >= u_end) break;      // walked from the END of the range: every pass but the last starts at tile 0 (attention_fwd.hip)
+      const int ti = (unsigned)(u_end - 1) / (unsigned)nt;
       item = p.sk_rounds * (int)gridDim.x + ti;
-      tb = u - ti * nt;
-      te = min(nt, tb + (u_end - u));
-      u += te - tb;
+      te = u_end - ti * nt;
+      tb = max(u - ti * nt, 0);
+      u_end -= te - tb;
     }
   }
   const int rb = item % nrb;
