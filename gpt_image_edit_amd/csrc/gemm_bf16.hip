@@ -347,8 +347,8 @@ static int gemm_bn_override() {
   return g_bn_override;
 }
 extern "C" int fk_gemm_set_variant(int32_t variant) {
-  FK_CHECK_ARG(variant == 0 || variant == 128 || variant == 256 || variant == 384 || variant == 512,
-               "fk_gemm_set_variant: %d is not one of 0 (automatic), 128, 256, 384 (mixed), 512 (split-K)", variant);
+  FK_CHECK_ARG(variant == 0 || variant == 128 || variant == 256 || variant == 384 || variant == 512 || variant == 640,
+               "fk_gemm_set_variant: %d is not one of 0 (automatic), 128, 256, 384 (mixed), 512 (split-K pairs), 640 (stream-K ranges)", variant);
   g_bn_override = variant;
   return FK_OK;
 }

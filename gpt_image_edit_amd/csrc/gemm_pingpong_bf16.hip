@@ -59,6 +59,7 @@ struct GroupArgs {
   // tiles (256 KiB apiece) and one (ticket, flag) word pair per tile in a caller-owned workspace
   float* sk_partials;
   unsigned* sk_ctl;
+  int sk_min_part;     // stream-K launch (gemm8_streamk_kernel): the shortest part (in K-tiles) a cut may leave
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -411,8 +412,9 @@ struct Cfg8 {
   static FK_DEV int tile_col(int wn, int nf) { return nf * 128 + wn * 32; }
 };
 
-// sk_half < 0: the whole K range.  sk_half = 0 / 1 (split-K launch): this workgroup multiplies K-tiles
-// [sk_half * nk, (sk_half + 1) * nk), nk = K / 128, and meets its partner through workspace slot sk_slot (below).
+// This workgroup multiplies the K-tiles [kt_first, kt_first + nk) of the tile.  sk_slot < 0: that is the whole K range
+// (or its result stands alone).  sk_slot >= 0 (split-K pairs, stream-K ranges): the range is one of the two parts of the
+// tile's K range and meets the other part through workspace slot sk_slot (below).
 //
 // LAY (fk_gemm_args.layout) -- the backward pass's operands as they lie in memory, no transposed copies:
 //   0  A [M, K], W [N, K]                 (K contiguous in both: the forward)
@@ -423,7 +425,7 @@ struct Cfg8 {
 // deliver k = 8 hh + 0..7 in the slot order of the ds_read_b128 path, so a K-major operand multiplies a row-major one and
 // the sums are those of the LAY 0 kernel on transposed copies bit for bit (attention_fwd.hip's V^T operand is the recipe).
 template <int EPI, int BN, int LAY = 0>
-FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, int sk_half, int sk_slot) {
+FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, int kt_first, int nk, int sk_slot) {
   using C = Cfg8<BN>;
   constexpr bool AT = LAY == 2, WT = LAY >= 1;
   const int tid = threadIdx.x;
@@ -431,8 +433,7 @@ FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;   // group = wm; waves w and w + 4 share a SIMD
   const fk_gemm_args& p = ga.p[pi];
-  const int nk = sk_half < 0 ? p.K / C::BK : p.K / (2 * C::BK);
-  const int kbase = sk_half > 0 ? nk * (C::BK * 2) : 0;   // byte offset of this workgroup's first K-tile in a row
+  const int kbase = kt_first * (C::BK * 2);   // byte offset of this workgroup's first K-tile in a (K-contiguous) row
 
   // ---- LDS-DMA sources: piece = 8 rows x 128 B, lane -> (row, slot), source chunk = slot ^ swz(row).
   // Wave w requests pieces 2w and 2w + 1 of every half-tile.
@@ -574,7 +575,7 @@ FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, 
   if (wm == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus (clamped) requests must not land in the C tile
 
-  if (sk_half >= 0) {
+  if (sk_slot >= 0) {
     // ---- split-K rendezvous ---------------------------------------------------------------------------------------
     // The two workgroups of a tile each hold the fp32 partial sums of half the K range.  Whoever finishes FIRST
     // (ticket = an agent-scope fetch-add on the tile's counter word: even -> first) writes its accumulators to the
@@ -610,7 +611,13 @@ FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, 
       return;
     }
     if (tid == 0) {
-      while (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket) __builtin_amdgcn_s_sleep(4);
+      // bounded (~seconds): the partner has drawn its ticket and is microseconds from publishing; a corrupted workspace must
+      // end in a wrong tile (the parity tests see it), not in a hung device
+      int spins = 0;
+      while (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket && spins < (1 << 22)) {
+        __builtin_amdgcn_s_sleep(8);
+        ++spins;
+      }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -641,12 +648,49 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int pi, m0, n0;
   const int t = xcd_chunk_index();
+  const int nk_all = ga.p[0].K / Cfg8<BN>::BK;
   if constexpr (SPLITK) {
     select_tile<BN>(ga, t >> 1, pi, m0, n0);
-    gemm8_body<EPI, BN, LAY>(ga, smem, pi, m0, n0, t & 1, t >> 1);
+    gemm8_body<EPI, BN, LAY>(ga, smem, pi, m0, n0, (t & 1) * (nk_all >> 1), nk_all >> 1, t >> 1);
   } else {
     select_tile<BN>(ga, t, pi, m0, n0);
-    gemm8_body<EPI, BN, LAY>(ga, smem, pi, m0, n0, -1, 0);
+    gemm8_body<EPI, BN, LAY>(ga, smem, pi, m0, n0, 0, nk_all, -1);
+  }
+}
+
+// ---- stream-K ranges (round 4) --------------------------------------------------------------------------------------------
+// A long-K GEMM whose 256 x 256 tiling needs a poorly filled last round (M = 8704, N = 3072, K = 12288 / 15360: 408 tiles =
+// 1.59 rounds of 256 CUs, run as 2) as a PERSISTENT grid of one workgroup per CU: the tiles' K-tiles are dealt out as G
+// equal contiguous ranges (cut j at floor(U j / G), moved onto a tile boundary when it would leave a part shorter than
+// sk_min_part K-tiles); the launcher guarantees U / G >= nk + 2 sk_min_part, so a tile is cut at most once and its two parts
+// meet through the split-K pairs' rendezvous (slot = the cut's index).  Round 1's stream-K (every CU a share of EVERY last-round
+// tile, device-scope fences, partials re-read in K order) was 2x slower; this one moves one 256 KiB partial per CU and launch.
+// The range is walked from its end: the head part of its last tile first (the part that publishes), the tail part of its
+// first tile last (the part that merges) -- whoever merges finds the partial already there.
+template <int EPI, int BN>
+__global__ __launch_bounds__(512, 2) void gemm8_streamk_kernel(const GroupArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int pos = xcd_chunk_index();
+  const unsigned G = gridDim.x, nk = ga.p[0].K / Cfg8<BN>::BK;
+  const unsigned U = (unsigned)ga.tiles_before[FK_MAX_GROUP] * nk, qU = U / G, rU = U - qU * G;
+  auto cut = [&](unsigned j) __attribute__((always_inline)) {
+    unsigned c = qU * j + (rU * j) / G;                      // floor(U j / G) without a 64-bit product
+    const unsigned r = c % nk;
+    if (r != 0 && r < (unsigned)ga.sk_min_part) c -= r;
+    else if (r != 0 && nk - r < (unsigned)ga.sk_min_part) c += nk - r;
+    return (int)c;
+  };
+  const int u = cut(pos);
+  int u_end = cut(pos + 1);
+  while (u < u_end) {
+    const int t = (unsigned)(u_end - 1) / nk;
+    const int k1 = u_end - t * (int)nk, k0 = max(u - t * (int)nk, 0);
+    u_end -= k1 - k0;
+    int pi, m0, n0;
+    select_tile<BN>(ga, t, pi, m0, n0);
+    const bool part = k0 > 0 || k1 < (int)nk;
+    gemm8_body<EPI, BN, 0>(ga, smem, pi, m0, n0, k0, k1 - k0, part ? (k1 < (int)nk ? pos + 1 : pos) : -1);
+    __syncthreads();   // every wave is done with the C tile / the ticket word before the next pass refills the ring
   }
 }
 
@@ -668,6 +712,16 @@ int launch8(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream)
   FK_ENSURE_MAX_LDS(kern, Cfg8<BN>::SMEM_BYTES, "fk_gemm_bf16 (256 x 256 tile, 8 waves ping-pong)");
   hipLaunchKernelGGL(kern, dim3(SPLITK ? 2 * total : total), dim3(512), Cfg8<BN>::SMEM_BYTES, stream, ga);
   FK_CHECK_LAUNCH("fk_gemm_bf16 (256 x 256 tile, 8 waves ping-pong)");
+  return FK_OK;
+}
+
+template <int EPI, int BN>
+int launch8_streamk(GroupArgs& ga, const fk_gemm_args* probs, int n, int grid, hipStream_t stream) {
+  count_tiles<BN>(ga, probs, n);
+  auto kern = gemm8_streamk_kernel<EPI, BN>;
+  FK_ENSURE_MAX_LDS(kern, Cfg8<BN>::SMEM_BYTES, "fk_gemm_bf16 (256 x 256 tile, stream-K ranges)");
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Cfg8<BN>::SMEM_BYTES, stream, ga);
+  FK_CHECK_LAUNCH("fk_gemm_bf16 (256 x 256 tile, stream-K ranges)");
   return FK_OK;
 }
 
@@ -863,7 +917,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mix_kernel(const GroupArgs ga) {
   int pi, m0, n0;
   if (idx < nbig) {
     tile_of<256>(ga, ga.tiles_before, ga.xcd_big_start[xcd] + idx, ga.big_cols, 0, pi, m0, n0);
-    gemm8_body<EPI, 256>(ga, smem, pi, m0, n0, -1, 0);
+    gemm8_body<EPI, 256>(ga, smem, pi, m0, n0, 0, ga.p[0].K / 64, -1);
   } else {
     tile_of<128>(ga, ga.small_before, ga.xcd_small_start[xcd] + idx - nbig, (ga.p[0].N - ga.big_cols * 256 + 127) / 128,
                  ga.big_cols * 256, pi, m0, n0);
@@ -907,13 +961,15 @@ int launch_mix(GroupArgs& ga, const fk_gemm_args* probs, int n, int big_cols, hi
   return FK_OK;
 }
 
-// variant: 128 -> gemm9_kernel (256 x 128), 256 -> gemm8_kernel (256 x 256), 384 -> mixed, 512 -> split-K pairs of 256 x 256
+// variant: 128 -> gemm9_kernel (256 x 128), 256 -> gemm8_kernel (256 x 256), 384 -> mixed, 512 -> split-K pairs of 256 x 256,
+// 640 -> stream-K ranges over 256 x 256 tiles (big_cols carries the grid size)
 template <int EPI>
 int launch_variant(GroupArgs& ga, const fk_gemm_args* probs, int n, int variant, int big_cols, hipStream_t stream) {
   switch (variant) {
     case 256: return launch8<EPI, 256, false>(ga, probs, n, stream);
     case 384: return launch_mix<EPI>(ga, probs, n, big_cols, stream);
     case 512: return launch8<EPI, 256, true>(ga, probs, n, stream);
+    case 640: return launch8_streamk<EPI, 256>(ga, probs, n, big_cols, stream);
     default: return launch9<EPI, 128>(ga, probs, n, stream);
   }
 }
@@ -953,6 +1009,7 @@ double makespan(long nb, long ns, double cs, int G) {
 }
 
 struct Plan { int variant, big_cols; };
+constexpr int SK_MIN_PART = 16;   // stream-K: the shortest part of a tile's K range a cut may leave, in K-tiles of 64
 
 // nbm: row tiles summed over the problems of the launch; N, K shared.  allow: bit 0 mixed, bit 1 split-K.
 Plan plan_launch(long nbm, int N, int K, int G, int allow, bool have_ws, int ws_slots) {
@@ -977,6 +1034,12 @@ Plan plan_launch(long nbm, int N, int K, int G, int allow, bool have_ws, int ws_
     // barriers and a fence) against K x 25.8 ns for a whole tile
     const double t = 0.5 + 17.0e-6 / (K * 25.8e-9);
     if (t < tbest * 0.97) { tbest = t; best = {512, 0}; }
+  }
+  if ((allow & 2) && have_ws && K >= 6144 && t256 > G && G <= ws_slots &&
+      t256 * (K / 64) >= (long)G * (K / 64 + 2 * SK_MIN_PART) && t256 * (long)(K / 64) < (1l << 31)) {
+    // stream-K ranges: every CU the same share of the K-tiles, one exchange per CU (a tile is cut at most once)
+    const double t = (double)t256 / G + 17.0e-6 / (K * 25.8e-9);
+    if (t < tbest * 0.97) { tbest = t; best = {640, G}; }
   }
   return best;
 }
@@ -1066,7 +1129,7 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int variant_hint, hipStrea
   const int N = probs[0].N, K = probs[0].K;
   const int G = cu_count();
   const long t256 = nbm_total * ((N + 255) / 256);
-  const bool sk_ok = ws_slots > 0 && ok256 && (K / 64) % 4 == 0 && t256 <= ws_slots;
+  const bool sk_ok = ws_slots > 0 && ok256 && (K / 64) % 4 == 0 && t256 <= ws_slots;   // split-K pairs
   Plan plan;
   switch (variant_hint) {
     case 128: plan = {128, 0}; break;
@@ -1087,9 +1150,16 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int variant_hint, hipStrea
       break;
     }
     case 512: plan = {sk_ok ? 512 : (ok256 ? 256 : 128), 0}; break;
-    default: plan = plan_launch(nbm_total, N, K, G, plan_allow(), sk_ok, ws_slots); break;
+    case 640: {   // forced: stream-K ranges wherever every tile would be cut at most once (test hook: also on small grids)
+      const int Gs = G < ws_slots ? G : ws_slots;
+      const bool ok = ws_slots > 0 && ok256 && t256 * (K / 64) >= (long)Gs * (K / 64 + 2 * SK_MIN_PART) && t256 * (long)(K / 64) < (1l << 31);
+      plan = ok ? Plan{640, Gs} : Plan{ok256 ? 256 : 128, 0};
+      break;
+    }
+    default: plan = plan_launch(nbm_total, N, K, G, plan_allow(), ws_slots > 0 && ok256, ws_slots); break;
   }
-  if (plan.variant == 512) {
+  ga.sk_min_part = SK_MIN_PART;
+  if (plan.variant == 512 || plan.variant == 640) {
     ga.sk_partials = (float*)probs[0].splitk_ws;
     ga.sk_ctl = (unsigned*)((char*)probs[0].splitk_ws + (size_t)ws_slots * (BM * 256 * 4));
   }

@@ -54,7 +54,7 @@ def rows_of(t):
 
 # Split-K workspace (fk.h: fk_gemm_args.splitk_ws): one per (device, stream) -- launches that share one must be ordered.
 # 128 slots cover every grid the planner splits (two half-K workgroups per tile on at most all 256 CUs); 32 MiB each.
-SPLITK_SLOTS = 128
+SPLITK_SLOTS = 256      # one per cut of a stream-K launch (= CUs) / per tile of a split-K pair launch
 _SPLITK_WS = {}
 
 

@@ -61,7 +61,8 @@ def test_gemm_fp32_out(ops, M, N, K):
 
 # the five M = 2560 launch classes of the 512^2 edit + the M = 8704 MLP-up shape, on the kernels that carry the FLOPs
 HOT_SHAPES = [(2560, 9216, 3072, "fused QKV"), (2560, 12288, 3072, "MLP up"), (2560, 3072, 12288, "MLP down"),
-              (2560, 3072, 15360, "single proj_out"), (2560, 3072, 3072, "out projection"), (8704, 12288, 3072, "MLP up @1024^2")]
+              (2560, 3072, 15360, "single proj_out"), (2560, 3072, 3072, "out projection"), (8704, 12288, 3072, "MLP up @1024^2"),
+              (8704, 3072, 15360, "single proj_out @1024^2")]
 
 
 @pytest.mark.parametrize("M,N,K,what", HOT_SHAPES)
@@ -77,7 +78,7 @@ def test_hot_gemm_kernels_at_the_stated_tolerance(ops, M, N, K, what):
     ad, wd, bd = a.cuda(), w.cuda(), bias.cuda()
     seen = {}
     try:
-        for force in (0, 128, 256, 384, 512):
+        for force in (0, 128, 256, 384, 512, 640):
             lib.fk_gemm_set_variant(force)
             got = ops.gemm(ad, wd, bd, out_fp32=2)
             torch.cuda.synchronize()
@@ -92,8 +93,10 @@ def test_hot_gemm_kernels_at_the_stated_tolerance(ops, M, N, K, what):
     finally:
         lib.fk_gemm_set_variant(0)
     assert {128, 256} <= set(seen)
-    if K >= 6144:
+    if K >= 6144 and M == 2560:
         assert 512 in seen                   # the split-K pair form ran (M = 2560, N = 3072: 120 tiles)
+    if K >= 6144 and M == 8704:
+        assert 640 in seen                   # the stream-K ranges ran (408 tiles = 1.59 rounds of 256 CUs), by the planner's own choice too
     # 128 / 256 / mixed accumulate over K in the same order: identical fp32 bits; the split-K pair adds two half sums
     assert torch.equal(seen[128], seen[256]) and (384 not in seen or torch.equal(seen[384], seen[256]))
 
@@ -169,7 +172,8 @@ def _last_variant():
 
 
 @pytest.mark.parametrize("B,S,N,K,want", [(1, 2560, 12288, 3072, 256), (1, 2560, 9216, 3072, 384),
-                                          (3, 100, 512, 128, 128), (2, 1200, 3072, 1024, 128), (1, 2560, 3072, 12288, 512)])
+                                          (3, 100, 512, 128, 128), (2, 1200, 3072, 1024, 128), (1, 2560, 3072, 12288, 512),
+                                          (1, 8704, 3072, 12288, 640)])
 def test_gemm_tile_choice_and_batched_epilogue(ops, B, S, N, K, want):
     # the launcher picks the launch form with the shortest makespan over 256 CUs: 256 x 256 tiles where their higher rate
     # survives the round quantisation, one round of them + 256 x 128 tiles for the rest (384) where that beats both pure

@@ -21,11 +21,14 @@ BUDGET = {
     "attention_bwd.hip": [("attention_bwd_kernel", 64)],
     # the split-K instantiation (..., true) moves one accumulator tile through scratch around its rendezvous, outside the
     # K loop (at most 8 stores + 8 loads per workgroup); every other instantiation keeps everything in registers
-    "gemm_pingpong_bf16.hip": [("gemm8_kernelILi", 0), ("gemm9_kernel", 0), ("gemm_mix_kernel", 0)],
+    "gemm_pingpong_bf16.hip": [("gemm8_kernelILi", 0), ("gemm9_kernel", 0), ("gemm_mix_kernel", 0), ("gemm8_streamk_kernel", 0)],
 }
 # key -> [(name fragment, max scratch bytes, max spilled VGPRs)]; the fp32-output parity build of the split-K form (epilogue
 # 64 = FK_EPI_F32DBG, test-only) keeps its bias quads live across the rendezvous as well: more of the same, still outside the K loop
-EXCEPTIONS = {"gemm8_kernelILi": [("ILi64ELi256ELb1ELi0EEE", 320, 72), ("Lb1ELi0EEE", 136, 32)]}
+EXCEPTIONS = {"gemm8_kernelILi": [("ILi64ELi256ELb1ELi0EEE", 320, 72), ("Lb1ELi0EEE", 136, 32)],
+              # the stream-K form loops over passes (tile part, rendezvous, epilogue): what is live across a pass sits in
+              # scratch around it -- ~90 scratch instructions per pass, NONE inside the K loop (checked below)
+              "gemm8_streamk_kernel": [("ILi64E", 200, 300), ("", 260, 120)]}
 
 
 @pytest.mark.parametrize("src", sorted(BUDGET))
@@ -54,3 +57,23 @@ def test_hot_kernels_keep_their_accumulators_in_registers(src, tmp_path):
                 assert int(scratch) <= max_scratch, f"{name}: {scratch} B of scratch per lane (arrays in private memory?)"
                 assert int(spills) <= max_spills, f"{name}: {spills} spilled VGPRs"
     assert seen >= len(BUDGET[src]), f"expected kernels {BUDGET[src]} in {src}"
+    if src == "gemm_pingpong_bf16.hip":     # the stream-K kernels' spills must stay outside the K loop (the 64-MFMA loop body)
+        lines = text.split("\n")
+        starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN12_GLOBAL__N_120gemm8_streamk_kernel\w+:", l)]
+        assert starts
+        for a in starts:
+            if "ILi64E" in lines[a]:       # the fp32-output parity build (test-only) may spill where it likes
+                continue
+            e = next(i for i in range(a, len(lines)) if lines[i].startswith(".Lfunc_end"))
+            body = lines[a:e]
+            labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+            loops = []
+            for i, l in enumerate(body):
+                m = re.search(r"(?:s_cbranch_\w+|s_branch) (\.LBB\d+_\d+)", l)
+                if m and m.group(1) in labels and labels[m.group(1)] < i and any("v_mfma" in x for x in body[labels[m.group(1)]:i]):
+                    loops.append((labels[m.group(1)], i))
+            assert loops, "no loop with MFMAs found"
+            head = min(loops, key=lambda ab: ab[1] - ab[0])[0]      # header of the innermost loop that multiplies ...
+            k_loop = body[head:max(b for a_, b in loops if a_ == head)]   # ... up to its last back edge: two K-tiles = 64 MFMAs
+            assert sum("v_mfma" in x for x in k_loop) == 64
+            assert not any("scratch_" in x for x in k_loop), f"{lines[a][:70]}: scratch traffic inside the K loop"
