@@ -1035,7 +1035,12 @@ Plan plan_launch(long nbm, int N, int K, int G, int allow, bool have_ws, int ws_
     const double t = 0.5 + 17.0e-6 / (K * 25.8e-9);
     if (t < tbest * 0.97) { tbest = t; best = {512, 0}; }
   }
-  if ((allow & 2) && have_ws && K >= 6144 && t256 > G && G <= ws_slots &&
+  // MEASURED AND OFF BY DEFAULT (allow bit 2, FK_GEMM_PLAN=7): inside the 1024^2 edit the stream-K form of the two long-K launch
+  // classes (408 tiles = 1.59 rounds) LOSES 1.8 % of the GEMM time against the plain two-round grid (2643 vs 2596 ms per edit,
+  // same box, interleaved; train step 531.6 vs 525.9 ms): the plain grid's half-empty second round already runs 6 % below the
+  // full-grid rate only (idle CUs hand their power budget to the busy ones), and one 256 KiB exchange per CU plus the
+  // persistent loop's per-pass prologues cost more than that (profiles/r04_gemm_streamk_ab.txt)
+  if ((allow & 4) && have_ws && K >= 6144 && t256 > G && G <= ws_slots &&
       t256 * (K / 64) >= (long)G * (K / 64 + 2 * SK_MIN_PART) && t256 * (long)(K / 64) < (1l << 31)) {
     // stream-K ranges: every CU the same share of the K-tiles, one exchange per CU (a tile is cut at most once)
     const double t = (double)t256 / G + 17.0e-6 / (K * 25.8e-9);
@@ -1049,18 +1054,19 @@ static thread_local int g_last_variant = 0;
 // 128 / 256: the 256 x 128 / 256 x 256 kernel, 384: mixed grid, 512: split-K pairs, 0: none of the large-tile kernels yet
 int fk_gemm_last_variant(void) { return g_last_variant; }
 
-// bit 0: mixed grids, bit 1: split-K pairs (needs fk_gemm_args.splitk_ws); FK_GEMM_PLAN=0..3 (default 3) or
+// bit 0: mixed grids, bit 1: split-K pairs (needs fk_gemm_args.splitk_ws), bit 2: stream-K ranges (measured slower, off);
+// FK_GEMM_PLAN=0..7 (default 3) or
 // fk_gemm_set_plan().  Without bit 1 the result of a GEMM does not depend on the grid it runs in ("batch-invariant").
 static int g_plan_allow = -1;
 static int plan_allow() {
   if (g_plan_allow < 0) {
     const char* e = getenv("FK_GEMM_PLAN");
-    g_plan_allow = e ? (atoi(e) & 3) : 3;
+    g_plan_allow = e ? (atoi(e) & 7) : 3;
   }
   return g_plan_allow;
 }
 extern "C" int fk_gemm_set_plan(int32_t allow) {
-  FK_CHECK_ARG(allow >= 0 && allow <= 3, "fk_gemm_set_plan: %d is not in 0..3 (bit 0 mixed grids, bit 1 split-K)", allow);
+  FK_CHECK_ARG(allow >= 0 && allow <= 7, "fk_gemm_set_plan: %d is not in 0..7 (bit 0 mixed grids, bit 1 split-K pairs, bit 2 stream-K ranges)", allow);
   g_plan_allow = allow;
   return FK_OK;
 }

@@ -117,12 +117,13 @@ int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream);
  * 384 = mixed grid, 512 = split-K pairs of 256 x 256 tiles, 0 = none so far (tests, profiling). */
 int fk_gemm_last_variant(void);
 /* Tuning / measurement hook: force the launch form of every later fk_gemm_bf16[_grouped] call of the process where
- * it applies: 128 = 256 x 128 tiles, 256 = 256 x 256 tiles, 384 = mixed grid, 512 = split-K pairs; 0 = back to the
- * per-problem choice.  128 / 256 / 384 give the same results bit for bit. */
+ * it applies: 128 = 256 x 128 tiles, 256 = 256 x 256 tiles, 384 = mixed grid, 512 = split-K pairs, 640 = stream-K ranges;
+ * 0 = back to the per-problem choice.  128 / 256 / 384 give the same results bit for bit. */
 int fk_gemm_set_variant(int32_t variant);
 /* Which launch forms the per-problem choice may use: bit 0 = mixed grids (one round of 256 x 256 tiles, the remaining
  * columns as 256 x 128 tiles; bit-identical results), bit 1 = split-K pairs (results differ in the last bits from the
- * unsplit sum).  Default 3 (FK_GEMM_PLAN overrides).  With bit 1 clear a GEMM's result does not depend on the grid it
+ * unsplit sum), bit 2 = stream-K ranges for long-K launches with a poorly filled last round (round 4; measured slower inside the
+ * edits, so off).  Default 3 (FK_GEMM_PLAN overrides).  With bit 1 clear a GEMM's result does not depend on the grid it
  * runs in, i.e. a sample computed inside a batch equals the same sample computed alone bit for bit. */
 int fk_gemm_set_plan(int32_t allow);
 

@@ -96,7 +96,7 @@ def test_hot_gemm_kernels_at_the_stated_tolerance(ops, M, N, K, what):
     if K >= 6144 and M == 2560:
         assert 512 in seen                   # the split-K pair form ran (M = 2560, N = 3072: 120 tiles)
     if K >= 6144 and M == 8704:
-        assert 640 in seen                   # the stream-K ranges ran (408 tiles = 1.59 rounds of 256 CUs), by the planner's own choice too
+        assert 640 in seen                   # the stream-K ranges ran when forced (408 tiles = 1.59 rounds; the planner leaves them off: measured slower)
     # 128 / 256 / mixed accumulate over K in the same order: identical fp32 bits; the split-K pair adds two half sums
     assert torch.equal(seen[128], seen[256]) and (384 not in seen or torch.equal(seen[384], seen[256]))
 
@@ -173,7 +173,7 @@ def _last_variant():
 
 @pytest.mark.parametrize("B,S,N,K,want", [(1, 2560, 12288, 3072, 256), (1, 2560, 9216, 3072, 384),
                                           (3, 100, 512, 128, 128), (2, 1200, 3072, 1024, 128), (1, 2560, 3072, 12288, 512),
-                                          (1, 8704, 3072, 12288, 640)])
+                                          (1, 8704, 3072, 12288, 256)])
 def test_gemm_tile_choice_and_batched_epilogue(ops, B, S, N, K, want):
     # the launcher picks the launch form with the shortest makespan over 256 CUs: 256 x 256 tiles where their higher rate
     # survives the round quantisation, one round of them + 256 x 128 tiles for the rest (384) where that beats both pure
