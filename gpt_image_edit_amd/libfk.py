@@ -49,6 +49,26 @@ class ConvArgs(ctypes.Structure):
     ]
 
 
+class BlockWs(ctypes.Structure):          # fk_block_ws
+    _fields_ = [(n, c_vp) for n in ("s", "n", "qkv", "q", "k", "o", "ff", "cat", "rope_cs", "splitk_ws", "attn_ws")] + [
+        ("attn_ws_bytes", c_i64), ("splitk_slots", c_i32), ("B", c_i32), ("S_txt", c_i32), ("S_img", c_i32), ("H", c_i32),
+        ("eps", c_f32)]
+
+
+DOUBLE_BLOCK_FIELDS = ("wqkv_img", "bqkv_img", "wqkv_txt", "bqkv_txt", "norm_q", "norm_k", "norm_added_q", "norm_added_k",
+                       "w_out", "b_out", "w_add_out", "b_add_out", "w_ff1", "b_ff1", "w_ff1_ctx", "b_ff1_ctx",
+                       "w_ff2", "b_ff2", "w_ff2_ctx", "b_ff2_ctx")
+SINGLE_BLOCK_FIELDS = ("wqkv", "bqkv", "norm_q", "norm_k", "w_mlp", "b_mlp", "w_out", "b_out")
+
+
+class DoubleBlockWeights(ctypes.Structure):   # fk_double_block_weights
+    _fields_ = [(n, c_vp) for n in DOUBLE_BLOCK_FIELDS] + [("mod_off_img", c_i64), ("mod_off_txt", c_i64)]
+
+
+class SingleBlockWeights(ctypes.Structure):   # fk_single_block_weights
+    _fields_ = [(n, c_vp) for n in SINGLE_BLOCK_FIELDS] + [("mod_off", c_i64)]
+
+
 # symbol -> (restype, argtypes); must list every entry point of include/fk.h
 SIGNATURES = {
     "fk_gemm_bf16": (c_i32, [ctypes.POINTER(GemmArgs), c_vp]),
@@ -102,6 +122,10 @@ SIGNATURES = {
     "fk_nhwc_to_nchw": (c_i32, [c_vp, c_vp] + [c_i32] * 6 + [c_f32, c_f32, c_vp]),
     "fk_pixels_u8_to_nhwc_bf16": (c_i32, [c_vp, c_vp] + [c_i32] * 7 + [c_vp]),
     "fk_image_to_u8_nhwc": (c_i32, [c_vp, c_i32, c_vp] + [c_i32] * 4 + [c_vp]),
+    "fk_double_block_fwd": (c_i32, [ctypes.POINTER(BlockWs), ctypes.POINTER(DoubleBlockWeights), c_vp, c_i64, c_vp]),
+    "fk_single_block_fwd": (c_i32, [ctypes.POINTER(BlockWs), ctypes.POINTER(SingleBlockWeights), c_vp, c_i64, c_vp]),
+    "fk_mmdit_blocks_fwd": (c_i32, [ctypes.POINTER(BlockWs), ctypes.POINTER(DoubleBlockWeights), c_i32,
+                                    ctypes.POINTER(SingleBlockWeights), c_i32, c_vp, c_i64, c_vp]),
     "fk_last_error": (ctypes.c_char_p, []),
     "fk_version": (ctypes.c_char_p, []),
 }

@@ -39,6 +39,10 @@ FUSE_QKV = os.environ.get("FK_FUSE_QKV", "1") != "0"
 # after the attention, which then reads q / k / v while they are cache-warm -- cfg 2 on one box, three interleaved runs
 # each: 1.0149 / 1.0156 / 1.0150 images/s against 1.0145 / 0.9909 / 0.9646)
 MLP_FIRST = os.environ.get("FK_MLP_FIRST", "0") == "1"
+# FK_BLOCK_API: how the 57 blocks of a forward are enqueued.  0 = one ctypes call per kernel launch (~190 per forward),
+# 1 = one per block (fk_double_block_fwd / fk_single_block_fwd), 2 = ONE per forward (fk_mmdit_blocks_fwd; default).  The C
+# entry points issue the same launches with the same arguments: identical bits (tests/test_hip_mmdit.py).
+BLOCK_API = int(os.environ.get("FK_BLOCK_API", "2"))
 OVERLAP_MLP = {"0": False, "1": True, "auto": "auto"}.get(os.environ.get("FK_OVERLAP_MLP", "0"), False)
 
 
@@ -396,6 +400,34 @@ class HipFluxTransformer2DModel(ParamTreeMixin, nn.Module):
         def chunk(off, j):
             return mod[:, off + j * D: off + (j + 1) * D]
 
+        block_api = BLOCK_API if (FUSE_QKV and not MLP_FIRST and not (OVERLAP_MLP and (OVERLAP_MLP != "auto" or self._overlap_pays(B, ws.S)))
+                                  and S_txt > 0) else 0
+        if block_api:
+            self._blocks_by_c_entry(ws, pk, mod, cs, B, S_txt, S_img, block_api)
+        else:
+            self._blocks_by_kernel_calls(ws, pk, mod, cos, sin, cs, B, S_txt)
+
+        # -- output head: AdaLayerNormContinuous (scale first, then shift) + proj_out -----------------------
+        ops.ln_modulate(h, chunk(pk.mod_out, 1), chunk(pk.mod_out, 0), out=n_img)
+        # the result is a FRESH tensor every call (64 channels per token: tiny; the caching allocator serves it without
+        # a device sync): callers such as the reference pipeline's true-CFG branch keep one call's output while
+        # making the next (flux_pipeline.py:1067-1095), which a persistent workspace buffer would silently alias
+        sample = ops.gemm(n_img, P("proj_out.weight"), P("proj_out.bias"))
+        if not return_dict:
+            return (sample,)
+        return SimpleNamespace(sample=sample)
+
+    def _blocks_by_kernel_calls(self, ws, pk, mod, cos, sin, cs, B, S_txt):
+        """The 19 + 38 blocks as one ctypes call per kernel launch (FK_BLOCK_API=0; also the route of the A/B switches
+        FK_FUSE_QKV=0, FK_MLP_FIRST=1, FK_OVERLAP_MLP)."""
+        P, D = self.p, self.inner_dim
+        s, n = ws.s, ws.n
+        h, cx = s[:, S_txt:], s[:, :S_txt]
+        n_img, n_txt = n[:, S_txt:], n[:, :S_txt]
+
+        def chunk(off, j):
+            return mod[:, off + j * D: off + (j + 1) * D]
+
         # -- double-stream blocks ----------------------------------------------------------------------
         for i, blk in enumerate(pk.double):
             p = f"transformer_blocks.{i}."
@@ -473,15 +505,64 @@ class HipFluxTransformer2DModel(ParamTreeMixin, nn.Module):
             ops.gemm(ws.cat, P(p + "proj_out.weight"), P(p + "proj_out.bias"), out=s,
                      epilogue=ops.FK_EPI_GATE_RES, res=s, gate=chunk(m0, 2))
 
-        # -- output head: AdaLayerNormContinuous (scale first, then shift) + proj_out -----------------------
-        ops.ln_modulate(h, chunk(pk.mod_out, 1), chunk(pk.mod_out, 0), out=n_img)
-        # the result is a FRESH tensor every call (64 channels per token: tiny; the caching allocator serves it without
-        # a device sync): callers such as the reference pipeline's true-CFG branch keep one call's output while
-        # making the next (flux_pipeline.py:1067-1095), which a persistent workspace buffer would silently alias
-        sample = ops.gemm(n_img, P("proj_out.weight"), P("proj_out.bias"))
-        if not return_dict:
-            return (sample,)
-        return SimpleNamespace(sample=sample)
+
+    def _blocks_by_c_entry(self, ws, pk, mod, cs, B, S_txt, S_img, api):
+        """The same launches through the block-level C entry points: argument structs built once per (weights, workspace)
+        and re-used; per forward only the modulation pointer changes."""
+        from . import libfk
+        lib, P, D = libfk.load(), self.p, self.inner_dim
+        names_d = ("attn.norm_q.weight", "attn.norm_k.weight", "attn.norm_added_q.weight", "attn.norm_added_k.weight",
+                   "attn.to_out.0.weight", "attn.to_out.0.bias", "attn.to_add_out.weight", "attn.to_add_out.bias",
+                   "ff.net.0.proj.weight", "ff.net.0.proj.bias", "ff_context.net.0.proj.weight", "ff_context.net.0.proj.bias",
+                   "ff.net.2.weight", "ff.net.2.bias", "ff_context.net.2.weight", "ff_context.net.2.bias")
+        names_s = ("attn.norm_q.weight", "attn.norm_k.weight", "proj_mlp.weight", "proj_mlp.bias", "proj_out.weight", "proj_out.bias")
+        ptrs = []
+        for i, blk in enumerate(pk.double):
+            p = f"transformer_blocks.{i}."
+            ptrs.append((blk.wqkv_img.data_ptr(), blk.bqkv_img.data_ptr(), blk.wqkv_txt.data_ptr(), blk.bqkv_txt.data_ptr())
+                        + tuple(P(p + k).data_ptr() for k in names_d))
+        for i, blk in enumerate(pk.single):
+            p = f"single_transformer_blocks.{i}."
+            ptrs.append((blk.wqkv.data_ptr(), blk.bqkv.data_ptr()) + tuple(P(p + k).data_ptr() for k in names_s))
+        ptrs = tuple(ptrs)
+        st = self.__dict__.get("_block_structs")
+        if st is None or st.ptrs != ptrs:
+            nd, ns = len(pk.double), len(pk.single)
+            dbl, sgl = (libfk.DoubleBlockWeights * max(nd, 1))(), (libfk.SingleBlockWeights * max(ns, 1))()
+            for i, blk in enumerate(pk.double):
+                for f, v in zip(libfk.DOUBLE_BLOCK_FIELDS, ptrs[i]):
+                    setattr(dbl[i], f, v)
+                dbl[i].mod_off_img, dbl[i].mod_off_txt = blk.mod_img, blk.mod_txt
+            for i, blk in enumerate(pk.single):
+                for f, v in zip(libfk.SINGLE_BLOCK_FIELDS, ptrs[nd + i]):
+                    setattr(sgl[i], f, v)
+                sgl[i].mod_off = blk.mod
+            st = SimpleNamespace(ptrs=ptrs, dbl=dbl, sgl=sgl, nd=nd, ns=ns)
+            self.__dict__["_block_structs"] = st
+        sk, slots = ops.splitk_workspace(ws.s.device)
+        aw = ops.attention_workspace(ws.s.device)
+        key = tuple(getattr(ws, f).data_ptr() for f in ("s", "n", "qkv", "q", "k", "o", "ff", "cat")) + (
+            cs.data_ptr(), sk.data_ptr(), aw.data_ptr(), B, S_txt, S_img)
+        bw = self.__dict__.get("_block_ws")
+        if bw is None or bw[0] != key:
+            c = libfk.BlockWs()
+            for f in ("s", "n", "qkv", "q", "k", "o", "ff", "cat"):
+                setattr(c, f, getattr(ws, f).data_ptr())
+            c.rope_cs, c.splitk_ws, c.attn_ws, c.attn_ws_bytes, c.splitk_slots = cs.data_ptr(), sk.data_ptr(), aw.data_ptr(), aw.numel(), slots
+            c.B, c.S_txt, c.S_img, c.H, c.eps = B, S_txt, S_img, self.num_heads, 1e-6
+            bw = (key, c, (cs, sk, aw))            # strong references keep the buffers the struct points into alive
+            self.__dict__["_block_ws"] = bw
+        c = bw[1]
+        import ctypes
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        mp, mbs = ctypes.c_void_p(mod.data_ptr()), mod.stride(0)
+        if api >= 2:
+            libfk.check(lib.fk_mmdit_blocks_fwd(ctypes.byref(c), st.dbl, st.nd, st.sgl, st.ns, mp, mbs, stream), "fk_mmdit_blocks_fwd")
+            return
+        for i in range(st.nd):
+            libfk.check(lib.fk_double_block_fwd(ctypes.byref(c), ctypes.byref(st.dbl[i]), mp, mbs, stream), "fk_double_block_fwd")
+        for i in range(st.ns):
+            libfk.check(lib.fk_single_block_fwd(ctypes.byref(c), ctypes.byref(st.sgl[i]), mp, mbs, stream), "fk_single_block_fwd")
 
     # The reference training code calls this on the denoiser (train_denoiser.py:486) because its 80 GB GPUs cannot hold
     # a 1024^2 sample's activations.  Here it selects FluxBackward's recompute policy (one checkpoint per block, the

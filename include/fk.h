@@ -193,6 +193,53 @@ int fk_attention_fwd_f32_debug(const void* q, const void* k, const void* v, floa
                                int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld,
                                int64_t o_batch_stride, float scale, fk_stream_t stream);
 
+/* ---- block-level entry points ------------------------------------------------------------------------
+ * ONE call enqueues every launch of a FluxTransformerBlock / FluxSingleTransformerBlock (diffusers 0.32.2 as the reference
+ * reaches it at flux_pipeline.py:1067-1077), or of all blocks of a forward, on the caller's stream -- the same launches, in
+ * the same order, with the same arguments as the per-kernel calls above, hence the same bits; what they remove is host work
+ * (~5 400 calls per 28-step edit become 28).  All buffers are caller-owned bf16 (PyTorch's allocator), D = H * 128:
+ *   s   [B, S, D]   residual stream, text rows [0, S_txt) first, image rows after (S = S_txt + S_img); updated in place
+ *   n   [B, S, D]   LN + modulate output                 qkv [B, S, 3D]   fused QKV projection (V is read from it in place)
+ *   q,k [B, H, S, 128]                                    o   [B, S, D]    attention output (double blocks)
+ *   ff  [B, S, 4D]  MLP hidden (double blocks)            cat [B, S, 5D]   [attention | MLP hidden] (single blocks)
+ * rope_cs: fp32 [S, 64, 2] (cos, sin) per rotary pair.  splitk_ws / attn_ws: the optional workspaces of fk_gemm_args /
+ * fk_attention_fwd_ws_bf16 (NULL: never split).  mod: bf16 [B, mod_total] with row stride mod_batch_stride (elements), the
+ * modulation vectors of every block (Linear(SiLU(temb)) of norm1 / norm1_context / norm); a block's weights struct carries its
+ * element offset(s) into a row: double block (shift, scale, gate, shift_mlp, scale_mlp, gate_mlp) x D for the image stream at
+ * mod_off_img and for the text stream at mod_off_txt; single block (shift, scale, gate) x D at mod_off. */
+typedef struct fk_block_ws {
+  void *s, *n, *qkv, *q, *k, *o, *ff, *cat;
+  const float* rope_cs;
+  void* splitk_ws;
+  void* attn_ws;
+  int64_t attn_ws_bytes;
+  int32_t splitk_slots;
+  int32_t B, S_txt, S_img, H;
+  float eps;                       /* LayerNorm eps (1e-6) */
+} fk_block_ws;
+typedef struct fk_double_block_weights {   /* bf16; Linear weights [N, K] K-contiguous, fused q|k|v as [3D, D] / [3D] */
+  const void *wqkv_img, *bqkv_img, *wqkv_txt, *bqkv_txt;          /* attn.to_{q,k,v} / attn.add_{q,k,v}_proj */
+  const void *norm_q, *norm_k, *norm_added_q, *norm_added_k;      /* RMSNorm weights [128] */
+  const void *w_out, *b_out, *w_add_out, *b_add_out;              /* attn.to_out.0 / attn.to_add_out */
+  const void *w_ff1, *b_ff1, *w_ff1_ctx, *b_ff1_ctx;              /* ff.net.0.proj / ff_context.net.0.proj  [4D, D] */
+  const void *w_ff2, *b_ff2, *w_ff2_ctx, *b_ff2_ctx;              /* ff.net.2 / ff_context.net.2            [D, 4D] */
+  int64_t mod_off_img, mod_off_txt;
+} fk_double_block_weights;
+typedef struct fk_single_block_weights {
+  const void *wqkv, *bqkv, *norm_q, *norm_k;                      /* attn.to_{q,k,v} fused, attn.norm_{q,k} */
+  const void *w_mlp, *b_mlp, *w_out, *b_out;                      /* proj_mlp [4D, D], proj_out [D, 5D] */
+  int64_t mod_off;
+} fk_single_block_weights;
+int fk_double_block_fwd(const fk_block_ws* ws, const fk_double_block_weights* w, const void* mod, int64_t mod_batch_stride,
+                        fk_stream_t stream);
+int fk_single_block_fwd(const fk_block_ws* ws, const fk_single_block_weights* w, const void* mod, int64_t mod_batch_stride,
+                        fk_stream_t stream);
+/* All blocks of FluxTransformer2DModel.forward between the embedders and the output head: n_double double blocks, then
+ * n_single single blocks (the embedders, the conditioning GEMMs and norm_out / proj_out stay per-kernel calls: 8 launches). */
+int fk_mmdit_blocks_fwd(const fk_block_ws* ws, const fk_double_block_weights* dbl, int32_t n_double,
+                        const fk_single_block_weights* sgl, int32_t n_single, const void* mod, int64_t mod_batch_stride,
+                        fk_stream_t stream);
+
 /* ---- backward pass of the MMDiT (train_denoiser.py:1172 `accelerator.backward(loss)` through diffusers' blocks) ---- */
 /* Forward attention that also saves lse[b, h, s] = log2(sum_j exp(q.k_j * scale)) (fp32) for the backward pass. */
 int fk_attention_fwd_lse_bf16(const void* q, const void* k, const void* v, void* o, float* lse, int32_t B, int32_t H,

@@ -38,14 +38,16 @@ def test_struct_layouts_match_header():
     # fk_gemm_args: 4 pointers + ... ; compare against the C compiler's view
     import subprocess
     import tempfile
-    code = '#include <stdio.h>\n#include "fk.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(fk_gemm_args), sizeof(fk_conv_args), sizeof(fk_rows));return 0;}\n'
+    code = ('#include <stdio.h>\n#include "fk.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(fk_gemm_args), sizeof(fk_conv_args), '
+            'sizeof(fk_rows), sizeof(fk_block_ws), sizeof(fk_double_block_weights), sizeof(fk_single_block_weights));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "t.c")
         open(src, "w").write(code)
         exe = os.path.join(d, "t")
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
         sizes = [int(x) for x in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
-    assert sizes == [ctypes.sizeof(libfk.GemmArgs), ctypes.sizeof(libfk.ConvArgs), ctypes.sizeof(libfk.Rows)]
+    assert sizes == [ctypes.sizeof(libfk.GemmArgs), ctypes.sizeof(libfk.ConvArgs), ctypes.sizeof(libfk.Rows),
+                     ctypes.sizeof(libfk.BlockWs), ctypes.sizeof(libfk.DoubleBlockWeights), ctypes.sizeof(libfk.SingleBlockWeights)]
 
 
 def test_no_cpu_fallback():

@@ -267,3 +267,40 @@ def test_checkpoint_roundtrip_into_hip_models(tmp_path):
               timestep=torch.tensor([0.5], device="cuda").to(BFl), guidance=torch.full((1,), 3.5, device="cuda"),
               txt_ids=torch.zeros(64, 3, device="cuda", dtype=BFl), img_ids=ids(1, 8, 16, "cuda", BFl), return_dict=False)
     assert torch.equal(a(**kw)[0], b(**kw)[0])
+
+
+def test_block_entry_points_give_the_same_bits():
+    """SURVEY 8b / VERDICT r3 missing #6: the block-level C entry points (fk_double_block_fwd, fk_single_block_fwd,
+    fk_mmdit_blocks_fwd: one call per block / per forward) enqueue the launches of the per-kernel path with the same
+    arguments: the forward must agree bit for bit in all three forms, at a ragged shape with batch 2 and at a shape whose
+    K-long GEMMs run as split-K pairs, and call after call (the argument structs are cached)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd import flux_spec, transformer
+    cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=2, num_single_layers=3)
+    model = transformer.HipFluxTransformer2DModel(cfg, device="cuda", init="synthetic", seed=23)
+    saved = transformer.BLOCK_API
+    try:
+        for (B, S_txt, h, w) in ((2, 77, 10, 12), (1, 200, 24, 24)):
+            hs, enc, pooled, t, gd, img_ids, txt_ids = _inputs(B, S_txt, h, w, cfg, seed=9)
+            kw = dict(hidden_states=hs.cuda(), timestep=t.cuda(), guidance=gd.cuda(), pooled_projections=pooled.cuda(),
+                      encoder_hidden_states=enc.cuda(), txt_ids=txt_ids.cuda(), img_ids=img_ids.cuda(), return_dict=False)
+            outs = []
+            for api in (0, 1, 2, 2, 1, 0):
+                transformer.BLOCK_API = api
+                outs.append(model(**kw)[0].clone())
+            torch.cuda.synchronize()
+            assert torch.isfinite(outs[0].float()).all()
+            for o in outs[1:]:
+                assert torch.equal(o, outs[0])
+        # the cached structs follow the weights: after a parameter is REPLACED (new storage) the C path must see the new one
+        transformer.BLOCK_API = 2
+        before = model(**kw)[0].clone()
+        prm = model.p("single_transformer_blocks.1.proj_out.weight")
+        prm.data = (prm.data.float() * 0.5).to(BF)
+        after_c = model(**kw)[0].clone()
+        transformer.BLOCK_API = 0
+        after_py = model(**kw)[0].clone()
+        assert not torch.equal(before, after_c) and torch.equal(after_c, after_py)
+    finally:
+        transformer.BLOCK_API = saved
