@@ -95,8 +95,9 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* src, int64
 
 // Row softmax: fp32 scores in, bf16 probabilities out; one block (256 threads) per row, n <= 32768.
 template <int NV>
+// parts = 3 (fp32-class VAE encoder): the fp32 probability is written as the bf16 parts (hi, lo, hi), ps columns apart.
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* x, bf16_t* y, int64_t ldx,
-                                                           int64_t ldy, int n) {
+                                                           int64_t ldy, int n, int64_t ps, int parts) {
   __shared__ float red[8];
   const int tid = threadIdx.x;
   const float* xr = x + (int64_t)blockIdx.x * ldx;
@@ -141,6 +142,13 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* x, bf16_
       pk[0] = pack_bf2(v[i][0] * inv, v[i][1] * inv);
       pk[1] = pack_bf2(v[i][2] * inv, v[i][3] * inv);
       *(u32x2_t*)(yr + idx) = pk;
+      if (parts == 3) {
+        u32x2_t lo;
+        lo[0] = pack_bf2(v[i][0] * inv - bf_lo(pk[0]), v[i][1] * inv - bf_hi(pk[0]));
+        lo[1] = pack_bf2(v[i][2] * inv - bf_lo(pk[1]), v[i][3] * inv - bf_hi(pk[1]));
+        *(u32x2_t*)(yr + ps + idx) = lo;
+        *(u32x2_t*)(yr + 2 * ps + idx) = pk;
+      }
     }
   }
 }
@@ -222,17 +230,28 @@ extern "C" int fk_transpose_bf16(const void* src, int64_t lds, int64_t src_batch
   return FK_OK;
 }
 
-extern "C" int fk_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t n,
-                               fk_stream_t stream) {
+static int softmax_rows_entry(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t ps, int parts, int64_t rows,
+                              int32_t n, fk_stream_t stream) {
   FK_CHECK_ARG(x && y && rows > 0 && n > 0 && n % 4 == 0 && n <= 32768, "fk_softmax_rows: n must be a multiple of 4, <= 32768");
-  FK_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 8 == 0),
+  FK_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && ps % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 8 == 0),
                "fk_softmax_rows: alignment");
   const dim3 grid((unsigned)rows), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (n <= 1024) hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, block, 0, s, x, (bf16_t*)y, ldx, ldy, n);
-  else if (n <= 4096) hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, block, 0, s, x, (bf16_t*)y, ldx, ldy, n);
-  else if (n <= 16384) hipLaunchKernelGGL(softmax_rows_kernel<16>, grid, block, 0, s, x, (bf16_t*)y, ldx, ldy, n);
-  else hipLaunchKernelGGL(softmax_rows_kernel<32>, grid, block, 0, s, x, (bf16_t*)y, ldx, ldy, n);
+  if (n <= 1024) hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, block, 0, s, x, (bf16_t*)y, ldx, ldy, n, ps, parts);
+  else if (n <= 4096) hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, block, 0, s, x, (bf16_t*)y, ldx, ldy, n, ps, parts);
+  else if (n <= 16384) hipLaunchKernelGGL(softmax_rows_kernel<16>, grid, block, 0, s, x, (bf16_t*)y, ldx, ldy, n, ps, parts);
+  else hipLaunchKernelGGL(softmax_rows_kernel<32>, grid, block, 0, s, x, (bf16_t*)y, ldx, ldy, n, ps, parts);
   FK_CHECK_LAUNCH("fk_softmax_rows");
   return FK_OK;
+}
+
+extern "C" int fk_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t n,
+                               fk_stream_t stream) {
+  return softmax_rows_entry(x, ldx, y, ldy, 0, 1, rows, n, stream);
+}
+
+extern "C" int fk_softmax_rows_parts(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t part_stride, int64_t rows,
+                                     int32_t n, fk_stream_t stream) {
+  FK_CHECK_ARG(part_stride >= n, "fk_softmax_rows_parts: part_stride < n");
+  return softmax_rows_entry(x, ldx, y, ldy, part_stride, 3, rows, n, stream);
 }

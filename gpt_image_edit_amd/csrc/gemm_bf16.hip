@@ -184,6 +184,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const fk_gemm_ar
       const int m = m0 + wm * 64 + mf * 32 + frow;
       if (m >= p.M) continue;
       const int64_t roff = fk_row_offset(p.c, m);
+      // f32_flags (fp32-class VAE encoder): bit 0 = the bias is fp32, bit 1 = add the fp32 tensor `res` (rows r)
+      const float* resf = (p.f32_flags & 2) ? (const float*)p.res + fk_row_offset(p.r, m) : nullptr;
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
@@ -192,7 +194,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const fk_gemm_ar
           if (n < p.N) {
             float v = acc[nf][mf][r];
             if constexpr (EPI == FK_EPI_SCALE) v *= p.alpha;
-            else if (p.bias) v += bf2f(((const bf16_t*)p.bias)[n]);
+            else if (p.bias) v += (p.f32_flags & 1) ? ((const float*)p.bias)[n] : bf2f(((const bf16_t*)p.bias)[n]);
+            if (resf) v += resf[n];
             C[roff + n] = v;
           }
         }
@@ -307,6 +310,8 @@ static int validate_gemm(const fk_gemm_args& p) {
                  "fk_gemm_bf16: gate pointer/stride invalid");
   }
   FK_CHECK_ARG(p.epilogue >= FK_EPI_NONE && p.epilogue <= FK_EPI_QKV, "fk_gemm_bf16: unknown epilogue %d", p.epilogue);
+  FK_CHECK_ARG(p.f32_flags == 0 || (p.out_fp32 == 1 && (p.f32_flags & ~3) == 0 && (!(p.f32_flags & 2) || p.res)),
+               "fk_gemm_bf16: f32_flags (fp32 bias / fp32 residual) belong to out_fp32 = 1");
   if (p.epilogue == FK_EPI_QKV) {
     FK_CHECK_ARG(!p.out_fp32 && p.q_out && p.k_out && p.wq && p.wk && p.rope_cs,
                  "fk_gemm_bf16: FK_EPI_QKV needs q_out/k_out/wq/wk/rope_cs");
@@ -478,4 +483,34 @@ extern "C" int fk_conv2d_nhwc_bf16(const fk_conv_args* args, fk_stream_t stream_
   hipStream_t stream = (hipStream_t)stream_;
   if (a.res) return launch<FK_EPI_RES, false, true>(p, stream, g);
   return launch<FK_EPI_NONE, false, true>(p, stream, g);
+}
+
+// The same implicit GEMM with fp32 output for the fp32-class encoder: x / w hold the bf16 parts of fp32 operands side by
+// side along the channel axis ([a_hi | a_lo | a_hi] . [w_hi | w_hi | w_lo], see vae_kernels.hip), bias / res / y are fp32.
+extern "C" int fk_conv2d_nhwc_f32out(const fk_conv_args* args, fk_stream_t stream_) {
+  FK_CHECK_ARG(args != nullptr, "fk_conv2d_nhwc_f32out: null args");
+  const fk_conv_args& a = *args;
+  FK_CHECK_ARG(a.x && a.w && a.y, "fk_conv2d_nhwc_f32out: null x/w/y");
+  FK_CHECK_ARG((a.ksize == 1 || a.ksize == 3) && (a.stride == 1 || a.stride == 2) && !a.upsample2x,
+               "fk_conv2d_nhwc_f32out: ksize 1 / 3, stride 1 / 2, no upsample");
+  FK_CHECK_ARG(a.Cin % 8 == 0 && a.Cout > 0, "fk_conv2d_nhwc_f32out: Cin must be a multiple of 8 (pad channels)");
+  FK_CHECK_ARG(a.B > 0 && a.Hin > 0 && a.Win > 0 && a.Hout > 0 && a.Wout > 0, "fk_conv2d_nhwc_f32out: bad sizes");
+  const int64_t Mll = (int64_t)a.B * a.Hout * a.Wout;
+  FK_CHECK_ARG(Mll < (1ll << 31) && (int64_t)a.B * a.Hin * a.Win < (1ll << 31), "fk_conv2d_nhwc_f32out: too many pixels");
+  FK_CHECK_ARG(((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.w % 16 == 0) && ((uintptr_t)a.y % 16 == 0),
+               "fk_conv2d_nhwc_f32out: alignment");
+  const int Kreal = a.ksize * a.ksize * a.Cin;
+  const int Kpad = (Kreal + BK - 1) / BK * BK;
+  fk_gemm_args p = {};
+  p.A = a.x; p.a = {0, 0, 0};
+  p.W = a.w; p.ldw = Kpad;
+  p.bias = a.bias;
+  p.C = a.y; p.c = {a.Cout, 0, 0};
+  p.res = a.res; p.r = {a.Cout, 0, 0};
+  p.M = (int)Mll; p.N = a.Cout; p.K = Kpad;
+  p.epilogue = FK_EPI_NONE;
+  p.out_fp32 = 1;
+  p.f32_flags = 1 | (a.res ? 2 : 0);
+  ConvGeom g = {a.Hin, a.Win, a.Cin, a.Hout, a.Wout, a.ksize, a.stride, a.pad, 0};
+  return launch<FK_EPI_NONE, true, true>(p, (hipStream_t)stream_, g);
 }

@@ -19,7 +19,9 @@ inline int gn_blocks(int64_t HW, int C) {
 }
 
 // grid (nblk, B).  Thread t owns channel chunk (t % (C/8)) of pixels (t / (C/8)) + k * ppi.
-__global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(const bf16_t* x, float* ws, int64_t HW, int C,
+// T = bf16_t, or float for the fp32-class encoder (fk_groupnorm_f32_nhwc): same sums, same fixed merge order.
+template <typename T>
+__global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(const T* x, float* ws, int64_t HW, int C,
                                                                 int groups) {
   __shared__ float hs[2 * GN_THREADS], hq[2 * GN_THREADS];
   const int tid = threadIdx.x;
@@ -32,11 +34,17 @@ __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(const bf16_t* x,
   const int64_t p1 = (p0 + per_blk < HW) ? p0 + per_blk : HW;
   float s_lo = 0.f, q_lo = 0.f, s_hi = 0.f, q_hi = 0.f;  // channels [0,4) and [4,8) of the chunk
   if (prow < ppi) {
-    const bf16_t* xb = x + (int64_t)b * HW * C + chunk * 8;
+    const T* xb = x + (int64_t)b * HW * C + chunk * 8;
     for (int64_t p = p0 + prow; p < p1; p += ppi) {
-      const u32x4_t w = *(const u32x4_t*)(xb + p * C);
-      const float v0 = bf_lo(w[0]), v1 = bf_hi(w[0]), v2 = bf_lo(w[1]), v3 = bf_hi(w[1]);
-      const float v4 = bf_lo(w[2]), v5 = bf_hi(w[2]), v6 = bf_lo(w[3]), v7 = bf_hi(w[3]);
+      float v0, v1, v2, v3, v4, v5, v6, v7;
+      if constexpr (sizeof(T) == 4) {
+        const f32x4_t a = *(const f32x4_t*)(xb + p * C), c = *(const f32x4_t*)(xb + p * C + 4);
+        v0 = a[0]; v1 = a[1]; v2 = a[2]; v3 = a[3]; v4 = c[0]; v5 = c[1]; v6 = c[2]; v7 = c[3];
+      } else {
+        const u32x4_t w = *(const u32x4_t*)(xb + p * C);
+        v0 = bf_lo(w[0]); v1 = bf_hi(w[0]); v2 = bf_lo(w[1]); v3 = bf_hi(w[1]);
+        v4 = bf_lo(w[2]); v5 = bf_hi(w[2]); v6 = bf_lo(w[3]); v7 = bf_hi(w[3]);
+      }
       s_lo += (v0 + v1) + (v2 + v3);
       q_lo += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
       s_hi += (v4 + v5) + (v6 + v7);
@@ -213,6 +221,104 @@ __global__ __launch_bounds__(256) void image_to_u8_kernel(const T* src, uint8_t*
   }
 }
 
+// ---- fp32-class encoder (reference: train_denoiser.py:458,887-918 keeps the VAE in fp32) --------------------------------
+// Activations are fp32 NHWC.  A matrix product a . w is computed on the bf16 MFMA as the K-concatenation
+//   [a_hi | a_lo | a_hi] . [w_hi | w_hi | w_lo]   (a_hi = bf16(a), a_lo = bf16(a - a_hi); fp32 accumulation),
+// i.e. every fp32 operand is handed to the GEMM / implicit-GEMM kernels as 2 (bf16 weights: w_lo = 0) or 3 bf16 "parts"
+// laid side by side along K; the dropped term a_lo . w_lo is ~2^-16 of the product.
+FK_DEV void split_f32(float v, float& hi, float& lo) {
+  hi = round_bf(v);
+  lo = v - hi;   // exact in fp32; rounded to bf16 when packed
+}
+
+// part slots of (hi, lo): activation order (hi, lo, hi), weight order (hi, hi, lo); parts = 2: (hi, lo)
+FK_DEV void store_parts(bf16_t* y, int64_t ps, int parts, int order, const float* hi, const float* lo) {
+  u32x2_t h, l;
+  h[0] = pack_bf2(hi[0], hi[1]); h[1] = pack_bf2(hi[2], hi[3]);
+  l[0] = pack_bf2(lo[0], lo[1]); l[1] = pack_bf2(lo[2], lo[3]);
+  *(u32x2_t*)y = h;
+  if (parts == 2) {
+    *(u32x2_t*)(y + ps) = l;
+  } else {
+    *(u32x2_t*)(y + ps) = order ? h : l;
+    *(u32x2_t*)(y + 2 * ps) = order ? l : h;
+  }
+}
+
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* x, int64_t ldx, bf16_t* y, int64_t ldy, int64_t ps,
+                                                         int64_t rows, int n, int parts, int order) {
+  const int nv = n / 4;
+  const int64_t total = rows * nv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / nv;
+    const int c = (int)(i - r * nv) * 4;
+    const f32x4_t v = *(const f32x4_t*)(x + r * ldx + c);
+    float hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_f32(v[e], hi[e], lo[e]);
+    store_parts(y + r * ldy + c, ps, parts, order, hi, lo);
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_f32_kernel(const float* x, bf16_t* y, const float* stats,
+                                                           const float* gamma, const float* beta, int64_t HW, int C,
+                                                           int groups, int silu, int parts) {
+  const int b = blockIdx.y;
+  const int cpr = C / 4, cpg = C / groups;   // cpg >= 4: the four channels of a vector share a group
+  const int64_t nvec = HW * cpr;
+  const float* xb = x + (int64_t)b * HW * C;
+  bf16_t* yb = y + (int64_t)b * HW * C * parts;
+  const float* st = stats + (int64_t)b * groups * 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int64_t pix = i / cpr;
+    const int c0 = (int)(i - pix * cpr) * 4;
+    const f32x4_t v = *(const f32x4_t*)(xb + i * 4);
+    const f32x4_t gw = *(const f32x4_t*)(gamma + c0), bw = *(const f32x4_t*)(beta + c0);
+    const int g = c0 / cpg;
+    const float mean = st[2 * g], rstd = st[2 * g + 1];
+    float hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = (v[e] - mean) * rstd * gw[e] + bw[e];
+      if (silu) t = t / (1.0f + expf(-t));
+      split_f32(t, hi[e], lo[e]);
+    }
+    store_parts(yb + pix * (int64_t)C * parts + c0, C, parts, 0, hi, lo);
+  }
+}
+
+// NCHW fp32 -> NHWC bf16 parts, every part zero padded to Cpad channels: [B, HW, parts * Cpad]
+__global__ __launch_bounds__(256) void nchw_f32_to_parts_kernel(const float* src, bf16_t* dst, int C, int Cpad, int64_t HW,
+                                                                int parts) {
+  const int b = blockIdx.y;
+  const int64_t total = HW * Cpad;
+  const float* sb = src + (int64_t)b * C * HW;
+  bf16_t* db = dst + (int64_t)b * HW * Cpad * parts;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % Cpad);
+    const int64_t p = i / Cpad;
+    float hi = 0.f, lo = 0.f;
+    if (c < C) split_f32(sb[(int64_t)c * HW + p], hi, lo);
+    bf16_t* o = db + p * Cpad * parts + c;
+    o[0] = f2bf(hi);
+    o[Cpad] = f2bf(lo);
+    if (parts == 3) o[2 * Cpad] = f2bf(hi);
+  }
+}
+
+__global__ __launch_bounds__(256) void nhwc_f32_to_nchw_kernel(const float* src, float* dst, int C, int Cpad, int64_t HW,
+                                                               float add, float mul) {
+  const int b = blockIdx.y;
+  const int64_t total = HW * C;
+  const float* sb = src + (int64_t)b * HW * Cpad;
+  float* db = dst + (int64_t)b * C * HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i / HW);
+    const int64_t p = i - (int64_t)c * HW;
+    db[i] = __fmul_rn(__fadd_rn(sb[p * Cpad + c], add), mul);
+  }
+}
+
 inline int ew_grid(int64_t n) {
   int64_t g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -233,7 +339,7 @@ extern "C" int fk_groupnorm_stats_nhwc_bf16(const void* x, float* stats, float* 
   FK_CHECK_ARG((uintptr_t)x % 16 == 0, "fk_groupnorm_stats: alignment");
   hipStream_t stream = (hipStream_t)stream_;
   const int nblk = gn_blocks(HW, C);
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, B), dim3(GN_THREADS), 0, stream, (const bf16_t*)x, ws, HW, C, groups);
+  hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, dim3(nblk, B), dim3(GN_THREADS), 0, stream, (const bf16_t*)x, ws, HW, C, groups);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, stream, (const float*)ws, stats, nblk, groups,
                      (double)HW * (C / groups), eps);
   FK_CHECK_LAUNCH("fk_groupnorm_stats_nhwc_bf16");
@@ -299,5 +405,57 @@ extern "C" int fk_image_to_u8_nhwc(const void* src, int32_t src_is_fp32, void* d
   if (src_is_fp32) hipLaunchKernelGGL(image_to_u8_kernel<float>, grid, block, 0, s, (const float*)src, (uint8_t*)dst, C, HW);
   else hipLaunchKernelGGL(image_to_u8_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)src, (uint8_t*)dst, C, HW);
   FK_CHECK_LAUNCH("fk_image_to_u8_nhwc");
+  return FK_OK;
+}
+
+// ---- fp32-class encoder entry points ----------------------------------------------------------------------------------
+extern "C" int fk_split_f32_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t part_stride, int64_t rows,
+                                 int32_t n, int32_t parts, int32_t weight_order, fk_stream_t stream_) {
+  FK_CHECK_ARG(x && y && rows > 0 && n > 0 && n % 4 == 0 && (parts == 2 || parts == 3), "fk_split_f32_rows: bad arguments");
+  FK_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && part_stride % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 8 == 0),
+               "fk_split_f32_rows: alignment");
+  hipLaunchKernelGGL(split_rows_kernel, dim3(ew_grid(rows * (n / 4))), dim3(256), 0, (hipStream_t)stream_, x, ldx,
+                     (bf16_t*)y, ldy, part_stride, rows, n, parts, weight_order ? 1 : 0);
+  FK_CHECK_LAUNCH("fk_split_f32_rows");
+  return FK_OK;
+}
+
+extern "C" int fk_groupnorm_f32_nhwc(const float* x, void* y_parts, float* stats, float* ws, const float* gamma,
+                                     const float* beta, int32_t B, int64_t HW, int32_t C, int32_t groups, float eps,
+                                     int32_t silu, int32_t parts, fk_stream_t stream_) {
+  FK_CHECK_ARG(x && y_parts && stats && ws && gamma && beta && B > 0 && HW > 0 && (parts == 2 || parts == 3),
+               "fk_groupnorm_f32_nhwc: bad arguments");
+  FK_CHECK_ARG(groups == 32 && C % 128 == 0 && C <= 1024, "fk_groupnorm_f32_nhwc: needs 32 groups and C in {128, 256, 512}");
+  FK_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)y_parts % 16 == 0) && ((uintptr_t)gamma % 16 == 0) &&
+                   ((uintptr_t)beta % 16 == 0), "fk_groupnorm_f32_nhwc: alignment");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int nblk = gn_blocks(HW, C);
+  hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nblk, B), dim3(GN_THREADS), 0, stream, x, ws, HW, C, groups);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, stream, (const float*)ws, stats, nblk, groups,
+                     (double)HW * (C / groups), eps);
+  hipLaunchKernelGGL(gn_apply_f32_kernel, dim3(ew_grid(HW * (C / 4)), B), dim3(256), 0, stream, x, (bf16_t*)y_parts,
+                     (const float*)stats, gamma, beta, HW, C, groups, silu, parts);
+  FK_CHECK_LAUNCH("fk_groupnorm_f32_nhwc");
+  return FK_OK;
+}
+
+extern "C" int fk_nchw_f32_to_nhwc_parts(const float* src, void* dst, int32_t B, int32_t C, int32_t Cpad, int32_t H,
+                                         int32_t W, int32_t parts, fk_stream_t stream_) {
+  FK_CHECK_ARG(src && dst && B > 0 && C > 0 && Cpad >= C && H > 0 && W > 0 && (parts == 2 || parts == 3),
+               "fk_nchw_f32_to_nhwc_parts: bad arguments");
+  const int64_t HW = (int64_t)H * W;
+  hipLaunchKernelGGL(nchw_f32_to_parts_kernel, dim3(ew_grid(HW * Cpad), B), dim3(256), 0, (hipStream_t)stream_, src,
+                     (bf16_t*)dst, C, Cpad, HW, parts);
+  FK_CHECK_LAUNCH("fk_nchw_f32_to_nhwc_parts");
+  return FK_OK;
+}
+
+extern "C" int fk_nhwc_f32_to_nchw(const float* src, float* dst, int32_t B, int32_t C, int32_t Cpad, int32_t H, int32_t W,
+                                   float add, float mul, fk_stream_t stream_) {
+  FK_CHECK_ARG(src && dst && B > 0 && C > 0 && Cpad >= C && H > 0 && W > 0, "fk_nhwc_f32_to_nchw: bad arguments");
+  const int64_t HW = (int64_t)H * W;
+  hipLaunchKernelGGL(nhwc_f32_to_nchw_kernel, dim3(ew_grid(HW * C), B), dim3(256), 0, (hipStream_t)stream_, src, dst, C,
+                     Cpad, HW, add, mul);
+  FK_CHECK_LAUNCH("fk_nhwc_f32_to_nchw");
   return FK_OK;
 }

@@ -32,7 +32,7 @@ class GemmArgs(ctypes.Structure):
         ("M", c_i32), ("N", c_i32), ("K", c_i32),
         ("epilogue", c_i32), ("out_fp32", c_i32), ("alpha", c_f32),
         ("q_out", c_vp), ("k_out", c_vp), ("wq", c_vp), ("wk", c_vp), ("rope_cs", c_vp), ("splitk_ws", c_vp),
-        ("qkv_s_offset", c_i32), ("qkv_s_total", c_i32), ("qkv_heads", c_i32), ("splitk_slots", c_i32), ("layout", c_i32), ("reserved0", c_i32),
+        ("qkv_s_offset", c_i32), ("qkv_s_total", c_i32), ("qkv_heads", c_i32), ("splitk_slots", c_i32), ("layout", c_i32), ("f32_flags", c_i32),
     ]
 
 
@@ -112,6 +112,12 @@ SIGNATURES = {
     "fk_euler_step_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "fk_transpose_bf16": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "fk_softmax_rows": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp]),
+    "fk_softmax_rows_parts": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp]),
+    "fk_split_f32_rows": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "fk_groupnorm_f32_nhwc": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_f32, c_i32, c_i32, c_vp]),
+    "fk_conv2d_nhwc_f32out": (c_i32, [c_vp, c_vp]),
+    "fk_nchw_f32_to_nhwc_parts": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "fk_nhwc_f32_to_nchw": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp]),
     "fk_conv2d_nhwc_bf16": (c_i32, [ctypes.POINTER(ConvArgs), c_vp]),
     "fk_conv3x3_halo_bf16": (c_i32, [ctypes.POINTER(ConvArgs), c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "fk_conv3x3_halo_f32_debug": (c_i32, [ctypes.POINTER(ConvArgs), c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),

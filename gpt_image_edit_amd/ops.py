@@ -119,6 +119,9 @@ def _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv=None, 
         args.gate_rows_per_batch = a.shape[1]
     args.M, args.N, args.K = M, N, K
     args.epilogue, args.out_fp32, args.alpha = epilogue, int(out_fp32), float(alpha)
+    if int(out_fp32) == 1:       # fp32-class VAE encoder: fp32 bias / fp32 residual added to the fp32 output
+        args.f32_flags = ((1 if bias is not None and bias.dtype == torch.float32 else 0) |
+                          (2 if res is not None and res.dtype == torch.float32 and epilogue == FK_EPI_NONE else 0))
     if K >= 6144 and N % 256 == 0 and M <= 256 * SPLITK_SLOTS and int(out_fp32) != 1 and layout == 0:   # the only shapes the planner may split
         ws, slots = splitk_workspace(a.device)
         args.splitk_ws, args.splitk_slots = ws.data_ptr(), slots
@@ -348,6 +351,94 @@ def softmax_rows(x, out=None):
         out = torch.empty((rows, n), device=x.device, dtype=BF16)
     libfk.check(libfk.load().fk_softmax_rows(_ptr(x), x.stride(0), _ptr(out), out.stride(0), rows, n,
                                              _stream()), "fk_softmax_rows")
+    return out
+
+
+
+# ---- fp32-class VAE encoder (include/fk.h "fp32-class encoder"; reference train_denoiser.py:458,887-918) ---------------
+F32 = torch.float32
+
+
+def split_f32_rows(x, out, parts=3, weight_order=False):
+    """fp32 [rows, n] view -> bf16 parts in ``out`` [rows, parts * n]-like view: part p of x[r, c] at out[r, p*ps + c] with
+    ps = out.shape[1] // parts.  Order (hi, lo, hi), or (hi, hi, lo) for the weight side of a product."""
+    _need_cuda(x, out)
+    rows, n = x.shape
+    ps = out.shape[1] // parts
+    if x.dtype != F32 or out.dtype != BF16 or out.shape[0] != rows or ps < n or x.stride(1) != 1 or out.stride(1) != 1:
+        raise ValueError("split_f32_rows: fp32 [rows, n] -> bf16 [rows, parts * ps], ps >= n")
+    libfk.check(libfk.load().fk_split_f32_rows(_ptr(x), x.stride(0), _ptr(out), out.stride(0), ps, rows, n, parts,
+                                               int(weight_order), _stream()), "fk_split_f32_rows")
+    return out
+
+
+def group_norm_f32_parts(x, gamma, beta, silu, parts, eps=1e-6):
+    """GroupNorm(32) (+ SiLU) of fp32 NHWC x (fp32 gamma / beta) -> bf16 parts [B, ..., parts * C]."""
+    _need_cuda(x, gamma, beta)
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    if x.dtype != F32 or gamma.dtype != F32 or beta.dtype != F32 or not x.is_contiguous():
+        raise TypeError("group_norm_f32_parts takes contiguous fp32 tensors")
+    lib = libfk.load()
+    ws, stats = _gn_workspace(lib, B, HW, C, x.device)
+    out = torch.empty((*x.shape[:-1], parts * C), device=x.device, dtype=BF16)
+    libfk.check(lib.fk_groupnorm_f32_nhwc(_ptr(x), _ptr(out), _ptr(stats), _ptr(ws), _ptr(gamma), _ptr(beta), B, HW, C, 32,
+                                          eps, int(silu), parts, _stream()), "fk_groupnorm_f32_nhwc")
+    return out
+
+
+def conv2d_nhwc_f32out(x_parts, w_packed, bias, cout, ksize=3, stride=1, pad=1, res=None):
+    """x_parts: [B,H,W,parts*C] bf16 operand parts; w_packed [cout, Kpad] bf16 over the same channel layout; bias / res /
+    result fp32."""
+    _need_cuda(x_parts, w_packed, bias, res)
+    B, Hin, Win, Cin = x_parts.shape
+    if stride == 1:
+        Hout, Wout = Hin, Win
+    else:
+        Hout, Wout = (Hin + 1 - 3) // 2 + 1, (Win + 1 - 3) // 2 + 1
+    if x_parts.dtype != BF16 or bias.dtype != F32 or (res is not None and (res.dtype != F32 or not res.is_contiguous())) \
+            or not x_parts.is_contiguous():
+        raise TypeError("conv2d_nhwc_f32out: bf16 parts in, fp32 bias / residual")
+    out = torch.empty((B, Hout, Wout, cout), device=x_parts.device, dtype=F32)
+    a = libfk.ConvArgs()
+    a.x, a.w, a.bias, a.y = x_parts.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), out.data_ptr()
+    a.res = res.data_ptr() if res is not None else None
+    a.B, a.Hin, a.Win, a.Cin, a.Cout = B, Hin, Win, Cin, cout
+    a.ksize, a.stride, a.pad, a.upsample2x = ksize, stride, pad, 0
+    a.Hout, a.Wout = Hout, Wout
+    libfk.check(libfk.load().fk_conv2d_nhwc_f32out(ctypes.byref(a), _stream()), "fk_conv2d_nhwc_f32out")
+    return out
+
+
+def nchw_f32_to_nhwc_parts(x, cpad, parts):
+    _need_cuda(x)
+    B, C, H, W = x.shape
+    if x.dtype != F32 or not x.is_contiguous():
+        raise TypeError("nchw_f32_to_nhwc_parts takes contiguous fp32 NCHW")
+    out = torch.empty((B, H, W, parts * cpad), device=x.device, dtype=BF16)
+    libfk.check(libfk.load().fk_nchw_f32_to_nhwc_parts(_ptr(x), _ptr(out), B, C, cpad, H, W, parts, _stream()),
+                "fk_nchw_f32_to_nhwc_parts")
+    return out
+
+
+def nhwc_f32_to_nchw(x, c, add=0.0, mul=1.0):
+    _need_cuda(x)
+    B, H, W, cpad = x.shape
+    if x.dtype != F32 or not x.is_contiguous():
+        raise TypeError("nhwc_f32_to_nchw takes contiguous fp32 NHWC")
+    out = torch.empty((B, c, H, W), device=x.device, dtype=F32)
+    libfk.check(libfk.load().fk_nhwc_f32_to_nchw(_ptr(x), _ptr(out), B, c, cpad, H, W, float(add), float(mul), _stream()),
+                "fk_nhwc_f32_to_nchw")
+    return out
+
+
+def softmax_rows_parts(x, out):
+    """fp32 [rows, n] -> the bf16 parts (hi, lo, hi) of the fp32 softmax in ``out`` [rows, 3 * ps]."""
+    _need_cuda(x, out)
+    rows, n = x.shape
+    ps = out.shape[1] // 3
+    libfk.check(libfk.load().fk_softmax_rows_parts(_ptr(x), x.stride(0), _ptr(out), out.stride(0), ps, rows, n, _stream()),
+                "fk_softmax_rows_parts")
     return out
 
 

@@ -108,7 +108,7 @@ typedef struct fk_gemm_args {
    * gradient dW = dY^T X reads both operands token-major.  1 / 2: N % 256 == 0, K % 64 == 0, epilogue none (1: also
    * FK_EPI_RES), 2: M % 256 == 0; same sums, bit for bit, as layout 0 on transposed copies. */
   int32_t layout;
-  int32_t reserved0;
+  int32_t f32_flags;         /* out_fp32 = 1 only: bit 0 = bias is fp32 [N]; bit 1 = `res` is an fp32 tensor (rows r) added to C */
 } fk_gemm_args;
 #define FK_SPLITK_SLOT_BYTES (256 * 256 * 4 + 8)
 
@@ -421,6 +421,34 @@ int fk_nchw_to_nhwc_bf16(const void* src, int32_t src_is_fp32, void* dst, int32_
  * y = bf16(bf16(x + add) * mul)  (`(z - shift) * scaling` of flux_pipeline.py:611). */
 int fk_nhwc_to_nchw(const void* src, void* dst, int32_t dst_is_fp32, int32_t B, int32_t C, int32_t Cpad,
                     int32_t H, int32_t W, float add, float mul, fk_stream_t stream);
+
+/* ---- fp32-class encoder (reference: train_denoiser.py:458 loads the VAE in fp32 and :887-918 encodes the target and the
+ * condition image with it inside every optimisation step).  Activations are fp32 NHWC; a product a . w runs on the bf16
+ * MFMA as the K-concatenation [a_hi | a_lo | a_hi] . [w_hi | w_hi | w_lo] with a_hi = bf16(a), a_lo = bf16(a - a_hi) and
+ * fp32 accumulation (parts = 3; parts = 2 drops the third term: exact when the weights ARE bf16 numbers).  The term left
+ * out, a_lo . w_lo, is ~2^-16 of the product; tests hold the encoder to the fp32 oracle at rtol 1e-3 / atol 1e-4. ---- */
+/* y[r, p * part_stride + c] = part p of x[r, c] (fp32, n % 4 == 0); activation order (hi, lo, hi), or weight order
+ * (hi, hi, lo) when weight_order != 0; parts = 2: (hi, lo). */
+int fk_split_f32_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t part_stride, int64_t rows, int32_t n,
+                      int32_t parts, int32_t weight_order, fk_stream_t stream);
+/* GroupNorm(32) (+ SiLU, fp32 expf) of fp32 NHWC x with fp32 gamma / beta, written as the bf16 parts of the fp32 result:
+ * y_parts [B, HW, parts * C] = [hi | lo | hi] per pixel -- the operand layout of fk_conv2d_nhwc_f32out / fk_gemm_bf16.
+ * stats: [B, 32, 2] fp32 scratch, ws: fk_groupnorm_ws_floats(B, HW, C) floats. */
+int fk_groupnorm_f32_nhwc(const float* x, void* y_parts, float* stats, float* ws, const float* gamma, const float* beta,
+                          int32_t B, int64_t HW, int32_t C, int32_t groups, float eps, int32_t silu, int32_t parts,
+                          fk_stream_t stream);
+/* Implicit-GEMM convolution (fk_conv2d_nhwc_bf16's kernel) over operand parts: args->x [B, Hin, Win, Cin] and args->w hold
+ * the parts side by side along the channel axis (Cin = parts * C), args->bias / res / y are fp32. */
+int fk_conv2d_nhwc_f32out(const fk_conv_args* args, fk_stream_t stream);
+/* src NCHW fp32 -> NHWC bf16 parts [B, HW, parts * Cpad], every part zero padded to Cpad channels. */
+int fk_nchw_f32_to_nhwc_parts(const float* src, void* dst, int32_t B, int32_t C, int32_t Cpad, int32_t H, int32_t W,
+                              int32_t parts, fk_stream_t stream);
+/* src NHWC fp32 (channel stride Cpad) -> dst NCHW fp32, first C channels, y = (x + add) * mul in fp32. */
+int fk_nhwc_f32_to_nchw(const float* src, float* dst, int32_t B, int32_t C, int32_t Cpad, int32_t H, int32_t W, float add,
+                        float mul, fk_stream_t stream);
+/* fk_softmax_rows with the fp32 probability written as the three bf16 parts (hi, lo, hi), part_stride columns apart. */
+int fk_softmax_rows_parts(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t part_stride, int64_t rows, int32_t n,
+                          fk_stream_t stream);
 
 /* Pixels in: uint8 NHWC [B, Hin, Win, 3] (PIL / numpy layout) -> NHWC bf16 [B, Hout, Wout, Cpad] (channels >= 3 zero),
  * fusing the three host steps the reference runs in front of vae.encode:

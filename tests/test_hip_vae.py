@@ -236,3 +236,95 @@ def test_vae_is_deterministic_at_ragged_sizes():
     lat = torch.randn(2, 16, 6, 10, generator=g).to(torch.bfloat16).cuda()
     im = [vae.decode(lat, return_dict=False)[0].clone() for _ in range(4)]
     assert all(torch.equal(im[0], t) for t in im[1:])
+
+
+# ---- fp32-class encoder (train_denoiser.py:458,887-918: the reference encodes with an fp32 VAE) -----------------------
+def test_fp32_class_kernels():
+    """split / GroupNorm / softmax parts and the fp32-output convolution, each against fp32 torch."""
+    _skip()
+    from gpt_image_edit_amd import ops
+    from gpt_image_edit_amd.vae import _pack_conv_parts
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(37, 64, generator=g) * 3
+    out = torch.zeros(37, 3 * 72, dtype=BF).cuda()
+    ops.split_f32_rows(x.cuda(), out, parts=3)
+    o = out.cpu().float()
+    hi = x.to(BF).float()
+    lo = (x - hi).to(BF).float()
+    assert torch.equal(o[:, :64], hi) and torch.equal(o[:, 72:136], lo) and torch.equal(o[:, 144:208], hi)
+    assert ((hi + lo) - x).abs().max().item() <= x.abs().max().item() * 2.0 ** -16
+    ops.split_f32_rows(x.cuda(), out, parts=3, weight_order=True)
+    o = out.cpu().float()
+    assert torch.equal(o[:, :64], hi) and torch.equal(o[:, 72:136], hi) and torch.equal(o[:, 144:208], lo)
+    # GroupNorm + SiLU in fp32, written as parts
+    C, B = 256, 2
+    a = torch.randn(B, 9, 7, C, generator=g) * 2 + 0.5
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.1
+    for P in (2, 3):
+        yp = ops.group_norm_f32_parts(a.cuda(), gamma.cuda(), beta.cuda(), True, P).cpu().float()
+        got = yp[..., :C] + yp[..., C:2 * C]
+        ref = F.silu(F.group_norm(a.permute(0, 3, 1, 2), 32, gamma, beta, eps=1e-6)).permute(0, 2, 3, 1)
+        report(f"fp32 GroupNorm+SiLU parts={P}", got, ref)
+        torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5)
+        if P == 3:
+            assert torch.equal(yp[..., 2 * C:], yp[..., :C])
+    # convolution over parts: fp32 weights -> (hi, hi, lo), fp32 bias and residual
+    for (cin, cout, h, w, stride) in [(128, 256, 9, 7, 1), (3, 128, 10, 12, 1), (256, 256, 10, 8, 2), (512, 32, 6, 6, 1)]:
+        xa = torch.randn(B, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+        bias = torch.randn(cout, generator=g) * 0.1
+        if stride == 2:
+            ref = F.conv2d(F.pad(xa.double(), (0, 1, 0, 1)), wt.double(), bias.double(), stride=2).float()
+        else:
+            ref = F.conv2d(xa.double(), wt.double(), bias.double(), padding=1).float()
+        res = torch.randn(*ref.shape, generator=g)
+        cpad = 32 if cin < 32 else cin
+        xp = ops.nchw_f32_to_nhwc_parts(xa.cuda(), cpad, 3)
+        whi = wt.to(BF)
+        wp = _pack_conv_parts([whi.cuda(), whi.cuda(), (wt - whi.float()).to(BF).cuda()], cpad, cout)
+        got = ops.conv2d_nhwc_f32out(xp, wp, bias.cuda(), cout, stride=stride, pad=1 if stride == 1 else 0,
+                                     res=res.permute(0, 2, 3, 1).contiguous().cuda()).permute(0, 3, 1, 2).cpu()
+        report(f"fp32-class conv {cin}->{cout} s{stride}", got, ref + res)
+        torch.testing.assert_close(got, ref + res, rtol=1e-3, atol=1e-4)
+        d = (got - ref - res).abs().max().item()
+        assert d <= 3e-5 * ref.abs().max().item(), d          # ~2^-16 class, far below bf16's 2^-8
+    # softmax parts
+    s = torch.randn(50, 200, generator=g) * 4
+    pp = torch.zeros(50, 3 * 256, dtype=BF).cuda()
+    ops.softmax_rows_parts(s.cuda(), pp)
+    pp = pp.cpu().float()
+    ref = torch.softmax(s, dim=-1)
+    torch.testing.assert_close(pp[:, :200] + pp[:, 256:456], ref, rtol=1e-4, atol=1e-7)
+    assert torch.equal(pp[:, 512:712], pp[:, :200]) and pp[:, 200:256].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("fp32_weights", [False, True])
+def test_fp32_class_encoder_at_the_stated_tolerance(fp32_weights):
+    """HipAutoencoderKL.encode(fp32=True) against the fp32 oracle at rtol 1e-3 / atol 1e-4 -- with the module's bf16
+    parameters (two-term products) and with an fp32 checkpoint (load_fp32_state_dict: three-term products)."""
+    _skip()
+    from gpt_image_edit_amd import flux_spec
+    from gpt_image_edit_amd.vae import HipAutoencoderKL
+    from oracle import vae as ovae
+    sd = flux_spec.synthetic_state(flux_spec.vae_param_shapes(), seed=6)
+    vae = HipAutoencoderKL(device="cuda")
+    if fp32_weights:
+        sd32 = {k: v.float() for k, v in sd.items()}
+        assert any((v - v.to(BF).float()).abs().max().item() > 0 for v in sd32.values())
+        vae.load_fp32_state_dict(sd32)
+    else:
+        vae.load_state_dict({k: v.to(BF) for k, v in sd.items()})
+        sd32 = {k: v.to(BF).float() for k, v in sd.items()}
+    img = (torch.rand(2, 3, 64, 48, generator=torch.Generator().manual_seed(12)) * 2 - 1)
+    dist = vae.encode(img.cuda(), fp32=True).latent_dist
+    lat = dist.mode().cpu()
+    assert lat.dtype == torch.float32 and lat.shape == (2, 16, 8, 6)
+    ref = ovae.encode_mode(sd32, img)
+    d = report(f"vae.encode(fp32=True, fp32 weights={fp32_weights}) vs fp32-oracle", lat, ref)
+    torch.testing.assert_close(lat, ref, rtol=1e-3, atol=1e-4)
+    lat_bf = vae.encode(img.cuda()).latent_dist.mode().float().cpu()
+    d_bf = report("vae.encode (bf16 path) vs the same fp32-oracle", lat_bf, ref)
+    assert d.max().item() * 50 < d_bf.max().item()            # two orders of magnitude closer than the bf16 encoder
+    # the pipeline's shift / scale in fp32
+    lat2 = vae.encode(img.cuda(), fp32=True, post_add=-0.1159, post_mul=0.3611).latent_dist.mode().cpu()
+    torch.testing.assert_close(lat2, (ref - 0.1159) * 0.3611, rtol=1e-3, atol=1e-4)
