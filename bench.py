@@ -99,6 +99,7 @@ def instrumented_edit(pipe, inp):
     from gpt_image_edit_amd import ops, transformer
     overlap, transformer.OVERLAP_MLP = transformer.OVERLAP_MLP, False
     use_graph, pipe.use_graph = pipe.use_graph, False      # per-launch brackets need the eager loop
+    block_api, transformer.BLOCK_API = transformer.BLOCK_API, 0   # ... and one host call per launch (same kernels, same bits)
     rec = {"gemm": [], "attention": [], "conv": []}
     st = torch.cuda.current_stream()
 
@@ -152,7 +153,11 @@ def instrumented_edit(pipe, inp):
     finally:
         ops.gemm, ops.gemm_grouped, ops.attention, ops.conv2d_nhwc, ops.conv3x3_halo = orig
         transformer.OVERLAP_MLP = overlap
+        transformer.BLOCK_API = block_api
         pipe.use_graph = use_graph
+    if len(rec["attention"]) < 57 or len(rec["gemm"]) < 4 * 57:
+        raise RuntimeError(f"instrumented edit bracketed {len(rec['attention'])} attention / {len(rec['gemm'])} GEMM launches: "
+                           "the blocks' kernels were not enqueued one host call per launch")
     out = {}
     for fam, lst in rec.items():
         ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in lst)

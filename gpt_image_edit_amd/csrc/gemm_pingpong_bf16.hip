@@ -60,6 +60,7 @@ struct GroupArgs {
   float* sk_partials;
   unsigned* sk_ctl;
   int sk_min_part;     // stream-K launch (gemm8_streamk_kernel): the shortest part (in K-tiles) a cut may leave
+  int group_m;         // depth (in row tiles) of the grouped tile order; >= the row-tile count: every XCD owns a column range
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -157,10 +158,10 @@ FK_DEV void tile_of(const GroupArgs& ga, const int (&before)[FK_MAX_GROUP + 1], 
   const fk_gemm_args& p = ga.p[pi];
   t -= before[pi];
   const int nbm = (p.M + BM - 1) / BM;
-  const int per_group = GROUP_M * nbn;
+  const int per_group = ga.group_m * nbn;
   const int g = t / per_group;
-  const int first_m = g * GROUP_M;
-  const int gm = min(nbm - first_m, GROUP_M);
+  const int first_m = g * ga.group_m;
+  const int gm = min(nbm - first_m, ga.group_m);
   const int rem = t - g * per_group;
   m0 = (first_m + rem % gm) * BM;
   n0 = col0 + (rem / gm) * BN;
@@ -1077,9 +1078,25 @@ extern "C" int fk_gemm_set_plan(int32_t allow) {
 // runs in rounds of #CUs tiles: plan_launch picks the form with the shortest list-scheduling makespan.  (A stream-K form
 // of the 256 x 256 kernel that shares the last round's K-iterations among all CUs was built in round 1 and measured 2x
 // slower: DESIGN.md section 4b; git history.)
+static int g_group_m = -1;
+static int gemm_group_m() {
+  if (g_group_m < 0) {
+    const char* e = getenv("FK_GEMM_GROUP_M");
+    const int v = e ? atoi(e) : GROUP_M;
+    g_group_m = v >= 1 && v <= 4096 ? v : GROUP_M;
+  }
+  return g_group_m;
+}
+extern "C" int fk_gemm_set_group_m(int32_t depth) {
+  FK_CHECK_ARG(depth >= 0 && depth <= 4096, "fk_gemm_set_group_m: 0 (default) or 1..4096 row tiles");
+  g_group_m = depth == 0 ? GROUP_M : depth;
+  return FK_OK;
+}
+
 int fk_gemm2_launch(const fk_gemm_args* probs, int n, int variant_hint, hipStream_t stream) {
   GroupArgs ga;
   ga.n = n;
+  ga.group_m = gemm_group_m();
   ga.big_cols = 0;
   ga.sk_partials = nullptr;
   ga.sk_ctl = nullptr;

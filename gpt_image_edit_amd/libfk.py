@@ -76,6 +76,7 @@ SIGNATURES = {
     "fk_gemm_last_variant": (c_i32, []),
     "fk_gemm_set_variant": (c_i32, [c_i32]),
     "fk_gemm_set_plan": (c_i32, [c_i32]),
+    "fk_gemm_set_group_m": (c_i32, [c_i32]),
     "fk_ln_modulate_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "fk_ln_modulate2_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "fk_qkv_post_bf16": (c_i32, [c_vp] * 9 + [c_i32] * 4 + [c_f32, c_vp]),

@@ -126,6 +126,11 @@ int fk_gemm_set_variant(int32_t variant);
  * edits, so off).  Default 3 (FK_GEMM_PLAN overrides).  With bit 1 clear a GEMM's result does not depend on the grid it
  * runs in, i.e. a sample computed inside a batch equals the same sample computed alone bit for bit. */
 int fk_gemm_set_plan(int32_t allow);
+/* Tile order of the large-tile kernels (measurement hook; results do not depend on it): workgroup b runs on XCD b % 8 and every
+ * XCD works off a contiguous chunk of the tile list, which is ordered in groups of `depth` row tiles (256 rows each), rows
+ * fastest inside a group.  depth >= the number of row tiles makes every XCD's chunk a range of COLUMN tiles over all rows
+ * (a W tile then enters one XCD's L2 only).  0 = the default (8; FK_GEMM_GROUP_M overrides). */
+int fk_gemm_set_group_m(int32_t depth);
 
 /* n (<= FK_MAX_GROUP) independent problems that share N, K and the epilogue in ONE launch: the text- and
  * image-stream linears of a FluxTransformerBlock (different weights, different row counts) fill the GPU

@@ -4,6 +4,7 @@ once per round (1 warm-up + `edits` timed edits), medians over the rounds are pr
     plan=<0..3>   fk_gemm_set_plan (bit 0 mixed grids, bit 1 split-K pairs)
     split=<0|1>   fk_attention_set_split (stream-K attention grids where the plain grid wastes a round)
     side=<0|1|auto>  transformer.OVERLAP_MLP (single blocks' MLP-up GEMM on a second stream)
+    gm=<depth>    fk_gemm_set_group_m (row tiles per group of the tile order; 0 = default 8)
 
     AB_ARMS="plan=0;plan=1;plan=3" python tools/ab_edit_plans.py [workload] [rounds] [edits]
 """
@@ -31,12 +32,15 @@ def apply(arm):
     ops.gemm_set_plan(3)
     lib.fk_attention_set_split(1)
     transformer.OVERLAP_MLP = DEFAULT_SIDE
+    lib.fk_gemm_set_group_m(0)
     for kv in arm.split(","):
         k, v = kv.split("=")
         if k == "plan":
             ops.gemm_set_plan(int(v))
         elif k == "split":
             lib.fk_attention_set_split(int(v))
+        elif k == "gm":
+            lib.fk_gemm_set_group_m(int(v))
         elif k == "side":
             transformer.OVERLAP_MLP = {"0": False, "1": True}.get(v, "auto")
         else:
