@@ -101,6 +101,30 @@ def test_hot_gemm_kernels_at_the_stated_tolerance(ops, M, N, K, what):
     assert torch.equal(seen[128], seen[256]) and (384 not in seen or torch.equal(seen[384], seen[256]))
 
 
+def test_gemm_tile_order_does_not_change_the_bits(ops):
+    """fk_gemm_set_group_m only changes WHICH workgroup (and XCD) computes a tile: every depth -- incl. the one that gives
+    each XCD a column range over all rows -- must give the default order's bits, in every launch form, grouped or not."""
+    from gpt_image_edit_amd import libfk
+    lib = libfk.load()
+    a, a2 = randn(2560, 3072, seed=81).cuda(), randn(512, 3072, seed=82).cuda()
+    w, bias = randn(9216, 3072, seed=83, scale=0.05).cuda(), randn(9216, seed=84, scale=0.1).cuda()
+    try:
+        for force in (128, 256, 384):
+            lib.fk_gemm_set_variant(force)
+            lib.fk_gemm_set_group_m(0)
+            ref = ops.gemm(a, w, bias).clone()
+            ref_g = [t.clone() for t in ops.gemm_grouped([dict(a=a2, w=w, bias=bias), dict(a=a, w=w, bias=bias)])]
+            for depth in (1, 3, 16, 4096):
+                lib.fk_gemm_set_group_m(depth)
+                assert torch.equal(ops.gemm(a, w, bias), ref), (force, depth)
+                got_g = ops.gemm_grouped([dict(a=a2, w=w, bias=bias), dict(a=a, w=w, bias=bias)])
+                assert all(torch.equal(x, y) for x, y in zip(got_g, ref_g)), (force, depth)
+    finally:
+        lib.fk_gemm_set_variant(0)
+        lib.fk_gemm_set_group_m(0)
+    assert lib.fk_gemm_set_group_m(-1) != 0          # refused
+
+
 def test_gemm_layout_is_transpose_detecting(ops):
     # A = identity-like selector with an asymmetric W: catches row/col swaps of the MFMA C layout
     M = N = 128
