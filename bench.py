@@ -56,6 +56,7 @@ WORKLOADS = {
     "cfg4_slice4_1024x1024_28step": (4, 1024, 1024, 1024, 1024, 512),
 }
 EXTRA_WORKLOAD = "single_1024x1024_28step"
+CFG3_WORKLOAD = "cfg3_batch32_1024x1024_28step"
 TRAFFIC_FILE = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"))
                      if os.path.exists(f)), os.path.join(ROOT, "profiles", "r04_traffic.json"))
 
@@ -505,7 +506,7 @@ def main():
                     help="full: one full-depth CPU step + VAE (default); cfg1: all four steps of BASELINE.json configs[0]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the 1024^2 and prompt-encode extras")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extras (1024^2 edit, cfg 3 batch, prompt encode, cfg 5 train step)")
     args = ap.parse_args()
     if args.no_cpu_baseline:
         args.cpu_baseline = "none"
@@ -577,6 +578,20 @@ def main():
             ex["roofline"] = roofline_of(instrumented_edit(pipe, inp2), EXTRA_WORKLOAD)
         extra[EXTRA_WORKLOAD] = ex
         del inp2
+    if rank == 0 and world == 1 and not args.no_extra and WORKLOADS[args.workload][0] == 1 and os.environ.get("FK_BENCH_CFG3", "1") != "0":
+        # BASELINE.json configs[2] (B = 32 at 1024^2: one GPU's share of the reference's batch runs) in the same run: ONE timed
+        # batch, no warm-up batch of that shape (a batch takes ~2 min; its first-call allocations are < 1 % of it)
+        try:
+            inp3 = make_inputs(CFG3_WORKLOAD, device, seed=242)
+            el3 = timed_edits(pipe, inp3, 1, 0, 1, device, backend)
+            extra[CFG3_WORKLOAD] = {"value": 32 / el3, "unit": "images/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": el3 * 1e3,
+                                    "config": {"workload": CFG3_WORKLOAD, "batch_per_gpu": 32, "height": 1024, "width": 1024,
+                                               "seq_len": inp3["S_txt"] + inp3["S_tgt"] + inp3["S_cond"], "num_inference_steps": 28},
+                                    "peak_memory_gb": torch.cuda.max_memory_allocated(device) / 1e9}
+            del inp3
+        except Exception as e:
+            extra[CFG3_WORKLOAD] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_extra:
         try:
             del pipe
