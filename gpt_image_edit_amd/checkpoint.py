@@ -130,18 +130,24 @@ def load_flux_transformer(model, path):
 
 
 # ---- VAE ----------------------------------------------------------------------------------------------------
-def read_vae(flux_path, config=None):
+def read_vae(flux_path, config=None, dtype=torch.bfloat16):
     sub = os.path.join(flux_path, "vae")
     directory = sub if os.path.isdir(sub) else flux_path
     cfg = config or _config_of(directory, flux_spec.FLUX_VAE_CONFIG)
-    state = read_state_dict(directory, dtype=torch.bfloat16)
+    state = read_state_dict(directory, dtype=dtype)
     check_against(flux_spec.vae_param_shapes(cfg), state, f"AutoencoderKL at {directory}")
     return state, cfg
 
 
-def load_vae(model, path):
-    state, _ = read_vae(path, config=vars(model.config))
-    model.load_state_dict(state, strict=True)
+def load_vae(model, path, fp32=False):
+    """``fp32=True``: the reference's ``vae_fp32`` (train_denoiser.py:458 loads the VAE with torch_dtype float32) -- the
+    checkpoint is read in fp32 and kept beside the bf16 parameters for ``encode(fp32=True)``
+    (HipAutoencoderKL.load_fp32_state_dict)."""
+    state, _ = read_vae(path, config=vars(model.config), dtype=torch.float32 if fp32 else torch.bfloat16)
+    if fp32:
+        model.load_fp32_state_dict(state, strict=True)
+    else:
+        model.load_state_dict(state, strict=True)
     return model
 
 
