@@ -49,6 +49,7 @@ struct HaloArgs {
   int up, silu, groups;
   int tiles_x, tiles_y, tiles_n;
   int ldw;                 // weight row stride in elements (>= 9 * Cin)
+  int f32io;               // F32OUT only: bias and res are fp32 (fk_conv3x3_halo_f32out, the fp32-class encoder)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -253,15 +254,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloArgs p) 
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = n0 + wn * 64 + nf * 32 + 8 * q + 4 * fhalf;
-        const u32x2_t bw = *(const u32x2_t*)(p.bias + min(n, p.Cout - 4));
+        const int nb = min(n, p.Cout - 4);
+        f32x4_t bv;
+        if (p.f32io) {
+          bv = *(const f32x4_t*)((const float*)p.bias + nb);
+        } else {
+          const u32x2_t bw = *(const u32x2_t*)(p.bias + nb);
+          bv = f32x4_t{bf_lo(bw[0]), bf_hi(bw[0]), bf_lo(bw[1]), bf_hi(bw[1])};
+        }
 #pragma unroll
         for (int mf = 0; mf < 2; ++mf) {
           const int pix = wm * 64 + mf * 32 + frow;
           const int oy = y0 + (pix >> 4), ox = x0 + (pix & 15);
-          if (oy < p.H && ox < p.W && n < p.Cout)
-            *(f32x4_t*)((float*)p.y + (((int64_t)b * p.H + oy) * p.W + ox) * p.Cout + n) =
-                f32x4_t{acc[nf][mf][4 * q + 0] + bf_lo(bw[0]), acc[nf][mf][4 * q + 1] + bf_hi(bw[0]),
-                        acc[nf][mf][4 * q + 2] + bf_lo(bw[1]), acc[nf][mf][4 * q + 3] + bf_hi(bw[1])};
+          if (oy < p.H && ox < p.W && n < p.Cout) {
+            const int64_t off = (((int64_t)b * p.H + oy) * p.W + ox) * p.Cout + n;
+            f32x4_t o = f32x4_t{acc[nf][mf][4 * q + 0], acc[nf][mf][4 * q + 1], acc[nf][mf][4 * q + 2], acc[nf][mf][4 * q + 3]} + bv;
+            if (p.f32io && p.res) o += *(const f32x4_t*)((const float*)p.res + off);
+            *(f32x4_t*)((float*)p.y + off) = o;
+          }
         }
       }
     return;
@@ -319,7 +329,7 @@ int launch_halo(const HaloArgs& p, hipStream_t stream) {
 }  // namespace
 
 static int conv3x3_halo_entry(const fk_conv_args* args, const float* gn_stats, const void* gn_gamma, const void* gn_beta,
-                              int32_t gn_groups, int32_t gn_silu, bool f32out, fk_stream_t stream_) {
+                              int32_t gn_groups, int32_t gn_silu, bool f32out, fk_stream_t stream_, bool f32io = false) {
   FK_CHECK_ARG(args != nullptr, "fk_conv3x3_halo_bf16: null args");
   const fk_conv_args& a = *args;
   FK_CHECK_ARG(a.x && a.w && a.y && a.bias, "fk_conv3x3_halo_bf16: null x / w / bias / y");
@@ -330,7 +340,7 @@ static int conv3x3_halo_entry(const fk_conv_args* args, const float* gn_stats, c
   FK_CHECK_ARG(a.Hout == (a.Hin << up) && a.Wout == (a.Win << up), "fk_conv3x3_halo_bf16: output size does not match the input");
   FK_CHECK_ARG((int64_t)a.Hin * a.Win * a.Cin < (1ll << 31), "fk_conv3x3_halo_bf16: one image must stay below 2^31 elements");
   FK_CHECK_ARG(((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.w % 16 == 0) && ((uintptr_t)a.y % 16 == 0) &&
-                   (!a.res || (uintptr_t)a.res % 16 == 0) && ((uintptr_t)a.bias % 8 == 0),
+                   (!a.res || (uintptr_t)a.res % 16 == 0) && ((uintptr_t)a.bias % (f32io ? 16 : 8) == 0),
                "fk_conv3x3_halo_bf16: alignment");
   const bool gn = gn_stats != nullptr;
   if (gn) {
@@ -346,10 +356,12 @@ static int conv3x3_halo_entry(const fk_conv_args* args, const float* gn_stats, c
   p.up = up; p.silu = gn_silu; p.groups = gn ? gn_groups : 1;
   p.tiles_x = (a.Wout + TW - 1) / TW; p.tiles_y = (a.Hout + TH - 1) / TH; p.tiles_n = (a.Cout + BN - 1) / BN;
   p.ldw = (9 * a.Cin + 63) / 64 * 64;
+  p.f32io = f32io ? 1 : 0;
   FK_CHECK_ARG((int64_t)BN * p.ldw * 2 < (1ll << 31), "fk_conv3x3_halo_bf16: weight slice too large");
   hipStream_t stream = (hipStream_t)stream_;
   if (f32out) {
-    FK_CHECK_ARG(!a.res, "fk_conv3x3_halo_f32_debug: no residual in the parity build");
+    FK_CHECK_ARG(f32io || !a.res, "fk_conv3x3_halo_f32_debug: no residual in the parity build");
+    FK_CHECK_ARG(!f32io || (!gn && !up && a.Cout % 4 == 0), "fk_conv3x3_halo_f32out: no GroupNorm prologue, no upsample");
     return gn ? launch_halo<true, false, true>(p, stream) : launch_halo<false, false, true>(p, stream);
   }
   if (gn) return a.res ? launch_halo<true, true>(p, stream) : launch_halo<true, false>(p, stream);
@@ -364,4 +376,10 @@ extern "C" int fk_conv3x3_halo_bf16(const fk_conv_args* args, const float* gn_st
 extern "C" int fk_conv3x3_halo_f32_debug(const fk_conv_args* args, const float* gn_stats, const void* gn_gamma,
                                          const void* gn_beta, int32_t gn_groups, int32_t gn_silu, fk_stream_t stream_) {
   return conv3x3_halo_entry(args, gn_stats, gn_gamma, gn_beta, gn_groups, gn_silu, true, stream_);
+}
+
+// The halo kernel over the operand parts of the fp32-class encoder (vae_kernels.hip): args->x / w hold the bf16 parts side by
+// side along the channel axis (Cin = parts * C, a multiple of 64), args->bias / res / y are fp32.
+extern "C" int fk_conv3x3_halo_f32out(const fk_conv_args* args, fk_stream_t stream_) {
+  return conv3x3_halo_entry(args, nullptr, nullptr, nullptr, 0, 0, true, stream_, true);
 }

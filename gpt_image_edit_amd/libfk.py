@@ -117,6 +117,7 @@ SIGNATURES = {
     "fk_split_f32_rows": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "fk_groupnorm_f32_nhwc": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_f32, c_i32, c_i32, c_vp]),
     "fk_conv2d_nhwc_f32out": (c_i32, [c_vp, c_vp]),
+    "fk_conv3x3_halo_f32out": (c_i32, [c_vp, c_vp]),
     "fk_nchw_f32_to_nhwc_parts": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "fk_nhwc_f32_to_nchw": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp]),
     "fk_conv2d_nhwc_bf16": (c_i32, [ctypes.POINTER(ConvArgs), c_vp]),

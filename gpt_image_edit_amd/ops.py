@@ -387,9 +387,10 @@ def group_norm_f32_parts(x, gamma, beta, silu, parts, eps=1e-6):
     return out
 
 
-def conv2d_nhwc_f32out(x_parts, w_packed, bias, cout, ksize=3, stride=1, pad=1, res=None):
+def conv2d_nhwc_f32out(x_parts, w_packed, bias, cout, ksize=3, stride=1, pad=1, res=None, halo=False):
     """x_parts: [B,H,W,parts*C] bf16 operand parts; w_packed [cout, Kpad] bf16 over the same channel layout; bias / res /
-    result fp32."""
+    result fp32.  ``halo=True`` (3 x 3, stride 1, pad 1, parts*C % 64 == 0): the LDS halo-tiled kernel instead of the
+    implicit GEMM."""
     _need_cuda(x_parts, w_packed, bias, res)
     B, Hin, Win, Cin = x_parts.shape
     if stride == 1:
@@ -406,7 +407,10 @@ def conv2d_nhwc_f32out(x_parts, w_packed, bias, cout, ksize=3, stride=1, pad=1, 
     a.B, a.Hin, a.Win, a.Cin, a.Cout = B, Hin, Win, Cin, cout
     a.ksize, a.stride, a.pad, a.upsample2x = ksize, stride, pad, 0
     a.Hout, a.Wout = Hout, Wout
-    libfk.check(libfk.load().fk_conv2d_nhwc_f32out(ctypes.byref(a), _stream()), "fk_conv2d_nhwc_f32out")
+    if halo:
+        libfk.check(libfk.load().fk_conv3x3_halo_f32out(ctypes.byref(a), _stream()), "fk_conv3x3_halo_f32out")
+    else:
+        libfk.check(libfk.load().fk_conv2d_nhwc_f32out(ctypes.byref(a), _stream()), "fk_conv2d_nhwc_f32out")
     return out
 
 

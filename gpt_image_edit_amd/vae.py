@@ -252,7 +252,8 @@ class HipAutoencoderKL(ParamTreeMixin, nn.Module):
     def _conv32(self, name, x_parts, stride=1, pad=1, res=None):
         w, b, cout = self._packed_f32()[name]
         ks = self.p(name + ".weight").shape[-1]
-        return ops.conv2d_nhwc_f32out(x_parts, w, b, cout, ksize=ks, stride=stride, pad=pad if ks == 3 else 0, res=res)
+        halo = HALO and ks == 3 and stride == 1 and pad == 1 and x_parts.shape[-1] % 64 == 0 and cout >= 64
+        return ops.conv2d_nhwc_f32out(x_parts, w, b, cout, ksize=ks, stride=stride, pad=pad if ks == 3 else 0, res=res, halo=halo)
 
     def _gn32(self, name, x, silu):
         pk = self._packed_f32()

@@ -445,6 +445,9 @@ int fk_groupnorm_f32_nhwc(const float* x, void* y_parts, float* stats, float* ws
 /* Implicit-GEMM convolution (fk_conv2d_nhwc_bf16's kernel) over operand parts: args->x [B, Hin, Win, Cin] and args->w hold
  * the parts side by side along the channel axis (Cin = parts * C), args->bias / res / y are fp32. */
 int fk_conv2d_nhwc_f32out(const fk_conv_args* args, fk_stream_t stream);
+/* The same for the 3 x 3 / stride 1 / pad 1 convolutions with parts * C % 64 == 0 on the LDS halo-tiled kernel
+ * (fk_conv3x3_halo_bf16's main loop, fp32 epilogue): the operand parts are read once per channel chunk instead of nine times. */
+int fk_conv3x3_halo_f32out(const fk_conv_args* args, fk_stream_t stream);
 /* src NCHW fp32 -> NHWC bf16 parts [B, HW, parts * Cpad], every part zero padded to Cpad channels. */
 int fk_nchw_f32_to_nhwc_parts(const float* src, void* dst, int32_t B, int32_t C, int32_t Cpad, int32_t H, int32_t W,
                               int32_t parts, fk_stream_t stream);

@@ -269,7 +269,8 @@ def test_fp32_class_kernels():
         if P == 3:
             assert torch.equal(yp[..., 2 * C:], yp[..., :C])
     # convolution over parts: fp32 weights -> (hi, hi, lo), fp32 bias and residual
-    for (cin, cout, h, w, stride) in [(128, 256, 9, 7, 1), (3, 128, 10, 12, 1), (256, 256, 10, 8, 2), (512, 32, 6, 6, 1)]:
+    for (cin, cout, h, w, stride) in [(128, 256, 9, 7, 1), (3, 128, 10, 12, 1), (256, 256, 10, 8, 2), (512, 32, 6, 6, 1),
+                                      (128, 128, 33, 20, 1), (512, 512, 16, 16, 1)]:
         xa = torch.randn(B, cin, h, w, generator=g)
         wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
         bias = torch.randn(cout, generator=g) * 0.1
@@ -288,6 +289,15 @@ def test_fp32_class_kernels():
         torch.testing.assert_close(got, ref + res, rtol=1e-3, atol=1e-4)
         d = (got - ref - res).abs().max().item()
         assert d <= 3e-5 * ref.abs().max().item(), d          # ~2^-16 class, far below bf16's 2^-8
+        if stride == 1 and (3 * cpad) % 64 == 0 and cout >= 64:
+            # the same product on the LDS halo-tiled kernel (what the encoder's ResnetBlock2D convolutions run on)
+            for r_ in (res, None):
+                rd = r_.permute(0, 2, 3, 1).contiguous().cuda() if r_ is not None else None
+                got_h = ops.conv2d_nhwc_f32out(xp, wp, bias.cuda(), cout, res=rd, halo=True).permute(0, 3, 1, 2).cpu()
+                want = ref + res if r_ is not None else ref
+                report(f"fp32-class halo conv {cin}->{cout} res={r_ is not None}", got_h, want)
+                torch.testing.assert_close(got_h, want, rtol=1e-3, atol=1e-4)
+                assert (got_h - want).abs().max().item() <= 3e-5 * ref.abs().max().item()
     # softmax parts
     s = torch.randn(50, 200, generator=g) * 4
     pp = torch.zeros(50, 3 * 256, dtype=BF).cuda()
