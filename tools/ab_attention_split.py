@@ -15,7 +15,10 @@ from gpt_image_edit_amd import ops  # noqa: E402
 
 BF = torch.bfloat16
 H, D = 24, 3072
-for B, S in [(1, 2560), (1, 5632), (1, 8704), (2, 8704), (4, 8704), (1, 4608)]:
+SHAPES = [(1, 2560), (1, 5632), (1, 8704), (2, 8704), (4, 8704), (1, 4608)]
+if os.environ.get("AB_SHAPES"):          # e.g. AB_SHAPES=1x2560,4x8704
+    SHAPES = [tuple(int(v) for v in t.split("x")) for t in os.environ["AB_SHAPES"].split(",")]
+for B, S in SHAPES:
     g = torch.Generator(device="cuda").manual_seed(S + B)
     q = torch.randn(B, H, S, 128, device="cuda", generator=g).to(BF)
     k = torch.randn(B, H, S, 128, device="cuda", generator=g).to(BF)
