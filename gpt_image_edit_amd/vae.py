@@ -112,7 +112,11 @@ class HipAutoencoderKL(ParamTreeMixin, nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._pk = self._pk32 = None
-        return super()._apply(fn, *a, **k)
+        r = super()._apply(fn, *a, **k)
+        if self._f32_state is not None:      # follows the module's device; stays fp32 whatever dtype the move asked for
+            dev = self.device
+            self._f32_state = {n: v.to(dev) for n, v in self._f32_state.items()}
+        return r
 
     @property
     def dtype(self):

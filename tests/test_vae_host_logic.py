@@ -126,6 +126,15 @@ def test_load_vae_fp32_reads_the_checkpoint_in_fp32(tmp_path):
     assert vae._f32_state is None and vae._packed_f32()["parts"] == 2
 
 
+def test_fp32_state_follows_the_module():
+    vae, sd32 = _small_vae(True)
+    vae.to("cpu")                                    # a device move (here a no-op) keeps the fp32 values and drops the packed tables
+    assert vae._pk32 is None and vae._f32_state is not None
+    k = "encoder.conv_in.weight"
+    assert vae._f32_state[k].dtype == torch.float32 and torch.equal(vae._f32_state[k], sd32[k])
+    assert vae._packed_f32()["parts"] == 3
+
+
 def test_fp32_encode_refuses_cpu_tensors_and_nhwc_input():
     import pytest
     vae, _ = _small_vae(True)
