@@ -329,7 +329,8 @@ int fk_add3_bf16(const void* a, const void* b, const void* c, void* out, int64_t
  * (univa/utils/flux_pipeline.py:1095): out = bf16(neg + bf16(scale * bf16(pos - neg))) over n elements
  * (the python-float scale stays fp32, as on the GPU the reference runs on); out may alias pos or neg. */
 int fk_true_cfg_bf16(const void* pos, const void* neg, void* out, float scale, int64_t n, fk_stream_t stream);
-/* ---- optimisation step of the denoiser (reference train_denoiser.py:935-1181); the MMDiT backward is not built yet */
+/* ---- optimisation step of the denoiser (reference train_denoiser.py:935-1181): the HBM-bound pieces around the MMDiT forward /
+ * backward ("backward pass" section above) ---- */
 /* Doubles of workspace the two reductions below need. */
 int64_t fk_reduce_ws_doubles(void);
 /* noisy = (1 - sigma[b]) * x + sigma[b] * noise in fp32 (train_denoiser.py:994), rounded to bf16 and written as the
