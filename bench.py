@@ -92,8 +92,9 @@ def run_edit(pipe, inp, steps28=28):
                 output_type="pt_raw", max_area=inp["H"] * inp["W"], _auto_resize=False)
 
 
-def instrumented_edit(pipe, inp):
-    """Per-kernel-family HIP-event timing of one edit (events recorded on the launch stream).  For this pass the single
+def instrumented_edit(pipe, inp, steps28=28):
+    """Per-kernel-family HIP-event timing of one edit of `steps28` denoise steps (events recorded on the launch stream; the
+    per-launch rates do not depend on the step count, so the B = 32 pass runs 4 steps instead of 28).  For this pass the single
     blocks' MLP-up GEMM, which the timed edits run on a second stream beside the QKV GEMM and the attention
     (transformer.OVERLAP_MLP), is kept on the launch stream: a launch's duration can only be bracketed -- and priced
     against the roofline -- when nothing else shares the chip with it."""
@@ -149,14 +150,14 @@ def instrumented_edit(pipe, inp):
         wrap(ops.attention, "attention", attn_flops, attn_bytes), wrap(ops.conv2d_nhwc, "conv", conv_flops, conv_bytes),
         wrap(ops.conv3x3_halo, "conv", halo_flops, conv_bytes))
     try:
-        run_edit(pipe, inp)
+        run_edit(pipe, inp, steps28)
         torch.cuda.synchronize()
     finally:
         ops.gemm, ops.gemm_grouped, ops.attention, ops.conv2d_nhwc, ops.conv3x3_halo = orig
         transformer.OVERLAP_MLP = overlap
         transformer.BLOCK_API = block_api
         pipe.use_graph = use_graph
-    if len(rec["attention"]) < 57 or len(rec["gemm"]) < 4 * 57:
+    if len(rec["attention"]) < 57 * steps28 or len(rec["gemm"]) < 4 * 57 * steps28:
         raise RuntimeError(f"instrumented edit bracketed {len(rec['attention'])} attention / {len(rec['gemm'])} GEMM launches: "
                            "the blocks' kernels were not enqueued one host call per launch")
     out = {}
@@ -183,25 +184,21 @@ def roofline_of(fam, workload):
         except Exception as e:  # a malformed side file must not cost the bench line
             traffic_note = f"unreadable {TRAFFIC_FILE}: {e}"
     rl = {
-        "kernel": "gemm8_kernel<*> + gemm_mix_kernel<*> + gemm9_kernel<*> + gemm_bf16_kernel<*> (bf16 MFMA GEMM family: all MMDiT / VAE linears)",
+        "kernel": "bf16 MFMA GEMM family (gemm8 / gemm9 / gemm10 / gemm_mix / gemm_bf16 kernels: every MMDiT and VAE linear)",
         "bound": "mfma", "achieved": gm["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": gm["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
         "launches_per_edit": gm["launches"], "ms_per_edit": gm["ms"], "algorithmic_tflop_per_edit": gm["flops"] / 1e12,
         # the other MFMA kernels of the path: rate against the MFMA peak AND achieved HBM GB/s on their algorithmic bytes
-        # (north star: "achieved HBM GB/s on the attention / VAE kernels"): both are far from bandwidth-bound by design
-        "other_kernels": {k: {"ms_per_edit": v["ms"], "tflops": v["tflops"], "launches": v["launches"],
-                              "frac_of_mfma_peak": v["tflops"] / PEAK_BF16_TFLOPS,
-                              "algorithmic_gb_per_edit": v["algorithmic_bytes"] / 1e9, "hbm_gbps_algorithmic": v["gbps"],
-                              "frac_of_hbm_peak": v["gbps"] / PEAK_HBM_GBPS}
+        "other_kernels": {k: {"ms_per_edit": round(v["ms"], 3), "tflops": round(v["tflops"], 1), "launches": v["launches"],
+                              "frac_of_mfma_peak": round(v["tflops"] / PEAK_BF16_TFLOPS, 4),
+                              "hbm_gbps_algorithmic": round(v["gbps"], 1), "frac_of_hbm_peak": round(v["gbps"] / PEAK_HBM_GBPS, 4)}
                           for k, v in fam.items() if k != "gemm"},
-        "traffic_source": ("committed PMC passes (" + os.path.relpath(TRAFFIC_FILE, ROOT) + ", tools/pmc_traffic.sh: FETCH_SIZE / WRITE_SIZE in "
-                           "their own rocprofv3 passes, calibrated on a 1 GiB copy), per launch of the largest launch class; NOT counted in this run"),
+        "traffic_source": os.path.relpath(TRAFFIC_FILE, ROOT) + " (committed PMC passes, largest launch class; not counted in this run)",
     }
     if traffic_note:
         rl["traffic_note"] = traffic_note
     if traffic_classes:   # counted bytes beyond the XCD L2s per launch of EVERY GEMM launch class of the workload
-        rl["traffic_by_launch_class"] = {k: {"bytes": v["hbm_bytes_per_launch"], "x_algorithmic": v["ratio"], "l2_hit": v["l2_hit"]}
-                                         for k, v in traffic_classes.items()}
+        rl["traffic_x_algorithmic"] = {k: v["ratio"] for k, v in traffic_classes.items()}
     return rl
 
 
@@ -310,19 +307,16 @@ def cpu_baseline(workload, mode="full"):
     flops_step = mmdit.flops_forward(S_txt + S_img)
     if n_steps == 4:   # BASELINE.json configs[0] as defined: all four steps executed
         t4 = t_enc + sum(t_steps) + t_dec
-        what = (f"cfg 1 AS DEFINED: all 4 denoise steps executed ({', '.join(f'{t:.1f}' for t in t_steps)} s) + VAE encode {t_enc:.1f}s + "
-                f"VAE decode {t_dec:.1f}s = {t4:.0f}s per image; `value` = 1 / (enc + 28 x mean step + dec) = 1 / {t28:.0f}s is the 28-step extrapolation")
+        what = (f"cfg 1 as defined: 4 denoise steps executed ({', '.join(f'{t:.1f}' for t in t_steps)} s) + VAE encode {t_enc:.1f}s + decode "
+                f"{t_dec:.1f}s = {t4:.0f}s per image; `value` = 28-step EXTRAPOLATION 1 / (enc + 28 x mean step + dec) = 1 / {t28:.0f}s")
     else:
-        what = (f"ONE full-depth denoise step (embedders + 19 double + 38 single blocks + head) {t_step:.1f}s + VAE encode {t_enc:.1f}s + "
-                f"VAE decode {t_dec:.1f}s executed; steps 2-4 of cfg 1 and steps 2-28 of cfg 2 NOT executed: `value` = 1 / (enc + 28 x step + dec) "
-                f"= 1 / {t28:.0f}s and cfg 1 = 1 / {t4:.0f}s are EXTRAPOLATIONS of that one step (all four executed: `--cpu-baseline cfg1`, "
-                f"profiles/r03_cpu_baseline_cfg1.json)")
+        what = (f"ONE full-depth denoise step {t_step:.1f}s + VAE encode {t_enc:.1f}s + decode {t_dec:.1f}s executed; cfg 1 (1 / {t4:.0f}s) and "
+                f"`value` (28 steps, 1 / {t28:.0f}s) are EXTRAPOLATIONS of that step")
     return dict(common, value=1.0 / t28, cfg1_4step_images_per_s=1.0 / t4, steps_executed=n_steps,
-                steps_not_executed=[] if n_steps == 4 else [2, 3, 4],
-                t_step_s=t_step, t_steps_s=t_steps, t_vae_encode_s=t_enc, t_vae_decode_s=t_dec, gflops_step=flops_step / t_step / 1e9,
-                block_time_shared_vs_distinct_weights=weights_note,
-                sample=f"fp32 oracle through the cli-equivalent plumbing at S={S_txt + S_img} (B=1): {what}; 18 + 37 of the blocks "
-                       f"share one seeded weight set, block 9 / 19 of each kind has its own (timed apart: `block_time_shared_vs_distinct_weights`)")
+                steps_not_executed=[] if n_steps == 4 else [2, 3, 4], torch_num_threads=torch.get_num_threads(),
+                t_step_s=t_step, t_steps_s=[round(t, 2) for t in t_steps], t_vae_encode_s=t_enc, t_vae_decode_s=t_dec,
+                gflops_step=flops_step / t_step / 1e9, block_time_shared_vs_distinct_weights=weights_note,
+                sample=f"fp32 oracle (oracle/, CPU restatement) at S={S_txt + S_img}, B=1: {what}")
 
 
 def prompt_encode_time(device, batch=1):
@@ -392,17 +386,13 @@ def train_step_bench(device, steps=3, warmup=2, world=1, e2e=True):
             "loss": float(out["loss"].item()), "trainable_params": n_train, "seq_len": S,
             "peak_memory_gb": torch.cuda.max_memory_allocated(device) / 1e9, "host_enqueue_ms_per_step": t_host * 1e3,
             "host_work_ms_per_step": t_cpu * 1e3,
-            "host_work_note": "CPU time of the enqueueing thread per step (time.thread_time): upper bound on the pure host work of enqueueing a step; "
-                              "`host_enqueue_ms_per_step` is the WALL time of the enqueue loop, which also waits on the full launch queue",
             "T_step_e2e": e2e_res,
             "zero2_buckets": len(ts.opt.layout.buckets),
             "forward_tflop": fwd / 1e12,
             "model_tflops_3x_forward": 3 * fwd / dt / 1e12,
             "frac_of_mfma_peak_3x_forward": 3 * fwd / dt / 1e12 / PEAK_BF16_TFLOPS,
-            "what": "train_denoiser.py stage-2 step: denoise_projector on the VLM states, noisy tokens, MMDiT forward, flow-matching "
-                    "loss + gradient, backward (adjoints; weight gradients for the un-frozen subset + the projector), "
-                    "global-norm clip + AdamW (ZeRO-2 layout); `model_tflops_3x_forward` prices the step at the conventional "
-                    "3 x forward FLOPs (the 7-product attention backward is not credited beyond that)"}
+            "what": "train_denoiser.py:829-1181 stage-2 step (projector, noisy tokens, MMDiT fwd, flow loss + grad, bwd, clip + AdamW on the ZeRO-2 layout); "
+                    "host_work = thread CPU time of the enqueue loop (upper bound), host_enqueue = its wall time"}
 
 
 def train_step_e2e(device, ts, batch, L_vlm, steps=3):
@@ -455,15 +445,15 @@ def train_step_e2e(device, ts, batch, L_vlm, steps=3):
     return {"ms_per_step": dt * 1e3, "samples_per_s": B / dt, "steps": steps,
             "last_step_ms": {"vae_encode_x2": ev[0].elapsed_time(ev[1]), "vlm_forward": ev[1].elapsed_time(ev[2]),
                              "core_step": ev[2].elapsed_time(ev[3])},
-            "vae_encode": "fp32-class (fp32 activations and checkpoint, products as [a_hi|a_lo|a_hi].[w_hi|w_hi|w_lo] on the bf16 "
-                          "MFMA, fp32 accumulation; held to the fp32 oracle at rtol 1e-3 / atol 1e-4)",
+            "vae_encode": "fp32-class encoder (vae_fp32: true), split-bf16 products",
             "vae_encode_x2_bf16_ms": e0.elapsed_time(e1),
             "peak_memory_gb": torch.cuda.max_memory_allocated(device) / 1e9,
-            "caveats": "Qwen2.5-VL-7B random init, stock transformers model reused as-is on PyTorch-ROCm, one 448^2 image + 44 text "
-                       "tokens, first 256 hidden states used; T5 prefix embeddings given"}
+            "caveats": "random-init Qwen2.5-VL-7B (stock transformers), 448^2 image + 44 text tokens; T5 prefix given"}
 
 
 def timed_edits(pipe, inp, steps, warmup, world, device, backend):
+    """The contract's timed region (barrier + synchronize either side of EXACTLY `steps` edits, wall clock, MAX over ranks)
+    and, beside it, every step's duration from HIP events on the launch stream (median of >= 3)."""
     from gpt_image_edit_amd import dp
 
     def one_step():
@@ -477,20 +467,39 @@ def timed_edits(pipe, inp, steps, warmup, world, device, backend):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    st = torch.cuda.current_stream()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
+        ev[i].record(st)
         out = one_step()
+    ev[steps].record(st)
     timed_edits.host_enqueue_s = (time.perf_counter() - t0) / steps   # the host is done enqueueing; the GPU may still be working
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    timed_edits.hip_event_ms = {"median": per_step[len(per_step) // 2], "min": per_step[0], "max": per_step[-1],
+                                "mean": sum(per_step) / len(per_step), "n": steps}
     if world > 1:
         tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(out.images.float()).all(), "non-finite output image"
     return elapsed
+
+
+def workload_summary(value, ms_per_step, rl=None, **more):
+    """One entry of `roofline.workloads`: the driver's parsed record keeps `roofline` whole, so every workload's headline
+    numbers (throughput, GEMM-family and attention rates against the MFMA peak) ride inside it."""
+    d = {"value": round(value, 5), "ms_per_step": round(ms_per_step, 2)}
+    if rl:
+        att = rl.get("other_kernels", {}).get("attention", {})
+        d.update(gemm_tflops=round(rl["achieved"], 1), gemm_frac=round(rl["frac"], 4),
+                 attention_tflops=att.get("tflops"), attention_frac=att.get("frac_of_mfma_peak"))
+    d.update(more)
+    return d
 
 
 def main():
@@ -502,8 +511,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the workload's batch per GPU; strong: --global-batch fixed, sharded items[rank::world]")
     ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: total edits per step (default 8 x batch)")
-    ap.add_argument("--cpu-baseline", default="full", choices=["full", "cfg1", "blocks", "none"],
-                    help="full: one full-depth CPU step + VAE (default); cfg1: all four steps of BASELINE.json configs[0]")
+    ap.add_argument("--cpu-baseline", default="cfg1", choices=["full", "cfg1", "blocks", "none"],
+                    help="cfg1 (default): BASELINE.json configs[0] as defined, all four steps executed (~4 min of host time); "
+                         "full: one full-depth CPU step + VAE; blocks: 1 + 1 blocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extras (1024^2 edit, cfg 3 batch, prompt encode, cfg 5 train step)")
@@ -554,15 +564,18 @@ def main():
                    "height": inp["H"], "width": inp["W"], "S_txt": inp["S_txt"], "S_tgt": inp["S_tgt"],
                    "S_cond": inp["S_cond"], "seq_len": S, "num_inference_steps": 28, "guidance_scale": 3.5,
                    "blocks": "19 double + 38 single", "parallelism": f"dp{world}"},
-        "host": {"enqueue_ms_per_step": timed_edits.host_enqueue_s * 1e3, "denoise_loop_as_hipgraph": bool(pipe.use_graph),
-                 "note": "wall time the host needs to enqueue one edit (it runs ahead of the GPU unless the launch queue is full); "
-                         "FK_GRAPH=1 replaces the ~5 400 launches of the denoise loop by one graph launch"},
+        "ms_per_step_hip_events": timed_edits.hip_event_ms,
+        "host": {"enqueue_ms_per_step": timed_edits.host_enqueue_s * 1e3, "denoise_loop_as_hipgraph": bool(pipe.use_graph)},
         "dist": {"world_size": dist.get_world_size() if world > 1 else 1,
                  "backend": (dist.get_backend() + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else "none (single process)",
                  "collective": "one all_gather_into_tensor of the packed final latents per step" if world > 1 else None},
     }
+    summaries = {}
     if rank == 0 and not args.no_roofline:
-        result["roofline"] = roofline_of(instrumented_edit(pipe, inp), args.workload)
+        i_steps = 28 if batch <= 4 else 4          # a B = 32 pass brackets 4 denoise steps (same launches, same rates)
+        result["roofline"] = roofline_of(instrumented_edit(pipe, inp, i_steps), args.workload)
+        result["roofline"]["instrumented_denoise_steps"] = i_steps
+        summaries[args.workload] = workload_summary(result["value"], result["ms_per_step"], result["roofline"], unit="images/s")
 
     # ---- the 1024^2 half of BASELINE.json's metric, in the same run (every rank: weak scaling at 1024^2) ------------
     extra = {}
@@ -574,20 +587,29 @@ def main():
               "ms_per_step": el2 / k2 * 1e3, "scaling": "weak",
               "config": {"workload": EXTRA_WORKLOAD, "batch_per_gpu": 1, "height": 1024, "width": 1024,
                          "seq_len": inp2["S_txt"] + inp2["S_tgt"] + inp2["S_cond"], "num_inference_steps": 28}}
+        ex["ms_per_step_hip_events"] = timed_edits.hip_event_ms
         if rank == 0 and not args.no_roofline:
             ex["roofline"] = roofline_of(instrumented_edit(pipe, inp2), EXTRA_WORKLOAD)
+            summaries[EXTRA_WORKLOAD] = workload_summary(ex["value"], ex["ms_per_step"], ex["roofline"], unit="images/s")
         extra[EXTRA_WORKLOAD] = ex
         del inp2
     if rank == 0 and world == 1 and not args.no_extra and WORKLOADS[args.workload][0] == 1 and os.environ.get("FK_BENCH_CFG3", "1") != "0":
         # BASELINE.json configs[2] (B = 32 at 1024^2: one GPU's share of the reference's batch runs) in the same run: ONE timed
-        # batch, no warm-up batch of that shape (a batch takes ~2 min; its first-call allocations are < 1 % of it)
+        # batch, no warm-up batch of that shape (a batch takes ~2 min; its first-call allocations are < 1 % of it), then a
+        # 4-step instrumented pass of the same batch for its roofline (per-launch HIP events; M = 278 528 rows per GEMM)
         try:
             inp3 = make_inputs(CFG3_WORKLOAD, device, seed=242)
             el3 = timed_edits(pipe, inp3, 1, 0, 1, device, backend)
-            extra[CFG3_WORKLOAD] = {"value": 32 / el3, "unit": "images/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": el3 * 1e3,
-                                    "config": {"workload": CFG3_WORKLOAD, "batch_per_gpu": 32, "height": 1024, "width": 1024,
-                                               "seq_len": inp3["S_txt"] + inp3["S_tgt"] + inp3["S_cond"], "num_inference_steps": 28},
-                                    "peak_memory_gb": torch.cuda.max_memory_allocated(device) / 1e9}
+            ex3 = {"value": 32 / el3, "unit": "images/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": el3 * 1e3,
+                   "config": {"workload": CFG3_WORKLOAD, "batch_per_gpu": 32, "height": 1024, "width": 1024,
+                              "seq_len": inp3["S_txt"] + inp3["S_tgt"] + inp3["S_cond"], "num_inference_steps": 28},
+                   "peak_memory_gb": torch.cuda.max_memory_allocated(device) / 1e9}
+            if not args.no_roofline:
+                ex3["roofline"] = roofline_of(instrumented_edit(pipe, inp3, 4), CFG3_WORKLOAD)
+                ex3["roofline"]["instrumented_denoise_steps"] = 4
+                summaries[CFG3_WORKLOAD] = workload_summary(ex3["value"], ex3["ms_per_step"], ex3["roofline"], unit="images/s",
+                                                            instrumented_denoise_steps=4)
+            extra[CFG3_WORKLOAD] = ex3
             del inp3
         except Exception as e:
             extra[CFG3_WORKLOAD] = {"error": f"{type(e).__name__}: {e}"}
@@ -605,12 +627,18 @@ def main():
             extra["prompt_encode"] = {"error": f"{type(e).__name__}: {e}"}
         try:
             torch.cuda.empty_cache()
-            extra["cfg5_train_step_1024x1024_bs1"] = train_step_bench(device)
+            t5 = extra["cfg5_train_step_1024x1024_bs1"] = train_step_bench(device)
+            summaries["cfg5_train_step_1024x1024_bs1"] = workload_summary(
+                t5["value"], t5["ms_per_step"], unit="samples/s", frac_of_mfma_peak_3x_forward=round(t5["frac_of_mfma_peak_3x_forward"], 4),
+                host_work_ms_per_step=round(t5["host_work_ms_per_step"], 1),
+                T_step_e2e_ms=(t5.get("T_step_e2e") or {}).get("ms_per_step"))
             torch.cuda.empty_cache()
         except Exception as e:
             extra["cfg5_train_step_1024x1024_bs1"] = {"error": f"{type(e).__name__}: {e}"}
     if extra:
         result["extra"] = extra
+    if "roofline" in result and summaries:
+        result["roofline"]["workloads"] = summaries
     if rank == 0 and world == 1 and args.cpu_baseline != "none":
         result["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_baseline)
     if rank == 0:

@@ -171,6 +171,31 @@ FK_DEV void select_tile(const GroupArgs& ga, int t, int& pi, int& m0, int& n0) {
   tile_of<BN>(ga, ga.tiles_before, t, (ga.p[0].N + BN - 1) / BN, 0, pi, m0, n0);
 }
 
+// ---- MFMA shape ------------------------------------------------------------------------------------------------------
+// M16 = false: v_mfma_f32_32x32x16_bf16 (8 passes, 16 k per instruction); M16 = true: v_mfma_f32_16x16x32_bf16 (4 passes, 32 k
+// per instruction) on the SAME LDS image, the same accumulator registers and the same number of ds_read_b128 per K-tile.
+// Why both exist (tools/power_probe.hip, profiles/r05_power_probe.txt): under the chip's power limit a pure MFMA stream of
+// the 16 x 16 x 32 form sustains 2 017 TF/s at 1.97 GHz against 1 800 TF/s at 1.76 GHz for the 32 x 32 x 16 form -- half the
+// accumulator register traffic per flop -- and the GEMM main loops are power-bound.  A 32 x 32 accumulator block (nf, mf) of
+// the epilogue holds, as quad q = 2 * n16 + m16 (4 registers = 4 consecutive output columns of one row), the 16 x 16 block
+// (n16, m16) in the M16 form and columns 8 q + 4 (lane >> 5) of row (lane & 31) in the other.
+template <bool M16>
+struct FragMap {
+  static FK_DEV int row(int lane, int q) { return M16 ? (q & 1) * 16 + (lane & 15) : (lane & 31); }
+  static FK_DEV int col(int lane, int q) { return M16 ? (q >> 1) * 16 + (lane >> 4) * 4 : 8 * q + 4 * (lane >> 5); }
+};
+FK_DEV f32x4_t quad_get(const f32x16_t& v, int q) { return f32x4_t{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; }
+FK_DEV void quad_set(f32x16_t& v, int q, const f32x4_t& c) {
+  v[4 * q] = c[0]; v[4 * q + 1] = c[1]; v[4 * q + 2] = c[2]; v[4 * q + 3] = c[3];
+}
+// one 32 (n) x 32 (m) x 32 (k) step on a 32 x 32 accumulator block as four 16 x 16 x 32 MFMAs: w16[n16], a16[m16]
+FK_DEV void mma16_block(f32x16_t& blk, const bf16x8_t& w0, const bf16x8_t& w1, const bf16x8_t& a0, const bf16x8_t& a1) {
+  quad_set(blk, 0, __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, a0, quad_get(blk, 0), 0, 0, 0));
+  quad_set(blk, 2, __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, a0, quad_get(blk, 2), 0, 0, 0));
+  quad_set(blk, 1, __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, a1, quad_get(blk, 1), 0, 0, 0));
+  quad_set(blk, 3, __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, a1, quad_get(blk, 3), 0, 0, 0));
+}
+
 // epilogue (as gemm_bf16.hip): bias/activation -> bf16 -> LDS tile -> coalesced 16-byte rows.
 // acc[nf][mf] is the 32x32 block (n-block nf, m-block mf) of wave (wm, wn) in MFMA-output layout with the
 // swapped operands: lane l holds row (l & 31) of the m-block, columns 8*q + 4*(l >> 5) + j of the n-block.
@@ -185,7 +210,7 @@ FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& 
                        int wm, int wn) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int frow = lane & 31, fhalf = lane >> 5;
+  using FM = FragMap<C::M16>;
   // bias of this lane's 4-column quads (all loads in flight before the barrier below)
   u32x2_t bw[C::NF][4];
 #pragma unroll
@@ -198,7 +223,7 @@ FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& 
       for (int nf = 0; nf < C::NF; ++nf)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n = n0 + C::tile_col(wn, nf) + 8 * q + 4 * fhalf;
+          const int n = n0 + C::tile_col(wn, nf) + FM::col(lane, q);
           bw[nf][q] = *(const u32x2_t*)((const bf16_t*)p.bias + min(n, p.N - 4));   // columns >= N are never stored
         }
     }
@@ -209,11 +234,11 @@ FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& 
     for (int nf = 0; nf < C::NF; ++nf)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n = n0 + C::tile_col(wn, nf) + 8 * q + 4 * fhalf;
+        const int n = n0 + C::tile_col(wn, nf) + FM::col(lane, q);
         const float b[4] = {bf_lo(bw[nf][q][0]), bf_hi(bw[nf][q][0]), bf_lo(bw[nf][q][1]), bf_hi(bw[nf][q][1])};
 #pragma unroll
         for (int mf = 0; mf < C::MF; ++mf) {
-          const int m = m0 + C::tile_row(wm, mf) + frow;
+          const int m = m0 + C::tile_row(wm, mf) + FM::row(lane, q);
           if (m < p.M && n < p.N)
             *(f32x4_t*)((float*)p.C + fk_row_offset(p.c, m) + n) =
                 f32x4_t{acc[nf][mf][4 * q + 0] + b[0], acc[nf][mf][4 * q + 1] + b[1], acc[nf][mf][4 * q + 2] + b[2],
@@ -228,7 +253,7 @@ FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& 
   for (int nf = 0; nf < C::NF; ++nf) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int nl = C::tile_col(wn, nf) + 8 * q + 4 * fhalf;
+      const int nl = C::tile_col(wn, nf) + FM::col(lane, q);
       const float b[4] = {bf_lo(bw[nf][q][0]), bf_hi(bw[nf][q][0]), bf_lo(bw[nf][q][1]), bf_hi(bw[nf][q][1])};
 #pragma unroll
       for (int mf = 0; mf < C::MF; ++mf) {
@@ -249,7 +274,7 @@ FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& 
         u32x2_t pk;
         pk[0] = pack_bf2(v[0], v[1]);
         pk[1] = pack_bf2(v[2], v[3]);
-        const int ml = C::tile_row(wm, mf) + frow;
+        const int ml = C::tile_row(wm, mf) + FM::row(lane, q);
         *(u32x2_t*)(ct + ml * C::CT_LD + nl) = pk;
       }
     }
@@ -395,9 +420,10 @@ FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& 
 // and the wait that retires it (vmcnt(10): five younger half-tiles may stay in flight) sits one phase before the
 // read, with a barrier in between; a slot is re-requested no earlier than two phases after its last read.  All eight
 // LDS slots are therefore always in use: 5 phases (~1.3 k cycles) of latency cover per request out of 128 KiB.
-template <int BN>
+template <int BN, bool M16_ = false>
 struct Cfg8 {
   static_assert(BN == 256, "the ping-pong kernel is instantiated for the 256 x 256 tile only");
+  static constexpr bool M16 = M16_;
   static constexpr int NTHREADS = 512;
   static constexpr int BK = 64, ROW_BYTES = 128;
   static constexpr int WAVES_M = 2, WAVES_N = 4;
@@ -425,10 +451,11 @@ struct Cfg8 {
 // block b ^ (r & 3)) and its MFMA fragments come through ds_read_b64_tr_b16 -- two reads of rows 8 hh + tj and + 4, which
 // deliver k = 8 hh + 0..7 in the slot order of the ds_read_b128 path, so a K-major operand multiplies a row-major one and
 // the sums are those of the LAY 0 kernel on transposed copies bit for bit (attention_fwd.hip's V^T operand is the recipe).
-template <int EPI, int BN, int LAY = 0>
+template <int EPI, int BN, int LAY = 0, bool M16 = false>
 FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, int kt_first, int nk, int sk_slot) {
-  using C = Cfg8<BN>;
+  using C = Cfg8<BN, M16>;
   constexpr bool AT = LAY == 2, WT = LAY >= 1;
+  static_assert(!(M16 && LAY != 0), "the K-major operand paths deliver 32 x 32 x 16 fragments");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -478,11 +505,18 @@ FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, 
   };
 
   // ---- MFMA operand addressing -----------------------------------------------------------------------------------
-  const int frow = lane & 31, fhalf = lane >> 5, fsw = C::swz(frow);
-  int koffs[4];
+  // 32 x 32 x 16: lane -> row (lane & 31), k-octet (lane >> 5) of each of the K-tile's 4 k-steps; 16 x 16 x 32: row (lane & 15),
+  // k-octet (lane >> 4) of each of its 2 k-steps.  Either way one ds_read_b128 per fragment, 8 + 4 per phase, the same
+  // swizzle (the XOR only depends on (row >> 1) & 7, which a 16-row sub-block offset does not change).
+  constexpr int NKS = M16 ? 2 : 4;          // k-steps per K-tile
+  constexpr int ASUB = M16 ? 4 : 2;         // fragments per k-step over the wave's 64 A rows
+  constexpr int WSUB = M16 ? 2 : 1;         // ... over its 32 W rows
+  constexpr int SUB_BYTES = (M16 ? 16 : 32) * C::ROW_BYTES;
+  const int frow = M16 ? (lane & 15) : (lane & 31), fhalf = M16 ? (lane >> 4) : (lane >> 5), fsw = C::swz(frow);
+  int koffs[NKS];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) koffs[kk] = ((kk * 2 + fhalf) ^ fsw) << 4;
-  const int a_rd = (wm * 64 + frow) * C::ROW_BYTES;   // + sub * 4096 inside half-tile A_i
+  for (int kk = 0; kk < NKS; ++kk) koffs[kk] = ((kk * (M16 ? 4 : 2) + fhalf) ^ fsw) << 4;
+  const int a_rd = (wm * 64 + frow) * C::ROW_BYTES;   // + sub * SUB_BYTES inside half-tile A_i
   const int w_rd = (wn * 32 + frow) * C::ROW_BYTES;   // inside half-tile W_j
 
   f32x16_t acc[C::NF][C::MF];
@@ -493,10 +527,10 @@ FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  bf16x8_t af[2][4], wf[2][4];   // A half in use [sub][kk]; W halves [j][kk]
+  bf16x8_t af[ASUB][NKS], wf[2][WSUB][NKS];   // A half in use [sub][kk]; W halves [j][sub][kk]
   // K-major half-tile: fragment (k-step kk, 32-column block df) through two transpose reads
   const int tj = (lane & 15) >> 2;
-  const int t_lo = (8 * fhalf + tj) * 256 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+  const int t_lo = (8 * (lane >> 5) + tj) * 256 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
   auto trfrag = [&](const char* half, int kk, int df) {
     const char* vp = half + kk * 4096 + ((df ^ tj) << 6) + t_lo;
     const s16x4_t lo = lds_tr16(vp);
@@ -509,28 +543,32 @@ FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, 
   auto read_a = [&](int buf, int h) {
     const char* b = smem + buf * C::BUF_BYTES + h * C::HALF_BYTES;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+    for (int sub = 0; sub < ASUB; ++sub)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
+      for (int kk = 0; kk < NKS; ++kk) {
         if constexpr (AT) af[sub][kk] = trfrag(b, kk, wm * 2 + sub);
-        else af[sub][kk] = *(const bf16x8_t*)(b + a_rd + sub * 4096 + koffs[kk]);
+        else af[sub][kk] = *(const bf16x8_t*)(b + a_rd + sub * SUB_BYTES + koffs[kk]);
       }
   };
   auto read_w = [&](int buf, int j) {
     const char* b = smem + buf * C::BUF_BYTES + (2 + j) * C::HALF_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      if constexpr (WT) wf[j][kk] = trfrag(b, kk, wn);
-      else wf[j][kk] = *(const bf16x8_t*)(b + w_rd + koffs[kk]);
-    }
+    for (int sub = 0; sub < WSUB; ++sub)
+#pragma unroll
+      for (int kk = 0; kk < NKS; ++kk) {
+        if constexpr (WT) wf[j][sub][kk] = trfrag(b, kk, wn);
+        else wf[j][sub][kk] = *(const bf16x8_t*)(b + w_rd + sub * SUB_BYTES + koffs[kk]);
+      }
   };
-  // quadrant (i, j): 2 m-blocks x 1 n-block x 4 k-steps, accumulators alternating
+  // quadrant (i, j): 2 m-blocks x 1 n-block x the K-tile, accumulators alternating (8 MFMAs of 32 x 32 x 16 or 16 of 16 x 16 x 32)
   auto mma = [&](int i, int j) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+    for (int kk = 0; kk < NKS; ++kk)
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-        acc[j][2 * i + sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][kk], af[sub][kk], acc[j][2 * i + sub], 0, 0, 0);
+      for (int sub = 0; sub < 2; ++sub) {
+        if constexpr (M16) mma16_block(acc[j][2 * i + sub], wf[j][0][kk], wf[j][1][kk], af[2 * sub][kk], af[2 * sub + 1][kk]);
+        else acc[j][2 * i + sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][0][kk], af[sub][kk], acc[j][2 * i + sub], 0, 0, 0);
+      }
   };
   auto phase_sync_mma = [&](int i, int j) {
     wait_vmcnt<10>();
@@ -644,7 +682,7 @@ FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, 
   store_tile<EPI, BN, C>(acc, p, smem, m0, n0, wm, wn);
 }
 
-template <int EPI, int BN, bool SPLITK, int LAY = 0>
+template <int EPI, int BN, bool SPLITK, int LAY = 0, bool M16 = false>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int pi, m0, n0;
@@ -652,10 +690,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
   const int nk_all = ga.p[0].K / Cfg8<BN>::BK;
   if constexpr (SPLITK) {
     select_tile<BN>(ga, t >> 1, pi, m0, n0);
-    gemm8_body<EPI, BN, LAY>(ga, smem, pi, m0, n0, (t & 1) * (nk_all >> 1), nk_all >> 1, t >> 1);
+    gemm8_body<EPI, BN, LAY, M16>(ga, smem, pi, m0, n0, (t & 1) * (nk_all >> 1), nk_all >> 1, t >> 1);
   } else {
     select_tile<BN>(ga, t, pi, m0, n0);
-    gemm8_body<EPI, BN, LAY>(ga, smem, pi, m0, n0, 0, nk_all, -1);
+    gemm8_body<EPI, BN, LAY, M16>(ga, smem, pi, m0, n0, 0, nk_all, -1);
   }
 }
 
@@ -668,7 +706,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
 // tile, device-scope fences, partials re-read in K order) was 2x slower; this one moves one 256 KiB partial per CU and launch.
 // The range is walked from its end: the head part of its last tile first (the part that publishes), the tail part of its
 // first tile last (the part that merges) -- whoever merges finds the partial already there.
-template <int EPI, int BN>
+template <int EPI, int BN, bool M16 = false>
 __global__ __launch_bounds__(512, 2) void gemm8_streamk_kernel(const GroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int pos = xcd_chunk_index();
@@ -690,7 +728,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_streamk_kernel(const GroupArgs g
     int pi, m0, n0;
     select_tile<BN>(ga, t, pi, m0, n0);
     const bool part = k0 > 0 || k1 < (int)nk;
-    gemm8_body<EPI, BN, 0>(ga, smem, pi, m0, n0, k0, k1 - k0, part ? (k1 < (int)nk ? pos + 1 : pos) : -1);
+    gemm8_body<EPI, BN, 0, M16>(ga, smem, pi, m0, n0, k0, k1 - k0, part ? (k1 < (int)nk ? pos + 1 : pos) : -1);
     __syncthreads();   // every wave is done with the C tile / the ticket word before the next pass refills the ring
   }
 }
@@ -706,20 +744,20 @@ int count_tiles(GroupArgs& ga, const fk_gemm_args* probs, int n) {
   return total;
 }
 
-template <int EPI, int BN, bool SPLITK, int LAY = 0>
+template <int EPI, int BN, bool SPLITK, int LAY = 0, bool M16 = false>
 int launch8(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) {
   const int total = count_tiles<BN>(ga, probs, n);
-  auto kern = gemm8_kernel<EPI, BN, SPLITK, LAY>;
+  auto kern = gemm8_kernel<EPI, BN, SPLITK, LAY, M16>;
   FK_ENSURE_MAX_LDS(kern, Cfg8<BN>::SMEM_BYTES, "fk_gemm_bf16 (256 x 256 tile, 8 waves ping-pong)");
   hipLaunchKernelGGL(kern, dim3(SPLITK ? 2 * total : total), dim3(512), Cfg8<BN>::SMEM_BYTES, stream, ga);
   FK_CHECK_LAUNCH("fk_gemm_bf16 (256 x 256 tile, 8 waves ping-pong)");
   return FK_OK;
 }
 
-template <int EPI, int BN>
+template <int EPI, int BN, bool M16 = false>
 int launch8_streamk(GroupArgs& ga, const fk_gemm_args* probs, int n, int grid, hipStream_t stream) {
   count_tiles<BN>(ga, probs, n);
-  auto kern = gemm8_streamk_kernel<EPI, BN>;
+  auto kern = gemm8_streamk_kernel<EPI, BN, M16>;
   FK_ENSURE_MAX_LDS(kern, Cfg8<BN>::SMEM_BYTES, "fk_gemm_bf16 (256 x 256 tile, stream-K ranges)");
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Cfg8<BN>::SMEM_BYTES, stream, ga);
   FK_CHECK_LAUNCH("fk_gemm_bf16 (256 x 256 tile, stream-K ranges)");
@@ -738,9 +776,10 @@ int launch8_streamk(GroupArgs& ga, const fk_gemm_args* probs, int n, int grid, h
 //     P2(u)   W_1(u), W_0(u+1)   (4 + 4)      W_0(u+3), W_1(u+2)       (2)   vmcnt(8)       j = 1
 // Every request is retired three phases after its issue and read one phase later; a slot is re-requested no earlier
 // than two phases after its last read (same rules as gemm8_kernel).
-template <int BN>
+template <int BN, bool M16_ = false>
 struct Cfg9 {
   static_assert(BN == 128, "instantiated for the 256 x 128 tile only");
+  static constexpr bool M16 = M16_;
   static constexpr int NTHREADS = 512;
   static constexpr int BK = 64, ROW_BYTES = 128;
   static constexpr int WAVES_M = 4, WAVES_N = 2;
@@ -756,9 +795,9 @@ struct Cfg9 {
   static FK_DEV int tile_col(int wn, int nf) { return wn * WTN + nf * 32; }
 };
 
-template <int EPI, int BN>
+template <int EPI, int BN, bool M16 = false>
 FK_DEV void gemm9_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0) {
-  using C = Cfg9<BN>;
+  using C = Cfg9<BN, M16>;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -802,11 +841,13 @@ FK_DEV void gemm9_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0) 
     buffer_lds16(rs_w, smem + stage * C::STAGE_BYTES + 2 * C::A_HALF + j * C::W_PART + wave * 1024, w_voff[j], koff);
   };
 
-  const int frow = lane & 31, fhalf = lane >> 5, fsw = C::swz(frow);
-  int koffs[4];
+  constexpr int NKS = M16 ? 2 : 4, ASUB = M16 ? 4 : 2, WSUB = M16 ? 2 : 1;   // as gemm8_body
+  constexpr int SUB_BYTES = (M16 ? 16 : 32) * C::ROW_BYTES;
+  const int frow = M16 ? (lane & 15) : (lane & 31), fhalf = M16 ? (lane >> 4) : (lane >> 5), fsw = C::swz(frow);
+  int koffs[NKS];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) koffs[kk] = ((kk * 2 + fhalf) ^ fsw) << 4;
-  const int a_rd = (wm * 64 + frow) * C::ROW_BYTES;                   // rows 64 wm .. of the 256-row A image (+ mf * 4096)
+  for (int kk = 0; kk < NKS; ++kk) koffs[kk] = ((kk * (M16 ? 4 : 2) + fhalf) ^ fsw) << 4;
+  const int a_rd = (wm * 64 + frow) * C::ROW_BYTES;                   // rows 64 wm .. of the 256-row A image (+ sub * SUB_BYTES)
   const int w_rd = 2 * C::A_HALF + (wn * 32 + frow) * C::ROW_BYTES;   // inside part W_j (+ j * W_PART)
 
   f32x16_t acc[C::NF][C::MF];
@@ -817,25 +858,29 @@ FK_DEV void gemm9_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  bf16x8_t af[2][4], wf[2][4];   // A [mf][kk]; W [j][kk]
+  bf16x8_t af[ASUB][NKS], wf[2][WSUB][NKS];   // A [sub][kk]; W [j][sub][kk]
   auto read_a = [&](int stage) {
     const char* b = smem + stage * C::STAGE_BYTES + a_rd;
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf)
+    for (int sub = 0; sub < ASUB; ++sub)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) af[mf][kk] = *(const bf16x8_t*)(b + mf * 4096 + koffs[kk]);
+      for (int kk = 0; kk < NKS; ++kk) af[sub][kk] = *(const bf16x8_t*)(b + sub * SUB_BYTES + koffs[kk]);
   };
   auto read_w = [&](int stage, int j) {
     const char* b = smem + stage * C::STAGE_BYTES + w_rd + j * C::W_PART;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) wf[j][kk] = *(const bf16x8_t*)(b + koffs[kk]);
+    for (int sub = 0; sub < WSUB; ++sub)
+#pragma unroll
+      for (int kk = 0; kk < NKS; ++kk) wf[j][sub][kk] = *(const bf16x8_t*)(b + sub * SUB_BYTES + koffs[kk]);
   };
   auto mma = [&](int j) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+    for (int kk = 0; kk < NKS; ++kk)
 #pragma unroll
-      for (int mf = 0; mf < 2; ++mf)
-        acc[j][mf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][kk], af[mf][kk], acc[j][mf], 0, 0, 0);
+      for (int mf = 0; mf < 2; ++mf) {
+        if constexpr (M16) mma16_block(acc[j][mf], wf[j][0][kk], wf[j][1][kk], af[2 * mf][kk], af[2 * mf + 1][kk]);
+        else acc[j][mf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][0][kk], af[mf][kk], acc[j][mf], 0, 0, 0);
+      }
   };
   auto phase_sync_mma = [&](auto vm, int j) {
     wait_vmcnt<decltype(vm)::value>();
@@ -885,18 +930,18 @@ FK_DEV void gemm9_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0) 
   store_tile<EPI, BN, C>(acc, p, smem, m0, n0, wm, wn);
 }
 
-template <int EPI, int BN>
+template <int EPI, int BN, bool M16 = false>
 __global__ __launch_bounds__(512, 2) void gemm9_kernel(const GroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int pi, m0, n0;
   select_tile<BN>(ga, xcd_chunk_index(), pi, m0, n0);
-  gemm9_body<EPI, BN>(ga, smem, pi, m0, n0);
+  gemm9_body<EPI, BN, M16>(ga, smem, pi, m0, n0);
 }
 
-template <int EPI, int BN>
+template <int EPI, int BN, bool M16 = false>
 int launch9(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) {
   const int total = count_tiles<BN>(ga, probs, n);
-  auto kern = gemm9_kernel<EPI, BN>;
+  auto kern = gemm9_kernel<EPI, BN, M16>;
   FK_ENSURE_MAX_LDS(kern, Cfg9<BN>::SMEM_BYTES, "fk_gemm_bf16 (256 x 128 tile, 8 waves ping-pong)");
   hipLaunchKernelGGL(kern, dim3(total), dim3(512), Cfg9<BN>::SMEM_BYTES, stream, ga);
   FK_CHECK_LAUNCH("fk_gemm_bf16 (256 x 128 tile, 8 waves ping-pong)");
@@ -910,7 +955,7 @@ int launch9(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream)
 // Both bodies accumulate over K in the same order, so WHICH tile shape computes an output element does not change its
 // bits: the split of the columns is free to follow the grid.  Workgroups are dispatched in blockIdx order, XCD = b % 8:
 // each XCD's list is its chunk of the big tiles first, then its chunk of the small ones.
-template <int EPI>
+template <int EPI, bool M16 = false>
 __global__ __launch_bounds__(512, 2) void gemm_mix_kernel(const GroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -918,17 +963,17 @@ __global__ __launch_bounds__(512, 2) void gemm_mix_kernel(const GroupArgs ga) {
   int pi, m0, n0;
   if (idx < nbig) {
     tile_of<256>(ga, ga.tiles_before, ga.xcd_big_start[xcd] + idx, ga.big_cols, 0, pi, m0, n0);
-    gemm8_body<EPI, 256>(ga, smem, pi, m0, n0, 0, ga.p[0].K / 64, -1);
+    gemm8_body<EPI, 256, 0, M16>(ga, smem, pi, m0, n0, 0, ga.p[0].K / 64, -1);
   } else {
     tile_of<128>(ga, ga.small_before, ga.xcd_small_start[xcd] + idx - nbig, (ga.p[0].N - ga.big_cols * 256 + 127) / 128,
                  ga.big_cols * 256, pi, m0, n0);
-    gemm9_body<EPI, 128>(ga, smem, pi, m0, n0);
+    gemm9_body<EPI, 128, M16>(ga, smem, pi, m0, n0);
   }
 }
 
 constexpr int MIX_SMEM = Cfg8<256>::SMEM_BYTES > Cfg9<128>::SMEM_BYTES ? Cfg8<256>::SMEM_BYTES : Cfg9<128>::SMEM_BYTES;
 
-template <int EPI>
+template <int EPI, bool M16 = false>
 int launch_mix(GroupArgs& ga, const fk_gemm_args* probs, int n, int big_cols, hipStream_t stream) {
   const int ncols128 = (probs[0].N - big_cols * 256 + 127) / 128;
   int tb = 0, ts = 0;
@@ -955,7 +1000,7 @@ int launch_mix(GroupArgs& ga, const fk_gemm_args* probs, int n, int big_cols, hi
     bs += bx;
     ss += wx - bx;
   }
-  auto kern = gemm_mix_kernel<EPI>;
+  auto kern = gemm_mix_kernel<EPI, M16>;
   FK_ENSURE_MAX_LDS(kern, MIX_SMEM, "fk_gemm_bf16 (mixed 256 x 256 / 256 x 128 tiles)");
   hipLaunchKernelGGL(kern, dim3(W), dim3(512), MIX_SMEM, stream, ga);
   FK_CHECK_LAUNCH("fk_gemm_bf16 (mixed 256 x 256 / 256 x 128 tiles)");
@@ -964,15 +1009,20 @@ int launch_mix(GroupArgs& ga, const fk_gemm_args* probs, int n, int big_cols, hi
 
 // variant: 128 -> gemm9_kernel (256 x 128), 256 -> gemm8_kernel (256 x 256), 384 -> mixed, 512 -> split-K pairs of 256 x 256,
 // 640 -> stream-K ranges over 256 x 256 tiles (big_cols carries the grid size)
-template <int EPI>
-int launch_variant(GroupArgs& ga, const fk_gemm_args* probs, int n, int variant, int big_cols, hipStream_t stream) {
+template <int EPI, bool M16>
+int launch_variant_m(GroupArgs& ga, const fk_gemm_args* probs, int n, int variant, int big_cols, hipStream_t stream) {
   switch (variant) {
-    case 256: return launch8<EPI, 256, false>(ga, probs, n, stream);
-    case 384: return launch_mix<EPI>(ga, probs, n, big_cols, stream);
-    case 512: return launch8<EPI, 256, true>(ga, probs, n, stream);
-    case 640: return launch8_streamk<EPI, 256>(ga, probs, n, big_cols, stream);
-    default: return launch9<EPI, 128>(ga, probs, n, stream);
+    case 256: return launch8<EPI, 256, false, 0, M16>(ga, probs, n, stream);
+    case 384: return launch_mix<EPI, M16>(ga, probs, n, big_cols, stream);
+    case 512: return launch8<EPI, 256, true, 0, M16>(ga, probs, n, stream);
+    case 640: return launch8_streamk<EPI, 256, M16>(ga, probs, n, big_cols, stream);
+    default: return launch9<EPI, 128, M16>(ga, probs, n, stream);
   }
+}
+template <int EPI>
+int launch_variant(GroupArgs& ga, const fk_gemm_args* probs, int n, int variant, int big_cols, bool m16, hipStream_t stream) {
+  return m16 ? launch_variant_m<EPI, true>(ga, probs, n, variant, big_cols, stream)
+             : launch_variant_m<EPI, false>(ga, probs, n, variant, big_cols, stream);
 }
 
 int cu_count() {
@@ -1071,6 +1121,28 @@ extern "C" int fk_gemm_set_plan(int32_t allow) {
   g_plan_allow = allow;
   return FK_OK;
 }
+
+// MFMA shape of the layout-0 large-tile kernels: 32 = v_mfma_f32_32x32x16_bf16, 16 = v_mfma_f32_16x16x32_bf16 (FragMap above).
+// The two differ in the last bits (16 against 32 products per hardware sum); every launch form of ONE shape agrees bit
+// for bit with the others.  FK_GEMM_MFMA=16|32 or fk_gemm_set_mfma(); the K-major layouts (1, 2) always use 32.
+#ifndef FK_GEMM_MFMA_DEFAULT
+#define FK_GEMM_MFMA_DEFAULT 32
+#endif
+static int g_mfma = -1;
+static int gemm_mfma() {
+  if (g_mfma < 0) {
+    const char* e = getenv("FK_GEMM_MFMA");
+    const int v = e ? atoi(e) : FK_GEMM_MFMA_DEFAULT;
+    g_mfma = v == 16 ? 16 : 32;
+  }
+  return g_mfma;
+}
+extern "C" int fk_gemm_set_mfma(int32_t shape) {
+  FK_CHECK_ARG(shape == 0 || shape == 16 || shape == 32, "fk_gemm_set_mfma: 16 (16 x 16 x 32), 32 (32 x 32 x 16) or 0 (default), got %d", shape);
+  g_mfma = shape == 0 ? FK_GEMM_MFMA_DEFAULT : shape;
+  return FK_OK;
+}
+extern "C" int fk_gemm_get_mfma(void) { return gemm_mfma(); }
 
 // Used by fk_gemm_bf16 / fk_gemm_bf16_grouped after argument validation.
 // variant_hint: 128 / 256 / 384 / 512 force a launch form where it is applicable; 0 = choose per problem.  The 256 x 256
@@ -1187,16 +1259,17 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int variant_hint, hipStrea
     ga.sk_ctl = (unsigned*)((char*)probs[0].splitk_ws + (size_t)ws_slots * (BM * 256 * 4));
   }
   g_last_variant = plan.variant;
+  const bool m16 = gemm_mfma() == 16;
   int rc;
   switch (probs[0].out_fp32 == 2 ? FK_EPI_F32DBG : probs[0].epilogue) {
-    case FK_EPI_F32DBG: rc = launch_variant<FK_EPI_F32DBG>(ga, probs, n, plan.variant, plan.big_cols, stream); break;
-    case FK_EPI_NONE: rc = launch_variant<FK_EPI_NONE>(ga, probs, n, plan.variant, plan.big_cols, stream); break;
-    case FK_EPI_GELU_TANH: rc = launch_variant<FK_EPI_GELU_TANH>(ga, probs, n, plan.variant, plan.big_cols, stream); break;
-    case FK_EPI_SILU: rc = launch_variant<FK_EPI_SILU>(ga, probs, n, plan.variant, plan.big_cols, stream); break;
-    case FK_EPI_GATE_RES: rc = launch_variant<FK_EPI_GATE_RES>(ga, probs, n, plan.variant, plan.big_cols, stream); break;
-    case FK_EPI_RES: rc = launch_variant<FK_EPI_RES>(ga, probs, n, plan.variant, plan.big_cols, stream); break;
-    case FK_EPI_SCALE: rc = launch_variant<FK_EPI_SCALE>(ga, probs, n, plan.variant, plan.big_cols, stream); break;
-    case FK_EPI_QKV: rc = launch_variant<FK_EPI_QKV>(ga, probs, n, plan.variant, plan.big_cols, stream); break;
+    case FK_EPI_F32DBG: rc = launch_variant<FK_EPI_F32DBG>(ga, probs, n, plan.variant, plan.big_cols, m16, stream); break;
+    case FK_EPI_NONE: rc = launch_variant<FK_EPI_NONE>(ga, probs, n, plan.variant, plan.big_cols, m16, stream); break;
+    case FK_EPI_GELU_TANH: rc = launch_variant<FK_EPI_GELU_TANH>(ga, probs, n, plan.variant, plan.big_cols, m16, stream); break;
+    case FK_EPI_SILU: rc = launch_variant<FK_EPI_SILU>(ga, probs, n, plan.variant, plan.big_cols, m16, stream); break;
+    case FK_EPI_GATE_RES: rc = launch_variant<FK_EPI_GATE_RES>(ga, probs, n, plan.variant, plan.big_cols, m16, stream); break;
+    case FK_EPI_RES: rc = launch_variant<FK_EPI_RES>(ga, probs, n, plan.variant, plan.big_cols, m16, stream); break;
+    case FK_EPI_SCALE: rc = launch_variant<FK_EPI_SCALE>(ga, probs, n, plan.variant, plan.big_cols, m16, stream); break;
+    case FK_EPI_QKV: rc = launch_variant<FK_EPI_QKV>(ga, probs, n, plan.variant, plan.big_cols, m16, stream); break;
     default: fk_set_error("fk_gemm_bf16: unknown epilogue %d", probs[0].epilogue); return FK_EUNSUPPORTED;
   }
   if (rc == FK_E2BIG_STRIDES && plan.variant == 384) {   // degenerate XCD split of a mixed grid: plain 256 x 128 grid

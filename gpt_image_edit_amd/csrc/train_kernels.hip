@@ -50,20 +50,30 @@ __global__ __launch_bounds__(256) void flow_mix_pack_kernel(const float* x, cons
   }
 }
 
-// d = float(pred) - (noise - x); partial[block] = sum of weight_b * d^2; grad = bf16(2 * weight_b * d * inv_count)
+// d = float(pred) - (noise - x); weighting = weight_b * area[b, y, x] * mask[b, y, x] (every factor optional, multiplied in the
+// reference's order, train_denoiser.py:1106-1149); partial[block] = sum of weighting * d^2;
+// grad = bf16(2 * weighting * d / denominator), denominator = mask_sum[0] * C (:1163-1165) or the element count (loss.mean())
 __global__ __launch_bounds__(RED_THREADS) void flow_loss_kernel(const bf16_t* pred, int64_t pred_bs, const float* x,
-                                                                const float* noise, const float* weight, bf16_t* grad,
+                                                                const float* noise, const float* weight, const float* area,
+                                                                const float* mask, const float* mask_sum, bf16_t* grad,
                                                                 int64_t grad_bs, double* partial, int C, int h, int w,
                                                                 int64_t n_per_batch, int64_t total, float inv_count) {
   __shared__ double sh[RED_THREADS / 64];
   double acc = 0.0;
+  const int hw = h * w;
+  const float inv = mask_sum ? 1.0f / (mask_sum[0] * (float)C) : inv_count;
   for (int64_t i = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * RED_THREADS) {
     const int64_t b = i / n_per_batch, r = i - b * n_per_batch;
     const int64_t src = latent_index(i, C, h, w);
-    const float wt = weight ? weight[b] : 1.0f;
+    float wt = weight ? weight[b] : 1.0f;
+    if (area || mask) {
+      const int64_t pix = b * hw + src % hw;
+      if (area) wt = __fmul_rn(wt, area[pix]);
+      if (mask) wt = __fmul_rn(wt, mask[pix]);
+    }
     const float d = bf2f(pred[b * pred_bs + r]) - (noise[src] - x[src]);
-    acc += (double)(wt * d * d);
-    if (grad) grad[b * grad_bs + r] = f2bf(2.0f * wt * d * inv_count);
+    acc += (double)__fmul_rn(wt, __fmul_rn(d, d));
+    if (grad) grad[b * grad_bs + r] = f2bf(2.0f * wt * d * inv);
   }
   const double t = block_sum(acc, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
@@ -80,13 +90,14 @@ __global__ __launch_bounds__(RED_THREADS) void sumsq_kernel(const void* g, int g
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
-// out[0] (+)= scale * sum(partial[0..n))  -- one block, fixed order
+// out[0] (+)= scale * sum(partial[0..n))  -- one block, fixed order.  denom (device scalar, optional): scale = 1 / (denom[0] * denom_mul)
 __global__ __launch_bounds__(RED_THREADS) void finish_sum_kernel(const double* partial, int n, double scale, int accumulate,
-                                                                 double* out) {
+                                                                 double* out, const float* denom = nullptr, double denom_mul = 1.0) {
   __shared__ double sh[RED_THREADS / 64];
   double acc = 0.0;
   for (int i = threadIdx.x; i < n; i += RED_THREADS) acc += partial[i];
   const double t = block_sum(acc, sh);
+  if (denom) scale = 1.0 / ((double)denom[0] * denom_mul);
   if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.0) + scale * t;
 }
 
@@ -140,21 +151,30 @@ extern "C" int fk_flow_noisy_tokens_bf16(const float* x, const float* noise, con
   return FK_OK;
 }
 
-extern "C" int fk_flow_loss_bf16(const void* pred, int64_t pred_batch_stride, const float* x, const float* noise,
-                                 const float* weight, void* grad, int64_t grad_batch_stride, double* loss, double* ws,
-                                 int32_t B, int32_t C, int32_t h, int32_t w, fk_stream_t stream) {
+extern "C" int fk_flow_loss_weighted_bf16(const void* pred, int64_t pred_batch_stride, const float* x, const float* noise,
+                                          const float* weight, const float* area_weights, const float* weight_mask,
+                                          const float* mask_sum, void* grad, int64_t grad_batch_stride, double* loss, double* ws,
+                                          int32_t B, int32_t C, int32_t h, int32_t w, fk_stream_t stream) {
   FK_CHECK_ARG(pred && x && noise && loss && ws, "fk_flow_loss_bf16: null pointer");
   FK_CHECK_ARG(B > 0 && C > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0, "fk_flow_loss_bf16: bad sizes");
+  FK_CHECK_ARG(!mask_sum || weight_mask, "fk_flow_loss_weighted_bf16: mask_sum (the weight_mask.sum() normaliser) without weight_mask");
   const int64_t npb = (int64_t)C * h * w, total = npb * B;
   FK_CHECK_ARG(pred_batch_stride >= npb && (!grad || grad_batch_stride >= npb), "fk_flow_loss_bf16: bad batch stride");
   const int blocks = grid_for(total, RED_THREADS);
   hipLaunchKernelGGL(flow_loss_kernel, dim3(blocks), dim3(RED_THREADS), 0, (hipStream_t)stream, (const bf16_t*)pred,
-                     pred_batch_stride, x, noise, weight, (bf16_t*)grad, grad_batch_stride, ws, C, h, w, npb, total,
-                     1.0f / (float)total);
+                     pred_batch_stride, x, noise, weight, area_weights, weight_mask, mask_sum, (bf16_t*)grad, grad_batch_stride, ws,
+                     C, h, w, npb, total, 1.0f / (float)total);
   hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(RED_THREADS), 0, (hipStream_t)stream, (const double*)ws, blocks,
-                     1.0 / (double)total, 0, loss);
+                     1.0 / (double)total, 0, loss, mask_sum, (double)C);
   FK_CHECK_LAUNCH("fk_flow_loss_bf16");
   return FK_OK;
+}
+
+extern "C" int fk_flow_loss_bf16(const void* pred, int64_t pred_batch_stride, const float* x, const float* noise,
+                                 const float* weight, void* grad, int64_t grad_batch_stride, double* loss, double* ws,
+                                 int32_t B, int32_t C, int32_t h, int32_t w, fk_stream_t stream) {
+  return fk_flow_loss_weighted_bf16(pred, pred_batch_stride, x, noise, weight, nullptr, nullptr, nullptr, grad, grad_batch_stride,
+                                    loss, ws, B, C, h, w, stream);
 }
 
 extern "C" int fk_sumsq(const void* g, int32_t g_is_bf16, int64_t n, int32_t accumulate, double* out, double* ws,

@@ -77,6 +77,8 @@ SIGNATURES = {
     "fk_gemm_set_variant": (c_i32, [c_i32]),
     "fk_gemm_set_plan": (c_i32, [c_i32]),
     "fk_gemm_set_group_m": (c_i32, [c_i32]),
+    "fk_gemm_set_mfma": (c_i32, [c_i32]),
+    "fk_gemm_get_mfma": (c_i32, []),
     "fk_ln_modulate_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "fk_ln_modulate2_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "fk_qkv_post_bf16": (c_i32, [c_vp] * 9 + [c_i32] * 4 + [c_f32, c_vp]),
@@ -107,6 +109,7 @@ SIGNATURES = {
     "fk_reduce_ws_doubles": (c_i64, []),
     "fk_flow_noisy_tokens_bf16": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64] + [c_i32] * 4 + [c_vp]),
     "fk_flow_loss_bf16": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp] + [c_i32] * 4 + [c_vp]),
+    "fk_flow_loss_weighted_bf16": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp] + [c_i32] * 4 + [c_vp]),
     "fk_sumsq": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "fk_adamw_step": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp] + [c_f32] * 6 + [c_i32, c_i64, c_vp]),
     "fk_adamw_step_scaled": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp] + [c_f32] * 7 + [c_i32, c_i64, c_vp]),

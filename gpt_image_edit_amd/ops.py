@@ -164,6 +164,12 @@ def gemm_set_plan(allow):
     libfk.check(libfk.load().fk_gemm_set_plan(int(allow)), "fk_gemm_set_plan")
 
 
+def gemm_set_mfma(shape):
+    """MFMA shape of the layout-0 large-tile GEMM kernels: 32 (v_mfma_f32_32x32x16_bf16), 16 (v_mfma_f32_16x16x32_bf16) or
+    0 = the built default.  The two differ in the last bits; see include/fk.h."""
+    libfk.check(libfk.load().fk_gemm_set_mfma(int(shape)), "fk_gemm_set_mfma")
+
+
 def gemm_grouped(problems, epilogue=FK_EPI_NONE):
     """Several independent GEMMs sharing (N, K, epilogue) in ONE launch.  ``problems`` is a list of dicts
     with the keyword arguments of :func:`gemm` (a, w, bias, out, res, gate); returns the outputs."""
@@ -789,21 +795,32 @@ def flow_noisy_tokens(x, noise, sigma, out=None):
     return out
 
 
-def flow_loss(pred, x, noise, weight=None, want_grad=True):
-    """(loss fp64 [1], grad bf16 like pred or None) of mean(w_b * (unpack(pred) - (noise - x))^2); pred: packed bf16
-    [B, S, 4C] view with contiguous samples."""
-    _need_cuda(pred, x, noise, weight)
+def flow_loss(pred, x, noise, weight=None, want_grad=True, area_mask_weights=None, weight_mask=None):
+    """(loss fp64 [1], grad bf16 like pred or None) of the reference's flow-matching loss (train_denoiser.py:1106-1166);
+    pred: packed bf16 [B, S, 4C] view with contiguous samples.  weighting = weight[b] * area_mask_weights[b, 0, y, x] *
+    weight_mask[b, 0, y, x] (fp32 [B] / [B, 1, h, w], each optional); the sum of weighting * (unpack(pred) - (noise - x))^2 is
+    divided by weight_mask.sum() * C when weight_mask is given (:1163-1165), by the element count otherwise (loss.mean())."""
+    _need_cuda(pred, x, noise, weight, area_mask_weights, weight_mask)
     _f32c(x, "x"); _f32c(noise, "noise")
     B, C, h, w = x.shape
     if pred.shape != (B, (h // 2) * (w // 2), 4 * C) or pred.dtype != BF16 or pred.stride(2) != 1 or pred.stride(1) != 4 * C:
         raise ValueError("pred must be a [B, S, 4C] bf16 view with contiguous samples")
     if weight is not None:
         _f32c(weight, "weight")
+        if weight.numel() != B:
+            raise ValueError("weight: one fp32 value per sample")
+    for name, m in (("area_mask_weights", area_mask_weights), ("weight_mask", weight_mask)):
+        if m is not None:
+            _f32c(m, name)
+            if tuple(m.shape) != (B, 1, h, w):
+                raise ValueError(f"{name} must be [B, 1, h, w] at the latent size (nearest-resize it as train_denoiser.py:1131-1148 does)")
+    mask_sum = weight_mask.sum().reshape(1) if weight_mask is not None else None     # device scalar: no host round trip
     grad = torch.empty(pred.shape, device=pred.device, dtype=BF16) if want_grad else None
     loss = torch.empty(1, dtype=torch.float64, device=pred.device)
-    libfk.check(libfk.load().fk_flow_loss_bf16(_ptr(pred), pred.stride(0), _ptr(x), _ptr(noise), _ptr(weight), _ptr(grad),
-                                               grad.stride(0) if want_grad else 0, _ptr(loss), _ptr(_reduce_ws(pred.device)),
-                                               B, C, h, w, _stream()), "fk_flow_loss_bf16")
+    libfk.check(libfk.load().fk_flow_loss_weighted_bf16(
+        _ptr(pred), pred.stride(0), _ptr(x), _ptr(noise), _ptr(weight), _ptr(area_mask_weights), _ptr(weight_mask), _ptr(mask_sum),
+        _ptr(grad), grad.stride(0) if want_grad else 0, _ptr(loss), _ptr(_reduce_ws(pred.device)), B, C, h, w, _stream()),
+        "fk_flow_loss_weighted_bf16")
     return loss, grad
 
 

@@ -240,8 +240,9 @@ def synthetic_turn(config, device, n_text=44, image_hw=(448, 448), batch=1, seed
 def bench_prompt_encode(device, batch=1, repeats=3):
     """T_prompt: Qwen2.5-VL-7B (random init, bf16, reused as-is on PyTorch-ROCm) run the way
     the cli runs it per edit -- LM forward + task head, then the ``denoise_embeds`` forward + HIP projector -- on one
-    448^2 image + ~44 text tokens (L = 300).  T5-XXL / CLIP (a14) are not timed (their weights alone are 9.5 GB of
-    random numbers that say nothing new); the T5 half of ``prompt_embeds`` is a random tensor."""
+    448^2 image + ~44 text tokens (L = 300), plus (round 5) the T5-XXL / CLIP-L ``encode_prompt`` call on random-init
+    encoders of the FLUX.1 shapes (``prompt_embedding.bench_text_encoders``; reference
+    ``denoiser_prompt_embedding_flux.py:107-144``).  T_prompt_s = the sum of the two medians."""
     from .projector import HipDenoiseProjector
     cfg = qwen25vl_config("7b")
     vlm = build_vlm(cfg, device)
@@ -262,7 +263,16 @@ def bench_prompt_encode(device, batch=1, repeats=3):
     L = int(inputs["input_ids"].shape[1])
     assert r["generate"] and r["prompt_embeds"].shape == (batch, L + 256, 4096)
     n_par = sum(p.numel() for p in vlm.parameters())
-    return {"T_prompt_s": times[len(times) // 2], "runs_s": times, "vlm_tokens": L, "vlm_params": n_par,
-            "what": "Qwen2.5-VL-7B random init bf16 on PyTorch-ROCm (stock transformers model, reused as-is): LM forward "
-                    "+ task head, then denoise_embeds forward + HIP denoise_projector (cli.py:199-234); one 448^2 image "
-                    "+ 44 text tokens; T5-XXL / CLIP not included"}
+    t_vlm = times[len(times) // 2]
+    del model, vlm
+    torch.cuda.empty_cache()
+    try:
+        from .prompt_embedding import bench_text_encoders
+        te = bench_text_encoders(device, batch=batch)
+    except Exception as e:   # the Qwen figure must survive a missing encoder class
+        te = {"T_t5_clip_s": 0.0, "error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
+    return {"T_prompt_s": t_vlm + te["T_t5_clip_s"], "T_qwen_s": t_vlm, "T_t5_clip_s": te["T_t5_clip_s"], "runs_s": times,
+            "vlm_tokens": L, "vlm_params": n_par, "text_encoders": te,
+            "what": "random-init Qwen2.5-VL-7B (cli.py:199-234: LM forward + task head, denoise_embeds forward + HIP projector; "
+                    "448^2 image + 44 text tokens) + random-init T5-XXL (256 tokens) / CLIP-L encode_prompt; stock transformers models"}

@@ -102,12 +102,29 @@ class DenoiserTrainStep:
         return dict(hidden_states=tokens, encoder_hidden_states=prompt_embeds, pooled_projections=pooled, timestep=timestep,
                     img_ids=ids, txt_ids=txt_ids, guidance=guidance), S_tgt
 
+    @staticmethod
+    def _latent_map(m, B, h, w, dev):
+        """A per-pixel weight map as the loss kernel reads it: fp32 [B, 1, h, w] on the device, nearest-resized to the latent
+        size when it comes at another resolution (``F.interpolate(..., mode='nearest')``, train_denoiser.py:1131-1148)."""
+        if m is None:
+            return None
+        m = m.to(device=dev, dtype=torch.float32)
+        if m.dim() != 4 or m.shape[0] != B or m.shape[1] != 1:
+            raise ValueError("area_mask_weights / weight_mask must be [B, 1, H, W]")
+        if tuple(m.shape[-2:]) != (h, w):
+            m = torch.nn.functional.interpolate(m, size=(h, w), mode="nearest")
+        return m.contiguous()
+
     @torch.no_grad()
     def forward_backward(self, model_input, cond_latents, noise, sigmas, prompt_embeds=None, pooled=None, guidance_scale=1.0,
-                         vlm_hidden=None, prefix_prompt_embeds=None):
+                         vlm_hidden=None, prefix_prompt_embeds=None, weighting=None, area_mask_weights=None, weight_mask=None):
         """(loss fp64 [1], grads, d_prompt_embeds) for one batch of equally sized samples; model_input / noise fp32
         [B,16,h,w] (VAE latents already shifted and scaled), cond_latents the same or None, sigmas fp32 [B].
-        Either ``prompt_embeds`` (projector frozen / absent) or ``vlm_hidden`` [B,L,3584] (+ optional T5 prefix)."""
+        Either ``prompt_embeds`` (projector frozen / absent) or ``vlm_hidden`` [B,L,3584] (+ optional T5 prefix).
+        The loss as the stage-2 config sets it up (``mask_weight_type: 'log'``; train_denoiser.py:1106-1166): ``weighting``
+        fp32 [B] (``compute_loss_weighting_for_sd3`` / ``sigmas_as_weight``; None = ones), ``area_mask_weights`` [B,1,H,W]
+        (the dataset's per-pixel area weights), ``weight_mask`` [B,1,H,W] (1 inside a padded sample's true extent; with it
+        the sum is divided by ``weight_mask.sum() * C`` instead of the element count)."""
         n_proj = 0
         if vlm_hidden is not None:
             if self.projector is None or prompt_embeds is not None:
@@ -121,7 +138,13 @@ class DenoiserTrainStep:
         inp, S_tgt = self.prepare_inputs(model_input, cond_latents, noise, sigmas, prompt_embeds, pooled, guidance_scale)
         pred = self.bw.forward(inp["hidden_states"], inp["encoder_hidden_states"], inp["pooled_projections"], inp["timestep"],
                                inp["img_ids"], inp["txt_ids"], inp["guidance"])
-        loss, grad = ops.flow_loss(pred[:, :S_tgt], model_input.contiguous(), noise.contiguous())
+        B, _, h, w = model_input.shape
+        dev = pred.device
+        if weighting is not None:
+            weighting = weighting.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        loss, grad = ops.flow_loss(pred[:, :S_tgt], model_input.contiguous(), noise.contiguous(), weight=weighting,
+                                   area_mask_weights=self._latent_map(area_mask_weights, B, h, w, dev),
+                                   weight_mask=self._latent_map(weight_mask, B, h, w, dev))
         dsample = torch.zeros_like(pred)
         dsample[:, :S_tgt].copy_(grad)
         sink = None

@@ -131,6 +131,12 @@ int fk_gemm_set_plan(int32_t allow);
  * fastest inside a group.  depth >= the number of row tiles makes every XCD's chunk a range of COLUMN tiles over all rows
  * (a W tile then enters one XCD's L2 only).  0 = the default (8; FK_GEMM_GROUP_M overrides). */
 int fk_gemm_set_group_m(int32_t depth);
+/* MFMA shape of the layout-0 large-tile kernels (measurement hook): 32 = v_mfma_f32_32x32x16_bf16, 16 =
+ * v_mfma_f32_16x16x32_bf16 (half the accumulator register traffic per flop: under the chip's power limit a pure stream of it
+ * sustains 12 % more flops, tools/power_probe.hip), 0 = the built default (FK_GEMM_MFMA overrides).  The two shapes differ in
+ * the last bits; all launch forms (256 x 256, 256 x 128, mixed, split-K) of one shape agree with each other as before. */
+int fk_gemm_set_mfma(int32_t shape);
+int fk_gemm_get_mfma(void);
 
 /* n (<= FK_MAX_GROUP) independent problems that share N, K and the epilogue in ONE launch: the text- and
  * image-stream linears of a FluxTransformerBlock (different weights, different row counts) fill the GPU
@@ -347,6 +353,17 @@ int fk_flow_noisy_tokens_bf16(const float* x, const float* noise, const float* s
 int fk_flow_loss_bf16(const void* pred, int64_t pred_batch_stride, const float* x, const float* noise,
                       const float* weight, void* grad, int64_t grad_batch_stride, double* loss, double* ws,
                       int32_t B, int32_t C, int32_t h, int32_t w, fk_stream_t stream);
+/* The stage-2 loss AS CONFIGURED (scripts/denoiser/flux_qwen2p5vl_7b_vlm_stage2_1024.yaml:27 `mask_weight_type: 'log'`;
+ * train_denoiser.py:1123-1165): per-pixel weights on top of the per-sample one,
+ *   weighting[b, y, x] = weight[b] * area_weights[b, 0, y, x] * weight_mask[b, 0, y, x]   (fp32, that order; NULL factor = 1;
+ *                        the maps are [B, 1, h, w] contiguous, already nearest-resized to the latent size as :1131-1148 does),
+ *   loss[0] = sum(weighting * d^2) / denominator,  grad = bf16(2 * weighting * d / denominator),
+ *   denominator = mask_sum[0] * C when mask_sum (a DEVICE scalar holding weight_mask.sum(), :1163-1165) is given, else B*C*h*w
+ *   (loss.mean()).  All map arguments NULL: fk_flow_loss_bf16 bit for bit. */
+int fk_flow_loss_weighted_bf16(const void* pred, int64_t pred_batch_stride, const float* x, const float* noise,
+                               const float* weight, const float* area_weights, const float* weight_mask, const float* mask_sum,
+                               void* grad, int64_t grad_batch_stride, double* loss, double* ws,
+                               int32_t B, int32_t C, int32_t h, int32_t w, fk_stream_t stream);
 /* out[0] = (accumulate ? out[0] : 0) + sum(g^2) over n fp32 (or bf16) elements: the global gradient norm of
  * accelerator.clip_grad_norm_ (train_denoiser.py:1171-1177) accumulated tensor by tensor, in double. */
 int fk_sumsq(const void* g, int32_t g_is_bf16, int64_t n, int32_t accumulate, double* out, double* ws, fk_stream_t stream);

@@ -534,3 +534,41 @@ def test_attention_moderate_logit_growth_needs_no_restart_and_stays_accurate(ops
     got = out.float().cpu()
     assert torch.isfinite(got).all()
     assert (got - ref).abs().max().item() <= 3e-2 * ref.abs().max().item()
+
+
+def test_gemm_mfma16_every_form(ops):
+    """The large-tile GEMM kernels on v_mfma_f32_16x16x32_bf16 (fk_gemm_set_mfma(16); FragMap<true> in gemm_pingpong_bf16.hip:
+    other fragment addressing, other accumulator-register -> (row, column) map in the epilogue): every check the
+    32 x 32 x 16 form passes -- the stated tolerance on the fp32-output build of every launch form, bit-equality between
+    the forms, transpose detection, all epilogues, grouped launches, the fused QKV epilogue against the unfused path."""
+    ops.gemm_set_mfma(16)
+    try:
+        for shape in HOT_SHAPES:
+            test_hot_gemm_kernels_at_the_stated_tolerance(ops, *shape)
+        # transpose detection ON the large-tile kernels (exact: a selector matrix against an asymmetric weight), every form
+        from gpt_image_edit_amd import libfk
+        lib = libfk.load()
+        M, N, K = 512, 768, 128
+        a = torch.zeros(M, K)
+        a[torch.arange(M), (torch.arange(M) * 7) % K] = 1.0
+        w = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) / 64.0
+        ref = a.to(BF).float() @ w.to(BF).float().T
+        for force in (128, 256, 384):
+            lib.fk_gemm_set_variant(force)
+            try:
+                got = ops.gemm(a.to(BF).cuda(), w.to(BF).cuda(), None, out_fp32=2).cpu()
+            finally:
+                lib.fk_gemm_set_variant(0)
+            torch.testing.assert_close(got, ref, rtol=0, atol=0)
+        for epi in ("none", "gelu", "silu", "scale"):
+            test_gemm_bf16_epilogues(ops, epi)
+        test_gemm_gate_residual_strided_views(ops)
+        for args in [(256, 128, 64), (2560, 3072, 3072), (2048 + 3, 9216, 128), (700, 200, 192)]:
+            test_gemm_large_tile_kernel(ops, *args)
+        for args in [(1, 2560, 12288, 3072, 256), (1, 2560, 9216, 3072, 384), (2, 1200, 3072, 1024, 128), (1, 2560, 3072, 12288, 512)]:
+            test_gemm_tile_choice_and_batched_epilogue(ops, *args)
+        test_gemm_grouped(ops)
+        test_gemm_fused_qkv_epilogue(ops)
+        test_gemm_tile_order_does_not_change_the_bits(ops)
+    finally:
+        ops.gemm_set_mfma(0)

@@ -279,3 +279,47 @@ def test_prepared_conditioning_notices_an_optimiser_step():
     assert m._cond is None and not torch.equal(moved, after)
     # ids built afresh every call (the reference's training loop, modeling_univa_denoise_tower.py:73-75) give the same bits
     assert torch.equal(m(timestep=steps[1].clone(), **dict(kw, txt_ids=txt_ids.clone(), img_ids=img_ids.clone()))[0], moved)
+
+
+def test_step_takes_the_stage2_loss_weights():
+    """VERDICT r4 missing #3: ``forward_backward`` carries the loss of the shipped stage-2 config (``mask_weight_type: 'log'``,
+    train_denoiser.py:1123-1165).  Per-pixel maps given at IMAGE resolution are nearest-resized to the latent size as the
+    reference does; the loss equals ``oracle.train.flow_matching_loss`` on the HIP model's own prediction with the same
+    maps, all-ones maps reproduce the unweighted step bit for bit, and a masked-out region contributes no gradient."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.nn.functional as F
+    from gpt_image_edit_amd import ops
+    from gpt_image_edit_amd.train_step import DenoiserTrainStep
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    from oracle import helpers, train as otrain
+    cfg, sd_bf, batch, trainable = _setup()
+    model = HipFluxTransformer2DModel(cfg, device="cuda")
+    model.load_state_dict(sd_bf)
+    ts = DenoiserTrainStep(model)
+    dev = {k: v.cuda() for k, v in batch.items()}
+    B, C, h, w = batch["model_input"].shape
+    g = torch.Generator().manual_seed(3)
+    area = torch.log1p(torch.rand(B, 1, 8 * h, 8 * w, generator=g) * 30.0) + 0.1      # at pixel resolution
+    mask = torch.ones(B, 1, h, w)
+    mask[1, :, h // 2:, :] = 0.0                                                        # sample 1: lower half is padding
+    weighting = torch.tensor([1.5, 0.5])
+    loss0, grads0, _ = ts.forward_backward(**dev)
+    loss1, grads1, _ = ts.forward_backward(**dev, weighting=torch.ones(B), area_mask_weights=torch.ones(B, 1, h, w))
+    assert torch.equal(loss0, loss1) and all(torch.equal(grads0[k], grads1[k]) for k in grads0)
+    loss2, grads2, _ = ts.forward_backward(**dev, weighting=weighting, area_mask_weights=area, weight_mask=mask)
+    # the oracle's loss on the HIP forward's own prediction (the forward itself is held to the oracle elsewhere)
+    inp, S_tgt = ts.prepare_inputs(dev["model_input"], dev["cond_latents"], dev["noise"], dev["sigmas"], dev["prompt_embeds"], dev["pooled"])
+    pred = ts.bw.forward(inp["hidden_states"], inp["encoder_hidden_states"], inp["pooled_projections"], inp["timestep"],
+                         inp["img_ids"], inp["txt_ids"], inp["guidance"])[:, :S_tgt].cpu()
+    area_l = F.interpolate(area, size=(h, w), mode="nearest")
+    wfull = weighting.view(B, 1, 1, 1).float() * area_l.float() * mask.float()
+    ref = otrain.flow_matching_loss(helpers.unpack_latents(pred, h * 8, w * 8), batch["model_input"], batch["noise"], wfull, weight_mask=mask)
+    assert float(loss2) == pytest.approx(float(ref), rel=1e-5)
+    assert abs(float(loss2) - float(loss0)) > 1e-3 * float(loss0)
+    assert any(not torch.equal(grads2[k], grads0[k]) for k in grads0)
+    # the loss kernel's gradient is zero on the padding
+    _, dpred = ops.flow_loss(pred.cuda(), dev["model_input"].contiguous(), dev["noise"].contiguous(), weight=weighting.cuda(),
+                             area_mask_weights=area_l.cuda().contiguous(), weight_mask=mask.cuda())
+    pad = helpers.pack_latents((1.0 - mask).expand(B, C, h, w).contiguous()) > 0
+    assert float(dpred.cpu().float()[pad].abs().max()) == 0 and float(dpred.cpu().float().abs().max()) > 0

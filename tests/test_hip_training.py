@@ -59,6 +59,47 @@ def test_flow_loss_and_gradient_match_autograd(ops, weighted):
     assert float(again) == float(loss)   # fixed-order reduction
 
 
+@pytest.mark.parametrize("masked", [False, True])
+def test_flow_loss_with_per_pixel_weights_matches_the_reference_form(ops, masked):
+    """The stage-2 loss as configured (``mask_weight_type: 'log'``, train_denoiser.py:1123-1165): weighting[b] x
+    area_mask_weights[b, 0, y, x] (x weight_mask[b, 0, y, x], the sum then divided by weight_mask.sum() * C) -- loss and
+    gradient against ``oracle.train.flow_matching_loss`` under autograd with random maps."""
+    from oracle import helpers, train as otrain
+    x, noise, sigma = _batch(seed=5)
+    B, C, h, w = x.shape
+    g = torch.Generator().manual_seed(6)
+    pred = torch.randn(B, (h // 2) * (w // 2), 4 * C, generator=g).to(BF)
+    wt = sigma ** -2.0
+    area = torch.log1p(torch.rand(B, 1, h, w, generator=g) * 20.0) + 0.25            # 'log' area weights: positive, spread over ~10x
+    mask = None
+    if masked:                                                                        # padded batch: sample b valid on a sub-rectangle
+        mask = torch.zeros(B, 1, h, w)
+        for b in range(B):
+            mask[b, :, : h - 2 * b, : w - 4 * b] = 1.0
+    p = pred.clone().requires_grad_(True)
+    weighting = wt.view(B, 1, 1, 1).float() * area.float()
+    if masked:
+        weighting = weighting * mask.float()
+    ref = otrain.flow_matching_loss(helpers.unpack_latents(p, h * 8, w * 8), x, noise, weighting, weight_mask=mask)
+    ref.backward()
+    loss, grad = ops.flow_loss(pred.cuda(), x.cuda(), noise.cuda(), wt.cuda(), area_mask_weights=area.cuda(),
+                               weight_mask=mask.cuda() if masked else None)
+    assert float(loss) == pytest.approx(float(ref.detach()), rel=2e-6)
+    d = report(f"flow_loss grad (area weights, masked={masked})", grad, p.grad)
+    assert float(d.max()) <= 2 ** -8 * float(p.grad.float().abs().max())
+    assert float((grad.cpu() == p.grad).float().mean()) > 0.99
+    if masked:
+        assert float(grad.cpu().float().abs().max()) > 0
+        outside = helpers.pack_latents((1.0 - mask).expand(B, C, h, w).contiguous()) > 0
+        assert float(grad.cpu().float()[outside].abs().max()) == 0            # no gradient from the padding
+    # maps of all ones + no mask = the plain path, bit for bit
+    l0, g0 = ops.flow_loss(pred.cuda(), x.cuda(), noise.cuda(), wt.cuda())
+    l1, g1 = ops.flow_loss(pred.cuda(), x.cuda(), noise.cuda(), wt.cuda(), area_mask_weights=torch.ones(B, 1, h, w).cuda())
+    assert float(l0) == float(l1) and torch.equal(g0, g1)
+    with pytest.raises(ValueError, match="latent size"):
+        ops.flow_loss(pred.cuda(), x.cuda(), noise.cuda(), area_mask_weights=torch.ones(B, 1, 2 * h, 2 * w).cuda())
+
+
 def test_adamw_with_clipping_matches_torch(ops):
     torch.manual_seed(4)
     shapes = [(257, 33), (1000,), (64, 64, 3)]

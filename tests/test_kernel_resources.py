@@ -25,7 +25,8 @@ BUDGET = {
 }
 # key -> [(name fragment, max scratch bytes, max spilled VGPRs)]; the fp32-output parity build of the split-K form (epilogue
 # 64 = FK_EPI_F32DBG, test-only) keeps its bias quads live across the rendezvous as well: more of the same, still outside the K loop
-EXCEPTIONS = {"gemm8_kernelILi": [("ILi64ELi256ELb1ELi0EEE", 320, 72), ("Lb1ELi0EEE", 136, 32)],
+# (template arguments <EPI, BN, SPLITK, LAY, M16>: the fragments below match both MFMA shapes)
+EXCEPTIONS = {"gemm8_kernelILi": [("ILi64ELi256ELb1ELi0ELb", 320, 72), ("Lb1ELi0ELb", 136, 32)],
               # the stream-K form loops over passes (tile part, rendezvous, epilogue): what is live across a pass sits in
               # scratch around it -- ~90 scratch instructions per pass, NONE inside the K loop (checked below)
               "gemm8_streamk_kernel": [("ILi64E", 200, 300), ("", 260, 120)]}
@@ -75,5 +76,6 @@ def test_hot_kernels_keep_their_accumulators_in_registers(src, tmp_path):
             assert loops, "no loop with MFMAs found"
             head = min(loops, key=lambda ab: ab[1] - ab[0])[0]      # header of the innermost loop that multiplies ...
             k_loop = body[head:max(b for a_, b in loops if a_ == head)]   # ... up to its last back edge: two K-tiles = 64 MFMAs
-            assert sum("v_mfma" in x for x in k_loop) == 64
+            n_mfma = sum("v_mfma" in x for x in k_loop)
+            assert n_mfma == (128 if "16x16x32" in "".join(k_loop) else 64)      # 32 x 32 x 16: 64 per two K-tiles; 16 x 16 x 32: 128
             assert not any("scratch_" in x for x in k_loop), f"{lines[a][:70]}: scratch traffic inside the K loop"

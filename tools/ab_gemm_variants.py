@@ -17,7 +17,12 @@ lib = libfk.load()
 shapes = [tuple(int(x) for x in t.split("x")) for t in os.environ["AB_SHAPES"].split(",")] if os.environ.get("AB_SHAPES") else [(2560, 9216, 3072), (2560, 12288, 3072), (2560, 3072, 12288), (2560, 3072, 15360), (2560, 3072, 3072),
           (8704, 9216, 3072), (8704, 12288, 3072), (8704, 3072, 12288), (8704, 3072, 15360), (8704, 3072, 3072),
           (32768, 12288, 3072), (32768, 3072, 12288), (32768, 9216, 3072)]
-variants = [int(v) if v != "vendor" else v for v in os.environ.get("AB_VARIANTS", "128,256,384,512,0,vendor").split(",")]
+# a variant is a launch form (fk_gemm_set_variant) with an optional MFMA shape suffix: "256m16" = 256 x 256 tiles on v_mfma_f32_16x16x32_bf16
+variants = [v for v in os.environ.get("AB_VARIANTS", "128,256,384,512,0,vendor").split(",")]
+
+
+def form_of(v):
+    return int(v.split("m")[0]), (int(v.split("m")[1]) if "m" in v else 32)
 for (M, N, K) in shapes:
     a = (torch.rand(M, K, device="cuda") * 2 - 1).to(BF)
     w = ((torch.rand(N, K, device="cuda") * 2 - 1) * 0.05).to(BF)
@@ -32,7 +37,8 @@ for (M, N, K) in shapes:
             if v == "vendor":
                 fn = lambda: torch.nn.functional.linear(a, w, b)  # noqa: E731
             else:
-                lib.fk_gemm_set_variant(v)
+                lib.fk_gemm_set_variant(form_of(v)[0])
+                lib.fk_gemm_set_mfma(form_of(v)[1])
                 fn = lambda: ops.gemm(a, w, b, out=out, epilogue=epi)  # noqa: E731
             fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -43,15 +49,16 @@ for (M, N, K) in shapes:
             e1.synchronize()
             if r:
                 res[v].append(fl * n_per / (e0.elapsed_time(e1) * 1e-3) / 1e12)
-            elif v != "vendor":   # first round: the variants must agree bit for bit (split-K pairs: to the last bits)
+            elif v != "vendor":   # first round: the variants must agree bit for bit (split-K pairs, other MFMA shape: to the last bits)
                 used[v] = lib.fk_gemm_last_variant()
                 if ref is None:
-                    ref = out.clone()
-                elif used[v] in (512, 640):
+                    ref, ref_m = out.clone(), form_of(v)[1]
+                elif used[v] in (512, 640) or form_of(v)[1] != ref_m:
                     d = (ref.float() - out.float()).abs().max().item()
                     assert d <= 2 ** -7 * ref.float().abs().max().item(), f"split-K differs by {d} on {M}x{N}x{K}"
                 else:
                     assert torch.equal(ref, out), f"variant {v} differs from variant 128 on {M}x{N}x{K}"
     lib.fk_gemm_set_variant(0)
-    print(f"{M}x{N}x{K} epi{epi}: " + "  ".join(f"{v}{'' if used.get(v, v) == v else '->' + str(used[v])}: med "
+    lib.fk_gemm_set_mfma(0)
+    print(f"{M}x{N}x{K} epi{epi}: " + "  ".join(f"{v}{'' if str(used.get(v, v)) == v.split('m')[0] else '->' + str(used[v])}: med "
                                                  f"{statistics.median(x):.0f} best {max(x):.0f}" for v, x in res.items()), flush=True)

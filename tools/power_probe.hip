@@ -44,8 +44,8 @@ __device__ __forceinline__ void stamp(Clocks* c, int which) {
 
 // ---- matrix pipe only -------------------------------------------------------------------------------------------------
 // NACC accumulator blocks per wave; every MFMA takes a different (a, b) pair of the 8 + 8 operand fragments the wave holds.
-template <int NT, int NACC>
-__global__ __launch_bounds__(NT) void mfma32_only(const bf16x8_t* __restrict__ src, float* out, int iters, Clocks* clk) {
+template <int NT, int NACC, int WPE = 1>   // WPE = 2 keeps the kernel in the 256-register (VGPR-form MFMA) budget: no AGPR copies in the loop
+__global__ __launch_bounds__(NT, WPE) void mfma32_only(const bf16x8_t* __restrict__ src, float* out, int iters, Clocks* clk) {
   bf16x8_t a[8], b[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -74,8 +74,8 @@ __global__ __launch_bounds__(NT) void mfma32_only(const bf16x8_t* __restrict__ s
   out[blockIdx.x * NT + threadIdx.x] = s;
 }
 
-template <int NT, int NACC>   // NACC 16 x 16 blocks (4 registers each); 128 MFMAs of 16 cycles per iteration = the same 2048 cycles
-__global__ __launch_bounds__(NT) void mfma16_only(const bf16x8_t* __restrict__ src, float* out, int iters, Clocks* clk) {
+template <int NT, int NACC, int WPE = 1>   // NACC 16 x 16 blocks (4 registers each); 128 MFMAs of 16 cycles per iteration = the same 2048 cycles
+__global__ __launch_bounds__(NT, WPE) void mfma16_only(const bf16x8_t* __restrict__ src, float* out, int iters, Clocks* clk) {
   bf16x8_t a[8], b[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -237,7 +237,7 @@ Result sustained(const char* name, double flops_per_launch, Launch launch, Clock
   std::sort(t2.begin(), t2.end());
   std::sort(g2.begin(), g2.end());
   Result r = {t2[t2.size() / 2], g2[g2.size() / 2]};
-  printf("%-44s first %7.1f  steady %7.1f TF/s  (%.3f of 2500)  clock %.3f GHz  [%zu samples]\n", name, tf[0], r.tflops,
+  printf("%-66s first %7.1f  steady %7.1f TF/s  (%.3f of 2500)  clock %.3f GHz  [%zu samples]\n", name, tf[0], r.tflops,
          r.tflops / 2500.0, r.ghz, tf.size());
   fflush(stdout);
   CHECK(hipEventDestroy(e0));
@@ -277,6 +277,11 @@ int main(int argc, char** argv) {
   sustained("mfma 16x16x32, 8 waves/CU, no LDS", f8, [&] { hipLaunchKernelGGL((mfma16_only<512, 32>), dim3(cus), dim3(512), 0, 0, d_src, d_out, iters, d_clk); }, d_clk, seconds);
   sustained("mfma 32x32x16, 4 waves/CU, no LDS", f4, [&] { hipLaunchKernelGGL((mfma32_only<256, 16>), dim3(cus), dim3(256), 0, 0, d_src, d_out, iters, d_clk); }, d_clk, seconds);
   sustained("mfma 16x16x32, 4 waves/CU, no LDS", f4, [&] { hipLaunchKernelGGL((mfma16_only<256, 64>), dim3(cus), dim3(256), 0, 0, d_src, d_out, iters, d_clk); }, d_clk, seconds);
+
+  // ONE wave per SIMD issuing MFMAs back to back from a small register set (the picture of a ping-pong group's MFMA phase:
+  // its partner wave issues no matrix work meanwhile): the single-wave issue cadence of the two shapes
+  sustained("mfma 32x32x16, 4 waves/CU, 8 acc blocks (single-wave cadence)", f4, [&] { hipLaunchKernelGGL((mfma32_only<256, 8, 2>), dim3(cus), dim3(256), 0, 0, d_src, d_out, iters, d_clk); }, d_clk, seconds);
+  sustained("mfma 16x16x32, 4 waves/CU, 32 acc blocks (single-wave cadence)", f4, [&] { hipLaunchKernelGGL((mfma16_only<256, 32, 2>), dim3(cus), dim3(256), 0, 0, d_src, d_out, iters, d_clk); }, d_clk, seconds);
 
   auto lds8 = [&](auto kern, int extra) {
     CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 4096 + extra));
