@@ -1125,8 +1125,11 @@ extern "C" int fk_gemm_set_plan(int32_t allow) {
 // MFMA shape of the layout-0 large-tile kernels: 32 = v_mfma_f32_32x32x16_bf16, 16 = v_mfma_f32_16x16x32_bf16 (FragMap above).
 // The two differ in the last bits (16 against 32 products per hardware sum); every launch form of ONE shape agrees bit
 // for bit with the others.  FK_GEMM_MFMA=16|32 or fk_gemm_set_mfma(); the K-major layouts (1, 2) always use 32.
+// Default 16 (round 5): +3.1 .. +4.1 % on every launch form of the M = 2560 QKV / MLP-up shapes, interleaved in one process
+// (profiles/r05_gemm_mfma_ab.txt); one wave per SIMD issues the 4-pass instruction every 17.3 cycles instead of 16, which is
+// why the ping-pong kernels keep 2/3 of the pure-MFMA stream's 12 %.
 #ifndef FK_GEMM_MFMA_DEFAULT
-#define FK_GEMM_MFMA_DEFAULT 32
+#define FK_GEMM_MFMA_DEFAULT 16
 #endif
 static int g_mfma = -1;
 static int gemm_mfma() {
