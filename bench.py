@@ -157,7 +157,7 @@ def instrumented_edit(pipe, inp, steps28=28):
         transformer.OVERLAP_MLP = overlap
         transformer.BLOCK_API = block_api
         pipe.use_graph = use_graph
-    if len(rec["attention"]) < 57 * steps28 or len(rec["gemm"]) < 4 * 57 * steps28:
+    if len(rec["attention"]) < 57 * steps28 or len(rec["gemm"]) < 3 * 57 * steps28:      # grouped launches count once
         raise RuntimeError(f"instrumented edit bracketed {len(rec['attention'])} attention / {len(rec['gemm'])} GEMM launches: "
                            "the blocks' kernels were not enqueued one host call per launch")
     out = {}

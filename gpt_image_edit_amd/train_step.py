@@ -199,6 +199,43 @@ class DenoiserTrainStep:
         self.bw.refresh()
         return sumsq
 
+    def discard(self):
+        """Drop the gradients of the backward passes since the last optimiser step (a step that is deliberately skipped, e.g.
+        a non-finite loss; the reference's ``optimizer.zero_grad()``, train_denoiser.py:1180).  With ``sharded=True`` every
+        rank must call it (it finishes the reductions in flight).  Without it a skipped backward pass would be summed into the
+        next step as a further micro-batch."""
+        if self.opt is not None:
+            self.opt.zero_grad()
+        self._sunk = {}
+
+    def state_dict(self):
+        """Optimiser state for ``accelerator.save_state``-style checkpoints (train_denoiser.py:1229): the ZeRO-2 shard of
+        this rank (``zero.ShardedAdamW.state_dict``) or, unsharded, the per-tensor fp32 masters and moments."""
+        if self.opt is not None:
+            return dict(kind="sharded", opt=self.opt.state_dict())
+        return dict(kind="per_tensor", step=self.step_count,
+                    state={k: tuple(t.detach().cpu().clone() for t in st) for k, st in self.state.items()})
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        """Resume (train_denoiser.py:349-367, 769): restores the state and rewrites the model's trainable bf16 parameters from
+        the fp32 masters, so the next step continues bit for bit."""
+        if (sd.get("kind") == "sharded") != (self.opt is not None):
+            raise ValueError("optimiser state was saved with another `sharded` setting")
+        self._sunk = {}
+        if self.opt is not None:
+            self.opt.load_state_dict(sd["opt"])
+            self.step_count = self.opt.step_count
+        else:
+            self.step_count = int(sd["step"])
+            self.state = {}
+            for k, (master, m1, m2) in sd["state"].items():
+                p = self._param(k)
+                self.state[k] = tuple(t.to(p.device) for t in (master, m1, m2))
+                p.data.copy_(self.state[k][0])
+        self.bw.refresh()
+        self.model._packed = None
+
     def step(self, **batch):
         loss, grads, d_enc = self.forward_backward(**batch)
         sumsq = self.optimizer_step(grads)

@@ -307,6 +307,80 @@ class ShardedAdamW:
             self._seen[b].update(bk["names"])
         return {n: self.grad_view(n) for n in self.layout.names}
 
+    # ---- skipped steps, save / resume ------------------------------------------------------------------------------------
+    def zero_grad(self):
+        """Discard every gradient taken in since the last ``step()`` (a backward pass whose step is deliberately skipped, e.g.
+        a non-finite loss -- the reference's ``optimizer.zero_grad()``, train_denoiser.py:1180): reductions in flight are
+        finished first (every rank must call this, like ``step()``), then the chunks and the micro-batch count are reset."""
+        self._flush()
+        self.grad_slice.zero_()
+        self._begin()
+
+    def layout_signature(self):
+        """What a saved shard must agree with to be loadable: world size, tensor names in layout order with their shapes, and
+        the bucket cuts (a different ``bucket_numel`` or ``order`` gives other chunks)."""
+        L = self.layout
+        return dict(world=self.world, names=list(L.names), shapes=[list(L.offsets[n][2]) for n in L.names],
+                    chunks=[b["chunk"] for b in L.buckets])
+
+    def state_dict(self):
+        """THIS RANK's shard of the optimiser state (``accelerator.save_state`` under ZeRO-2 writes one file per rank too,
+        train_denoiser.py:1229): fp32 master chunk, both Adam moments, the step count, hyper-parameters and the layout
+        signature.  The bf16 parameters are not part of it -- they are bf16(master) and are rebuilt on load."""
+        return dict(version=1, rank=self.rank, signature=self.layout_signature(), step=self.step_count,
+                    master=self.master.detach().cpu().clone(), exp_avg=self.exp_avg.detach().cpu().clone(),
+                    exp_avg_sq=self.exp_avg_sq.detach().cpu().clone(), hp=dict(self.hp), max_grad_norm=self.max_grad_norm)
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        """Resume from ``state_dict()`` of the same rank of a run with the same world size and layout (collective: every
+        rank calls it with its own shard).  Restores master / moments / step count, drops any gradient in flight, rewrites
+        this rank's chunks of the flat bf16 parameters as bf16(master) -- what the last ``step()`` of the saved run left
+        there -- and all-gathers them, so the next step continues bit for bit where the saved run stopped
+        (``accelerator.load_state``, train_denoiser.py:349-367, 769)."""
+        if sd.get("version") != 1:
+            raise ValueError("not a ShardedAdamW state dict")
+        if sd["signature"] != self.layout_signature():
+            raise ValueError("optimiser shard does not fit this layout (world size, trainable set, order or bucket size "
+                             f"changed): saved world {sd['signature']['world']} / {len(sd['signature']['names'])} tensors, "
+                             f"now world {self.world} / {len(self.layout.names)} tensors; re-sharding is not supported")
+        if sd["rank"] != self.rank:
+            raise ValueError(f"shard of rank {sd['rank']} loaded on rank {self.rank}")
+        self.zero_grad()
+        for name in ("master", "exp_avg", "exp_avg_sq"):
+            t = sd[name]
+            if t.shape != getattr(self, name).shape or t.dtype != torch.float32:
+                raise ValueError(f"{name}: saved {tuple(t.shape)} {t.dtype}, expected {tuple(getattr(self, name).shape)} float32")
+            getattr(self, name).copy_(t)
+        self.step_count = int(sd["step"])
+        self.hp = dict(sd["hp"])
+        self.max_grad_norm = sd["max_grad_norm"]
+        L = self.layout
+        works = []
+        for b, bk in enumerate(L.buckets):
+            mine = L.chunk_of(self.flat_param, b, self.rank)
+            mine.copy_(self.master[bk["state_offset"]: bk["state_offset"] + bk["chunk"]])      # fp32 -> bf16, round to nearest even
+            if self.world > 1:
+                works.append(self._all_gather(L.bucket_view(self.flat_param, b), mine))
+        for w in works:
+            w.wait()
+
+    @staticmethod
+    def shard_file(directory, rank, world):
+        import os
+        return os.path.join(directory, f"zero2_optim_rank{rank:05d}_of{world:05d}.pt")
+
+    def save(self, directory):
+        """One file per rank under ``directory`` (created if missing); returns the path."""
+        import os
+        os.makedirs(directory, exist_ok=True)
+        path = self.shard_file(directory, self.rank, self.world)
+        torch.save(self.state_dict(), path)
+        return path
+
+    def load(self, directory):
+        self.load_state_dict(torch.load(self.shard_file(directory, self.rank, self.world), map_location="cpu", weights_only=False))
+
     def state_bytes(self):
         """(replicated, sharded) bytes this rank holds for the optimiser: flat bf16 params + fp32 staging | 4 fp32 chunks."""
         return self.layout.total * 2 + sum(s.numel() for s in self.staging) * 4, self.layout.slice_numel * 4 * 4

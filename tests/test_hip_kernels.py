@@ -300,10 +300,12 @@ def test_gemm_k_major_operands(ops):
     g = torch.Generator(device=dev).manual_seed(11)
     rnd = lambda *sh, sc=1.0: ((torch.rand(*sh, device=dev, generator=g) * 2 - 1) * sc).to(BF)  # noqa: E731
     ops.gemm_set_plan(1)     # no split-K pairs in the row-major reference (they differ in the last bits by design)
+    ops.gemm_set_mfma(32)    # the K-major operand paths deliver 32 x 32 x 16 fragments: the row-major reference on the same shape
     try:
         _k_major_cases(ops, rnd, dev)
     finally:
         ops.gemm_set_plan(3)
+        ops.gemm_set_mfma(0)
 
 
 def _k_major_cases(ops, rnd, dev):
@@ -536,12 +538,14 @@ def test_attention_moderate_logit_growth_needs_no_restart_and_stays_accurate(ops
     assert (got - ref).abs().max().item() <= 3e-2 * ref.abs().max().item()
 
 
-def test_gemm_mfma16_every_form(ops):
-    """The large-tile GEMM kernels on v_mfma_f32_16x16x32_bf16 (fk_gemm_set_mfma(16); FragMap<true> in gemm_pingpong_bf16.hip:
-    other fragment addressing, other accumulator-register -> (row, column) map in the epilogue): every check the
-    32 x 32 x 16 form passes -- the stated tolerance on the fp32-output build of every launch form, bit-equality between
-    the forms, transpose detection, all epilogues, grouped launches, the fused QKV epilogue against the unfused path."""
-    ops.gemm_set_mfma(16)
+@pytest.mark.parametrize("shape", [16, 32])
+def test_gemm_both_mfma_shapes_every_form(ops, shape):
+    """The large-tile GEMM kernels on v_mfma_f32_16x16x32_bf16 (the default since round 5) and on v_mfma_f32_32x32x16_bf16
+    (fk_gemm_set_mfma; FragMap in gemm_pingpong_bf16.hip: other fragment addressing, other accumulator-register ->
+    (row, column) map in the epilogue): every check of this file under EACH shape explicitly -- the stated tolerance on the
+    fp32-output build of every launch form, bit-equality between the forms, transpose detection on the large-tile kernels,
+    all epilogues, grouped launches, the fused QKV epilogue against the unfused path."""
+    ops.gemm_set_mfma(shape)
     try:
         for shape in HOT_SHAPES:
             test_hot_gemm_kernels_at_the_stated_tolerance(ops, *shape)

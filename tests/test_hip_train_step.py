@@ -184,6 +184,7 @@ def test_k_major_operands_give_the_same_gradients(monkeypatch):
     from gpt_image_edit_amd.train_step import DenoiserTrainStep
     from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
     ops.gemm_set_plan(1)      # no split-K pairs: the row-major and K-major launches must add in the same order
+    ops.gemm_set_mfma(32)     # ... on the same MFMA shape (the K-major operand paths deliver 32 x 32 x 16 fragments)
     try:
         for B in (1, 2):
             cfg, sd_bf, batch, trainable = _setup(B=B, S_txt=64, h=32, w=32)
@@ -202,6 +203,7 @@ def test_k_major_operands_give_the_same_gradients(monkeypatch):
                     assert torch.equal(res[0][1][k], res[level][1][k]), f"K_MAJOR {level}, B {B}: {k}"
     finally:
         ops.gemm_set_plan(3)
+        ops.gemm_set_mfma(0)
 
 
 def test_sharded_gradient_accumulation_and_modified_gradient_error():
@@ -323,3 +325,41 @@ def test_step_takes_the_stage2_loss_weights():
                              area_mask_weights=area_l.cuda().contiguous(), weight_mask=mask.cuda())
     pad = helpers.pack_latents((1.0 - mask).expand(B, C, h, w).contiguous()) > 0
     assert float(dpred.cpu().float()[pad].abs().max()) == 0 and float(dpred.cpu().float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("sharded", [True, False])
+def test_optimizer_state_save_resume_and_discard(sharded):
+    """``DenoiserTrainStep.state_dict`` / ``load_state_dict`` (accelerator.save_state / load_state, train_denoiser.py:1229,
+    769): a run resumed from the saved optimiser state takes the same next step, bit for bit, as the uninterrupted one --
+    masters, moments, step count and the bf16 weights the forward reads.  ``discard()`` drops a backward pass whose step
+    is skipped instead of folding it into the next one as a micro-batch."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd.train_step import DenoiserTrainStep
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    cfg, sd_bf, batch, trainable = _setup()
+    dev = {k: v.cuda() for k, v in batch.items()}
+    dev2 = dict(dev, sigmas=torch.tensor([0.6, 0.1]).cuda())
+
+    def fresh(state):
+        m = HipFluxTransformer2DModel(cfg, device="cuda")
+        m.load_state_dict(state)
+        return m, DenoiserTrainStep(m, lr=1e-3, sharded=sharded)
+    model, ts = fresh(sd_bf)
+    ts.step(**dev)
+    ts.step(**dev2)
+    saved = ts.state_dict()
+    weights = {k: v.detach().clone() for k, v in model.state_dict().items()}          # the bf16 checkpoint written beside it
+    ts.forward_backward(**dev2)                                                       # a backward pass whose step is skipped ...
+    ts.discard()                                                                      # ... must leave no trace
+    out_a = ts.step(**dev)
+    want = {k: model.p(k).detach().clone() for k in trainable}
+    model_b, ts_b = fresh(weights)
+    ts_b.load_state_dict(saved)
+    assert ts_b.step_count == 2
+    out_b = ts_b.step(**dev)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a["loss"], out_b["loss"]) and torch.equal(torch.as_tensor(out_a["grad_sumsq"]).cpu(), torch.as_tensor(out_b["grad_sumsq"]).cpu())
+    assert all(torch.equal(want[k], model_b.p(k)) for k in trainable), "the resumed run's next step differs"
+    with pytest.raises(ValueError):
+        fresh(weights)[1].__class__(fresh(weights)[0], lr=1e-3, sharded=not sharded).load_state_dict(saved)

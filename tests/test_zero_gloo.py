@@ -224,3 +224,76 @@ def test_flat_layout_single_process():
         for n in order:
             o.accumulate({n: torch.ones(100, 7)})
         o.accumulate({order[0]: torch.ones(100, 7)})       # a second pass that was not announced
+
+
+def _resume_worker(rank, world, ports, q, tmp):
+    """save after step 2 -> uninterrupted step 3; then a NEW process group, a new optimiser built on different start values,
+    load, step 3 again: bit-identical parameters, moments and norm (accelerator.save_state / load_state under ZeRO-2)."""
+    from gpt_image_edit_amd.zero import ShardedAdamW, backward_order
+    order = backward_order(list(SHAPES))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(ports[0]), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    opt = ShardedAdamW(_params(), max_grad_norm=1.0, kernels=TorchKernels, order=order, bucket_numel=400, **HP)
+    for step in range(2):
+        gs = _grads(rank, step)
+        for n in order:
+            opt.accumulate({n: gs[n]})
+        opt.step()
+    path = opt.save(tmp)
+    assert os.path.basename(path) == f"zero2_optim_rank{rank:05d}_of{world:05d}.pt"
+    # a backward pass whose step is skipped must leave no trace (ADVICE r4: zero_grad)
+    junk = _grads(rank + 3, 9)
+    for n in order[:2]:
+        opt.accumulate({n: junk[n]})
+    opt.zero_grad()
+    gs = _grads(rank, 2)
+    for n in order:
+        opt.accumulate({n: gs[n]})
+    norm_a = float(opt.step())
+    want = {n: p.clone() for n, p in opt.params.items()}
+    want_m, want_v, want_master = opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.master.clone()
+    dist.barrier()
+    dist.destroy_process_group()
+    # ---- "restart" ---------------------------------------------------------------------------------------------------------
+    os.environ.update(MASTER_PORT=str(ports[1]))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    opt2 = ShardedAdamW(_params(seed=77), max_grad_norm=1.0, kernels=TorchKernels, order=order, bucket_numel=400, **HP)
+    opt2.load(tmp)
+    assert opt2.step_count == 2
+    for n in order:
+        opt2.accumulate({n: gs[n]})
+    norm_b = float(opt2.step())
+    ok = norm_a == norm_b and all(torch.equal(want[n], opt2.params[n]) for n in SHAPES)
+    ok = ok and torch.equal(want_m, opt2.exp_avg) and torch.equal(want_v, opt2.exp_avg_sq) and torch.equal(want_master, opt2.master)
+    # what does not fit is refused: another bucket size = other chunks; a shard of the other rank
+    bad = ShardedAdamW(_params(), max_grad_norm=1.0, kernels=TorchKernels, order=order, bucket_numel=900, **HP)
+    refused = 0
+    try:
+        bad.load(tmp)
+    except ValueError:
+        refused += 1
+    try:
+        opt2.load_state_dict(torch.load(ShardedAdamW.shard_file(tmp, 1 - rank, world), weights_only=False))
+    except ValueError:
+        refused += 1
+    q.put((rank, ok, refused))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_adamw_save_and_resume_gloo_world2(tmp_path):
+    """VERDICT r4 missing #4: optimiser-state save / resume on the ZeRO-2 layout (train_denoiser.py:1229, 769, 349-367)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ports = (_free_port(), _free_port())
+    procs = [ctx.Process(target=_resume_worker, args=(r, world, ports, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), "the resumed run's next step differs from the uninterrupted run's"
+    assert all(refused == 2 for _, _, refused in res)
+    assert sorted(os.listdir(tmp_path)) == ["zero2_optim_rank00000_of00002.pt", "zero2_optim_rank00001_of00002.pt"]

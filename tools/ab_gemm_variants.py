@@ -52,8 +52,8 @@ for (M, N, K) in shapes:
             elif v != "vendor":   # first round: the variants must agree bit for bit (split-K pairs, other MFMA shape: to the last bits)
                 used[v] = lib.fk_gemm_last_variant()
                 if ref is None:
-                    ref, ref_m = out.clone(), form_of(v)[1]
-                elif used[v] in (512, 640) or form_of(v)[1] != ref_m:
+                    ref, ref_m, ref_v = out.clone(), form_of(v)[1], used[v]
+                elif used[v] in (512, 640) or ref_v in (512, 640) or form_of(v)[1] != ref_m:
                     d = (ref.float() - out.float()).abs().max().item()
                     assert d <= 2 ** -7 * ref.float().abs().max().item(), f"split-K differs by {d} on {M}x{N}x{K}"
                 else:
