@@ -29,6 +29,7 @@ from types import SimpleNamespace
 
 import torch
 
+from .param_tree import raw_write_epoch
 from . import ops
 
 BF16 = torch.bfloat16
@@ -101,7 +102,9 @@ class FluxBackward:
         """W^T for the data gradient, re-made when its source was rewritten (an optimiser step bumps the parameter's
         version; a re-pack of the fused QKV weights gets a new serial)."""
         if stamp is None:
-            stamp = (w.data_ptr(), w._version)
+            # + the count of raw-pointer parameter writes (fk_adamw_step bumps no torch version): a cached transpose of a
+            # trainable weight is re-made after an optimiser step even when the caller skipped refresh()
+            stamp = (w.data_ptr(), w._version, raw_write_epoch())
         hit = self._wT.get(key)
         if hit is None or hit[1] != stamp:
             t = hit[0] if hit is not None else torch.empty((w.shape[1], w.shape[0]), device=w.device, dtype=BF16)

@@ -158,16 +158,27 @@ def gemm(a, w, bias=None, out=None, epilogue=FK_EPI_NONE, res=None, gate=None, o
     return out
 
 
+_LAUNCH_CFG_EPOCH = [0]
+
+
+def launch_config_epoch():
+    """Bumped by every launch-plan / kernel-form setter of this module: anything that froze host-side launch decisions (a
+    captured hipGraph of the denoise loop) keys on it."""
+    return _LAUNCH_CFG_EPOCH[0]
+
+
 def gemm_set_plan(allow):
     """fk_gemm_set_plan: bit 0 = mixed grids (bit-identical results), bit 1 = split-K pairs (last-bit differences against
     the unsplit sum, so a sample's result then depends on how full the grid is).  ``gemm_set_plan(1)`` = batch-invariant."""
     libfk.check(libfk.load().fk_gemm_set_plan(int(allow)), "fk_gemm_set_plan")
+    _LAUNCH_CFG_EPOCH[0] += 1
 
 
 def gemm_set_mfma(shape):
     """MFMA shape of the layout-0 large-tile GEMM kernels: 32 (v_mfma_f32_32x32x16_bf16), 16 (v_mfma_f32_16x16x32_bf16) or
     0 = the built default.  The two differ in the last bits; see include/fk.h."""
     libfk.check(libfk.load().fk_gemm_set_mfma(int(shape)), "fk_gemm_set_mfma")
+    _LAUNCH_CFG_EPOCH[0] += 1
 
 
 def gemm_grouped(problems, epilogue=FK_EPI_NONE):
@@ -250,6 +261,7 @@ def attention_workspace(device):
 def attention_set_split(mode):
     """fk_attention_set_split: 1 = stream-K grids where the plain grid wastes a round (default), 0 = never (batch-invariant)."""
     libfk.check(libfk.load().fk_attention_set_split(int(mode)), "fk_attention_set_split")
+    _LAUNCH_CFG_EPOCH[0] += 1
 
 
 def attention(q, k, v, out, scale=None, lse=None):
@@ -502,6 +514,7 @@ def rowdot(a, c, heads, out=None):
 def attention_bwd_set_mode(mode):
     """fk_attention_bwd_set_mode: 1 = dQ pass + paired dK / dV pass (default), 0 = three passes."""
     libfk.check(libfk.load().fk_attention_bwd_set_mode(int(mode)), "fk_attention_bwd_set_mode")
+    _LAUNCH_CFG_EPOCH[0] += 1
 
 
 def attention_bwd(q, k, v, dout, lse, dsum, dq, dk, dv, scale=None):

@@ -307,7 +307,7 @@ class FluxKontextPipeline:
                             do_true_cfg=do_true_cfg, true_cfg_scale=true_cfg_scale, jak=joint_attention_kwargs or {},
                             geom=(height, width, None if image is None else tuple(image.shape[-2:])),
                             dsigma=[self.scheduler.dsigma(i) for i in range(len(timesteps))])
-        if self.use_graph and callback_on_step_end is None and not joint_attention_kwargs:
+        if self.use_graph and callback_on_step_end is None and not joint_attention_kwargs and not self._interrupt:
             tokens = self._denoise_graph(L)
         else:
             self._denoise(L, callback_on_step_end, timesteps)
@@ -355,9 +355,14 @@ class FluxKontextPipeline:
         are copied into the graph's own (a few MB); everything the host decides during an eager pass -- launch plans,
         cached RoPE tables, the rows of the prepared conditioning, the Euler step sizes -- is frozen into the graph and
         therefore part of its key.  Returns the token buffer the graph updates."""
+        # weights rewritten in place since the last forward (load_state_dict, a LoRA merge, an optimiser step): packed() checks
+        # the source parameters' version stamps, re-packs the fused copies if needed and bumps the serial the key carries --
+        # a replay never mixes fresh unfused weights with stale fused ones
+        if hasattr(self.transformer, "packed"):
+            self.transformer.packed()
         key = (tuple(L.tokens.shape), tuple(L.embeds.shape), tuple(L.latent_ids.shape), L.geom, L.do_true_cfg,
                float(L.true_cfg_scale), tuple(L.dsigma), L.guidance is None, L.S_tgt,
-               getattr(self.transformer, "_pack_serial", 0))
+               getattr(self.transformer, "_pack_serial", 0), ops.launch_config_epoch())
         cur = torch.cuda.current_stream()
         if self._loop_graph is None or self._loop_graph[0] != key:
             self._loop_graph = None
@@ -381,7 +386,9 @@ class FluxKontextPipeline:
             if t is not None:
                 getattr(G, n).copy_(t)
         graph.replay()
-        return G.tokens
+        # the graph's own buffer is overwritten by the next same-shape call: hand out a copy, as the eager path hands out
+        # fresh tensors (results of consecutive calls -- a list of latents, the DP gather -- must stay distinct)
+        return G.tokens.clone()
 
     @staticmethod
     def postprocess(image, output_type="pil"):

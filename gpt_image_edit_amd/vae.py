@@ -278,13 +278,19 @@ class HipAutoencoderKL(ParamTreeMixin, nn.Module):
         n = self._gn32(p + "group_norm", x, False).view(B * S, P * C)
         wqkv, bqkv = pk[p + "qkv"]
         qkv = ops.gemm(n, wqkv, bqkv, out_fp32=True).view(B, S, 3 * C)              # fp32
+        if S % 4 != 0:
+            raise ValueError(f"fp32-class mid-block attention: {H} x {W} = {S} positions, the part kernels need a multiple of 4")
         S_pad = (S + 63) // 64 * 64
-        qp = torch.empty((S, 3 * C), device=dev, dtype=BF16)
-        kp = torch.empty((S, 3 * C), device=dev, dtype=BF16)
-        vp = torch.empty((S, 2 * C), device=dev, dtype=BF16)
-        scores = torch.empty((S, S_pad), device=dev, dtype=torch.float32)
-        probs = torch.zeros((S, 3 * S_pad), device=dev, dtype=BF16)
-        vt = torch.zeros((1, C, 3 * S_pad), device=dev, dtype=BF16)
+        # scores (fp32 S x S) and the probability parts are 1 GiB + 1.5 GiB at 1024^2: kept per shape, and the padding columns
+        # of probs / vt are zeroed ONCE (the kernels write columns < S only) instead of a 1.5 GiB memset per call
+        ws = self.__dict__.setdefault("_mid32_ws", {})
+        key = (S, C, str(dev))
+        if key not in ws:
+            ws.clear()                                                                  # one shape at a time: bounded memory
+            ws[key] = (torch.empty((S, 3 * C), device=dev, dtype=BF16), torch.empty((S, 3 * C), device=dev, dtype=BF16),
+                       torch.empty((S, 2 * C), device=dev, dtype=BF16), torch.empty((S, S_pad), device=dev, dtype=torch.float32),
+                       torch.zeros((S, 3 * S_pad), device=dev, dtype=BF16), torch.zeros((1, C, 3 * S_pad), device=dev, dtype=BF16))
+        qp, kp, vp, scores, probs, vt = ws[key]
         o = torch.empty((B, S, C), device=dev, dtype=torch.float32)
         for b in range(B):
             ops.split_f32_rows(qkv[b, :, :C], qp, parts=3)                           # (hi, lo, hi)

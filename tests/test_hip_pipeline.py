@@ -327,3 +327,27 @@ def test_graph_captured_loop_gives_the_same_bits():
     seen = []
     edit(graphed, 6, steps=3, callback_on_step_end=lambda p, i, t, kw: seen.append(i) or {})
     assert seen == [0, 1, 2]
+    # results of consecutive graph calls must stay distinct (the graph's static buffer is not handed out) ...
+    def latent_only(pipe, seed):
+        g = torch.Generator().manual_seed(seed)
+        noise = torch.randn(1, 16, H // 8, W // 8, generator=g).to(BF)
+        return pipe(image=(torch.rand(1, 3, H, W, generator=g) * 2 - 1).cuda(), prompt_embeds=torch.randn(1, 300, 4096, generator=g).to(BF).cuda(),
+                    pooled_prompt_embeds=torch.randn(1, 768, generator=g).to(BF).cuda(), height=H, width=W, num_inference_steps=6,
+                    guidance_scale=3.5, latents=pipe._pack_latents(noise, 1, 16, H // 8, W // 8).cuda(), output_type="latent",
+                    max_area=H * W, _auto_resize=False)
+    first = latent_only(graphed, 11)
+    keep_l, keep_i = first.latents.clone(), first.images.clone()
+    second = latent_only(graphed, 12)
+    torch.cuda.synchronize()
+    assert first.latents.data_ptr() != second.latents.data_ptr() and first.images.data_ptr() != second.images.data_ptr()
+    assert torch.equal(first.latents, keep_l) and torch.equal(first.images, keep_i) and not torch.equal(second.latents, keep_l)
+    # ... and a weight rewritten in place between two graph calls must reach the replay (no stale fused QKV copy)
+    before = latent_only(graphed, 13).latents.clone()
+    w = tr.p("transformer_blocks.0.attn.to_q.weight")
+    with torch.no_grad():
+        w.mul_(0.5)                                 # in place: bumps the parameter's version, like load_state_dict / an optimiser
+    after_g = latent_only(graphed, 13).latents.clone()
+    after_e = latent_only(eager, 13).latents.clone()
+    with torch.no_grad():
+        w.mul_(2.0)
+    assert not torch.equal(before, after_g) and torch.equal(after_g, after_e)
