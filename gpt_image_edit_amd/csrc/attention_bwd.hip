@@ -731,16 +731,6 @@ int launch_dkv(const BwdParams& p, hipStream_t stream) {
   return FK_OK;
 }
 
-// 1 = dQ pass + paired dK/dV pass (default), 0 = three passes; FK_ATTN_BWD overrides, fk_attention_bwd_set_mode sets
-int g_bwd_mode = -1;
-int bwd_mode() {
-  if (g_bwd_mode < 0) {
-    const char* e = getenv("FK_ATTN_BWD");
-    g_bwd_mode = e ? (atoi(e) != 0) : 1;
-  }
-  return g_bwd_mode;
-}
-
 bool view_ok(const fk_attn_view& v, int64_t S) {
   return v.p && ((uintptr_t)v.p % 16 == 0) && v.ld > 0 && v.ld % 8 == 0 && v.head_stride % 8 == 0 && v.batch_stride % 8 == 0 &&
          ((S - 1) * v.ld + HD) * 2 < (1ll << 31) && (S + CBLK) * v.ld * 2 < (1ll << 31);
@@ -749,13 +739,14 @@ TView tv(const fk_attn_view& v) { return TView{(const bf16_t*)v.p, v.ld, v.head_
 
 }  // namespace
 
-int fk_attention_split_mode(void);   // attention_fwd.hip: fk_attention_set_split / FK_ATTN_SPLIT
-
 static int attention_bwd_entry(const fk_attn_view* q, const fk_attn_view* k, const fk_attn_view* v,
                                const fk_attn_view* dout, const float* lse, const float* dsum, const fk_attn_view* dq,
                                const fk_attn_view* dk, const fk_attn_view* dv, int32_t B, int32_t H, int32_t S,
-                               float scale, void* ws, int64_t ws_bytes, fk_stream_t stream_) {
+                               float scale, void* ws, int64_t ws_bytes, int grid, int passes, fk_stream_t stream_) {
   FK_CHECK_ARG(q && k && v && dout && lse && dsum && dq && dk && dv, "fk_attention_bwd_bf16: null pointer");
+  FK_CHECK_ARG(grid >= -1 && grid != 1, "fk_attention_bwd_ws_bf16: grid %d is not 0 (default), -1 (plain grid) or a workgroup count >= 2", grid);
+  FK_CHECK_ARG(passes == 0 || passes == 2 || passes == 3, "fk_attention_bwd_ws_bf16: passes %d is not 0 / 2 (dQ pass + paired dK / dV "
+               "pass) or 3 (three passes)", passes);
   FK_CHECK_ARG(B > 0 && H > 0 && S > 0, "fk_attention_bwd_bf16: bad B/H/S %d %d %d", B, H, S);
   const fk_attn_view* all[7] = {q, k, v, dout, dq, dk, dv};
   for (const fk_attn_view* a : all)
@@ -775,7 +766,7 @@ static int attention_bwd_entry(const fk_attn_view* q, const fk_attn_view* k, con
   int rc;
   {
     const int64_t n_items = (int64_t)((S + 255) / 256) * H * B, nt = (S + CBLK - 1) / CBLK;
-    const int mode = fk_attention_split_mode();
+    const int mode = grid == 0 ? 1 : (grid < 0 ? 0 : grid);
     const int G = mode >= 2 ? (mode < bwd_cu_count() ? mode : bwd_cu_count()) : bwd_cu_count();
     const int64_t rounds = (n_items + G - 1) / G;
     const bool wasteful = mode >= 2 || (n_items > G && (rounds * G - n_items) * 25 >= rounds * G);
@@ -793,7 +784,7 @@ static int attention_bwd_entry(const fk_attn_view* q, const fk_attn_view* k, con
     }
   }
   if (rc != FK_OK) return rc;
-  if (bwd_mode() != 0) {
+  if (passes != 3) {
     set_out(*dk);
     p.out2 = (bf16_t*)dv->p; p.o2_ld = dv->ld; p.o2_hs = dv->head_stride; p.o2_bs = dv->batch_stride;
     return launch_dkv(p, stream);
@@ -809,18 +800,12 @@ extern "C" int fk_attention_bwd_bf16(const fk_attn_view* q, const fk_attn_view* 
                                      const fk_attn_view* dout, const float* lse, const float* dsum, const fk_attn_view* dq,
                                      const fk_attn_view* dk, const fk_attn_view* dv, int32_t B, int32_t H, int32_t S,
                                      float scale, fk_stream_t stream_) {
-  return attention_bwd_entry(q, k, v, dout, lse, dsum, dq, dk, dv, B, H, S, scale, nullptr, 0, stream_);
+  return attention_bwd_entry(q, k, v, dout, lse, dsum, dq, dk, dv, B, H, S, scale, nullptr, 0, 0, 0, stream_);
 }
 
 extern "C" int fk_attention_bwd_ws_bf16(const fk_attn_view* q, const fk_attn_view* k, const fk_attn_view* v,
                                         const fk_attn_view* dout, const float* lse, const float* dsum, const fk_attn_view* dq,
                                         const fk_attn_view* dk, const fk_attn_view* dv, int32_t B, int32_t H, int32_t S,
-                                        float scale, void* ws, int64_t ws_bytes, fk_stream_t stream_) {
-  return attention_bwd_entry(q, k, v, dout, lse, dsum, dq, dk, dv, B, H, S, scale, ws, ws_bytes, stream_);
-}
-
-extern "C" int fk_attention_bwd_set_mode(int32_t mode) {
-  FK_CHECK_ARG(mode == 0 || mode == 1, "fk_attention_bwd_set_mode: %d is not 0 (three passes) or 1 (dQ pass + paired dK / dV pass)", mode);
-  g_bwd_mode = mode;
-  return FK_OK;
+                                        float scale, void* ws, int64_t ws_bytes, int32_t grid, int32_t passes, fk_stream_t stream_) {
+  return attention_bwd_entry(q, k, v, dout, lse, dsum, dq, dk, dv, B, H, S, scale, ws, ws_bytes, grid, passes, stream_);
 }

@@ -683,15 +683,8 @@ int launch(const AttnParams& p, int grid, hipStream_t stream) {
 // contiguous ranges, so every CU works the same time and an item that straddles two CUs is finished by whichever of the
 // two arrives second (kernel, "stream-K seam").  Used when the plain grid would waste >= 4 % of its rounds and the items
 // are long enough that each is cut at most once.  An item's bits then depend on WHERE it is cut, i.e. on the grid:
-// fk_attention_set_split(0) / FK_ATTN_SPLIT=0 ("batch-invariant", like fk_gemm_set_plan(1)) keeps the plain grid.
-static int g_attn_split = -1;
-static int attn_split_mode() {
-  if (g_attn_split < 0) {
-    const char* e = getenv("FK_ATTN_SPLIT");
-    g_attn_split = e ? (atoi(e) < 0 ? 0 : atoi(e)) : 1;
-  }
-  return g_attn_split;
-}
+// `grid` = -1 of fk_attention_fwd_ws_bf16 ("batch-invariant", like fk_gemm_args.plan = FK_GEMM_PLAN_BATCH_INVARIANT) keeps
+// the plain grid.  The choice comes with the CALL: the library keeps no launch state.
 static int attn_cu_count() {
   static int cus = 0;
   if (!cus) {
@@ -721,7 +714,9 @@ static bool use_interleaved(const AttnParams& p) {
 
 int attention_entry(const void* q, const void* k, const void* v, void* o, int32_t B, int32_t H, int32_t S, int64_t v_ld,
                     int64_t v_batch_stride, int64_t o_ld, int64_t o_batch_stride, float scale, bool f32out,
-                    hipStream_t stream, float* lse = nullptr, void* ws = nullptr, int64_t ws_bytes = 0) {
+                    hipStream_t stream, float* lse = nullptr, void* ws = nullptr, int64_t ws_bytes = 0, int grid = 0) {
+  FK_CHECK_ARG(grid >= -1 && grid != 1, "fk_attention_fwd_ws_bf16: grid %d is not 0 (stream-K grid where the plain one wastes a round), "
+               "-1 (always one workgroup per 256-row block) or a workgroup count >= 2 (test hook)", grid);
   FK_CHECK_ARG(q && k && v && o, "fk_attention_fwd_bf16: null pointer");
   FK_CHECK_ARG(B > 0 && H > 0 && S > 0, "fk_attention_fwd_bf16: bad B/H/S %d %d %d", B, H, S);
   FK_CHECK_ARG(o_ld % 4 == 0 && o_batch_stride % 4 == 0 && ((uintptr_t)o % (f32out ? 16 : 8) == 0),
@@ -747,7 +742,7 @@ int attention_entry(const void* q, const void* k, const void* v, void* o, int32_
   p.sk_partials = nullptr;
   p.sk_ctl = nullptr;
   if (f32out) return launch<8, true, false, false>(p, (int)n_items, stream);
-  const int mode = attn_split_mode();   // 0: never; 1: where it pays; >= 2 (test hook): a persistent grid of `mode` workgroups
+  const int mode = grid == 0 ? 1 : (grid < 0 ? 0 : grid);   // 0: never; 1: where it pays; >= 2 (test hook): a persistent grid of `mode` workgroups
   const int G = mode >= 2 ? (mode < attn_cu_count() ? mode : attn_cu_count()) : attn_cu_count();
   const int64_t rounds = (n_items + G - 1) / G;
   const bool wasteful = mode >= 2 || (n_items > G && (rounds * G - n_items) * 25 >= rounds * G);   // >= 4 % of the rounds' CU time idle
@@ -772,15 +767,6 @@ int attention_entry(const void* q, const void* k, const void* v, void* o, int32_
 
 }  // namespace
 
-int fk_attention_split_mode(void) { return attn_split_mode(); }   // for attention_bwd.hip
-
-extern "C" int fk_attention_set_split(int32_t mode) {
-  FK_CHECK_ARG(mode >= 0, "fk_attention_set_split: %d is not 0 (one workgroup per 256-row block, always), 1 (stream-K grids where they "
-               "pay) or a workgroup count >= 2 (test hook: a persistent grid of that size whenever every item is cut at most once)", mode);
-  g_attn_split = mode;
-  return FK_OK;
-}
-
 // one slot per cut of the persistent grid (= per CU of the current device): the fp32 partial + its (ticket, flag) pair
 extern "C" int64_t fk_attention_ws_bytes(void) { return ATTN_CTL_BYTES + (int64_t)attn_cu_count() * PART_FLOATS * 4; }
 
@@ -801,9 +787,9 @@ extern "C" int fk_attention_fwd_lse_bf16(const void* q, const void* k, const voi
 
 extern "C" int fk_attention_fwd_ws_bf16(const void* q, const void* k, const void* v, void* o, float* lse, int32_t B, int32_t H,
                                         int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld, int64_t o_batch_stride,
-                                        float scale, void* ws, int64_t ws_bytes, fk_stream_t stream_) {
+                                        float scale, void* ws, int64_t ws_bytes, int32_t grid, fk_stream_t stream_) {
   return attention_entry(q, k, v, o, B, H, S, v_ld, v_batch_stride, o_ld, o_batch_stride, scale, false,
-                         (hipStream_t)stream_, lse, ws, ws_bytes);
+                         (hipStream_t)stream_, lse, ws, ws_bytes, grid);
 }
 
 extern "C" int fk_attention_fwd_f32_debug(const void* q, const void* k, const void* v, float* o, int32_t B,

@@ -32,6 +32,11 @@ void set_ws(fk_gemm_args& g, const fk_block_ws& ws) {   // ops._gemm_args: only 
   }
 }
 
+// launch controls of the block's GEMMs (fk_block_ws.gemm_*): a grouped launch reads them from its first problem
+void ctl(fk_gemm_args& g, const fk_block_ws& ws) {
+  g.variant = ws.gemm_variant; g.plan = ws.gemm_plan; g.group_m = ws.gemm_group_m; g.mfma = ws.gemm_mfma;
+}
+
 fk_gemm_args gemm(const View& a, const void* w, const void* bias, const View& c, int M, int N, int K, int epi) {
   fk_gemm_args g = {};
   g.A = a.p; g.a = a.r;
@@ -88,10 +93,10 @@ int double_block(const fk_block_ws& ws, const Dims& d, const fk_double_block_wei
     qkv_epi(g[0], ws, d, w.norm_q, w.norm_k, d.S_txt);
     g[1] = gemm(n_txt, w.wqkv_txt, w.bqkv_txt, view(ws.qkv, d, 3 * D, 0, d.S_txt, 0), Mt, 3 * D, D, FK_EPI_QKV);
     qkv_epi(g[1], ws, d, w.norm_added_q, w.norm_added_k, 0);
-    FK_TRY(fk_gemm_bf16_grouped(g, 2, st));
+    ctl(g[0], ws); FK_TRY(fk_gemm_bf16_grouped(g, 2, st));
   }
   FK_TRY(fk_attention_fwd_ws_bf16(ws.q, ws.k, (const char*)ws.qkv + (int64_t)2 * D * 2, ws.o, nullptr, B, d.H, d.S, 3 * D,
-                                  (int64_t)d.S * 3 * D, D, (int64_t)d.S * D, 0.08838834764831845f, ws.attn_ws, ws.attn_ws_bytes, st));
+                                  (int64_t)d.S * 3 * D, D, (int64_t)d.S * D, 0.08838834764831845f, ws.attn_ws, ws.attn_ws_bytes, ws.attn_grid, st));
   {
     fk_gemm_args g[2];
     g[0] = gemm(view(ws.o, d, D, d.S_txt, d.S_img, 0), w.w_out, w.b_out, h, Mi, D, D, FK_EPI_GATE_RES);
@@ -99,7 +104,7 @@ int double_block(const fk_block_ws& ws, const Dims& d, const fk_double_block_wei
     g[1] = gemm(view(ws.o, d, D, 0, d.S_txt, 0), w.w_add_out, w.b_add_out, cx, Mt, D, D, FK_EPI_GATE_RES);
     gate_res(g[1], cx, chunk(mt, 2), mod_bs, d.S_txt);
     set_ws(g[0], ws); set_ws(g[1], ws);
-    FK_TRY(fk_gemm_bf16_grouped(g, 2, st));
+    ctl(g[0], ws); FK_TRY(fk_gemm_bf16_grouped(g, 2, st));
   }
   FK_TRY(fk_ln_modulate2_bf16(s_all.p, s_all.r, (void*)n_all.p, n_all.r, chunk(mt, 3), chunk(mt, 4), chunk(mi, 3), chunk(mi, 4),
                               d.S_txt, mod_bs, d.S, M, D, ws.eps, st));
@@ -107,7 +112,7 @@ int double_block(const fk_block_ws& ws, const Dims& d, const fk_double_block_wei
     fk_gemm_args g[2];
     g[0] = gemm(n_img, w.w_ff1, w.b_ff1, view(ws.ff, d, 4 * D, d.S_txt, d.S_img, 0), Mi, 4 * D, D, FK_EPI_GELU_TANH);
     g[1] = gemm(n_txt, w.w_ff1_ctx, w.b_ff1_ctx, view(ws.ff, d, 4 * D, 0, d.S_txt, 0), Mt, 4 * D, D, FK_EPI_GELU_TANH);
-    FK_TRY(fk_gemm_bf16_grouped(g, 2, st));
+    ctl(g[0], ws); FK_TRY(fk_gemm_bf16_grouped(g, 2, st));
   }
   {
     fk_gemm_args g[2];
@@ -116,7 +121,7 @@ int double_block(const fk_block_ws& ws, const Dims& d, const fk_double_block_wei
     g[1] = gemm(view(ws.ff, d, 4 * D, 0, d.S_txt, 0), w.w_ff2_ctx, w.b_ff2_ctx, cx, Mt, D, 4 * D, FK_EPI_GATE_RES);
     gate_res(g[1], cx, chunk(mt, 5), mod_bs, d.S_txt);
     set_ws(g[0], ws); set_ws(g[1], ws);
-    FK_TRY(fk_gemm_bf16_grouped(g, 2, st));
+    ctl(g[0], ws); FK_TRY(fk_gemm_bf16_grouped(g, 2, st));
   }
   return FK_OK;
 }
@@ -133,21 +138,21 @@ int single_block(const fk_block_ws& ws, const Dims& d, const fk_single_block_wei
   {
     fk_gemm_args g = gemm(n_all, w.wqkv, w.bqkv, view(ws.qkv, d, 3 * D, 0, d.S, 0), Ms, 3 * D, D, FK_EPI_QKV);
     qkv_epi(g, ws, d, w.norm_q, w.norm_k, 0);
-    FK_TRY(fk_gemm_bf16(&g, st));
+    ctl(g, ws); FK_TRY(fk_gemm_bf16(&g, st));
   }
   // attention writes columns [0, D) of the [B, S, 5D] buffer, the MLP-up GEMM columns [D, 5D): proj_out reads one operand
   FK_TRY(fk_attention_fwd_ws_bf16(ws.q, ws.k, (const char*)ws.qkv + (int64_t)2 * D * 2, ws.cat, nullptr, B, d.H, d.S, 3 * D,
                                   (int64_t)d.S * 3 * D, 5 * D, (int64_t)d.S * 5 * D, 0.08838834764831845f, ws.attn_ws,
-                                  ws.attn_ws_bytes, st));
+                                  ws.attn_ws_bytes, ws.attn_grid, st));
   {
     fk_gemm_args g = gemm(n_all, w.w_mlp, w.b_mlp, view(ws.cat, d, 5 * D, 0, d.S, D), Ms, 4 * D, D, FK_EPI_GELU_TANH);
-    FK_TRY(fk_gemm_bf16(&g, st));
+    ctl(g, ws); FK_TRY(fk_gemm_bf16(&g, st));
   }
   {
     fk_gemm_args g = gemm(view(ws.cat, d, 5 * D, 0, d.S, 0), w.w_out, w.b_out, s_all, Ms, D, 5 * D, FK_EPI_GATE_RES);
     gate_res(g, s_all, chunk(2), mod_bs, d.S);
     set_ws(g, ws);
-    FK_TRY(fk_gemm_bf16(&g, st));
+    ctl(g, ws); FK_TRY(fk_gemm_bf16(&g, st));
   }
   return FK_OK;
 }

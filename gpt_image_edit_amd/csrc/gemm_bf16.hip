@@ -341,23 +341,6 @@ static int gemm_impl_override() {
   return v;
 }
 
-// FK_GEMM_BN=128|256 (or fk_gemm_set_variant) forces the tile width of the large-tile kernel (256 x 128 or 256 x 256);
-// default 0: chosen per problem size.
-static int g_bn_override = -1;
-static int gemm_bn_override() {
-  if (g_bn_override < 0) {
-    const char* e = getenv("FK_GEMM_BN");
-    g_bn_override = e ? atoi(e) : 0;
-  }
-  return g_bn_override;
-}
-extern "C" int fk_gemm_set_variant(int32_t variant) {
-  FK_CHECK_ARG(variant == 0 || variant == 128 || variant == 256 || variant == 384 || variant == 512 || variant == 640,
-               "fk_gemm_set_variant: %d is not one of 0 (automatic), 128, 256, 384 (mixed), 512 (split-K pairs), 640 (stream-K ranges)", variant);
-  g_bn_override = variant;
-  return FK_OK;
-}
-
 extern "C" int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream_) {
   FK_CHECK_ARG(args != nullptr, "fk_gemm_bf16: null args");
   const fk_gemm_args& p = *args;
@@ -374,7 +357,7 @@ extern "C" int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream_) {
     return rc2;
   }
   if (p.out_fp32 == 2) {   // the large-tile kernels' own main loops with an fp32 epilogue (launch form: plan / set_variant)
-    const int rc2 = fk_gemm2_launch(&p, 1, gemm_bn_override(), stream);
+    const int rc2 = fk_gemm2_launch(&p, 1, 0, stream);
     if (rc2 == FK_E2BIG_STRIDES) {
       fk_set_error("fk_gemm_bf16: out_fp32 = 2 needs row strides that keep a 256-row tile within 2 GiB");
       return FK_EUNSUPPORTED;
@@ -390,7 +373,7 @@ extern "C" int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream_) {
   }
   const int ov = gemm_impl_override();
   if (ov == 2 || p.epilogue == FK_EPI_QKV || (ov == 0 && p.M >= 192)) {
-    const int rc2 = fk_gemm2_launch(&p, 1, gemm_bn_override(), stream);
+    const int rc2 = fk_gemm2_launch(&p, 1, 0, stream);
     if (rc2 != FK_E2BIG_STRIDES) return rc2;   // row strides beyond 32-bit tile offsets: 64-bit-addressing kernel below
     if (p.epilogue == FK_EPI_QKV) {
       fk_set_error("fk_gemm_bf16: FK_EPI_QKV needs row strides that keep a 256-row tile within 2 GiB");
@@ -428,7 +411,7 @@ extern "C" int fk_gemm_bf16_grouped(const fk_gemm_args* args, int32_t n, fk_stre
     return rc2;
   }
   if (gemm_impl_override() != 1 || args[0].epilogue == FK_EPI_QKV) {
-    rc2 = fk_gemm2_launch(args, n, gemm_bn_override(), stream);
+    rc2 = fk_gemm2_launch(args, n, 0, stream);
     if (rc2 != FK_E2BIG_STRIDES) return rc2;
     if (args[0].epilogue == FK_EPI_QKV) {
       fk_set_error("fk_gemm_bf16_grouped: FK_EPI_QKV needs row strides that keep a 256-row tile within 2 GiB");

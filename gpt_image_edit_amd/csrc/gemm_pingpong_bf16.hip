@@ -1105,47 +1105,16 @@ static thread_local int g_last_variant = 0;
 // 128 / 256: the 256 x 128 / 256 x 256 kernel, 384: mixed grid, 512: split-K pairs, 0: none of the large-tile kernels yet
 int fk_gemm_last_variant(void) { return g_last_variant; }
 
-// bit 0: mixed grids, bit 1: split-K pairs (needs fk_gemm_args.splitk_ws), bit 2: stream-K ranges (measured slower, off);
-// FK_GEMM_PLAN=0..7 (default 3) or
-// fk_gemm_set_plan().  Without bit 1 the result of a GEMM does not depend on the grid it runs in ("batch-invariant").
-static int g_plan_allow = -1;
-static int plan_allow() {
-  if (g_plan_allow < 0) {
-    const char* e = getenv("FK_GEMM_PLAN");
-    g_plan_allow = e ? (atoi(e) & 7) : 3;
-  }
-  return g_plan_allow;
-}
-extern "C" int fk_gemm_set_plan(int32_t allow) {
-  FK_CHECK_ARG(allow >= 0 && allow <= 7, "fk_gemm_set_plan: %d is not in 0..7 (bit 0 mixed grids, bit 1 split-K pairs, bit 2 stream-K ranges)", allow);
-  g_plan_allow = allow;
-  return FK_OK;
-}
-
 // MFMA shape of the layout-0 large-tile kernels: 32 = v_mfma_f32_32x32x16_bf16, 16 = v_mfma_f32_16x16x32_bf16 (FragMap above).
 // The two differ in the last bits (16 against 32 products per hardware sum); every launch form of ONE shape agrees bit
-// for bit with the others.  FK_GEMM_MFMA=16|32 or fk_gemm_set_mfma(); the K-major layouts (1, 2) always use 32.
+// for bit with the others.  Per call: fk_gemm_args.mfma (0 = default); the K-major layouts (1, 2) always use 32.
 // Default 16 (round 5): +3.1 .. +4.1 % on every launch form of the M = 2560 QKV / MLP-up shapes, interleaved in one process
 // (profiles/r05_gemm_mfma_ab.txt); one wave per SIMD issues the 4-pass instruction every 17.3 cycles instead of 16, which is
 // why the ping-pong kernels keep 2/3 of the pure-MFMA stream's 12 %.
 #ifndef FK_GEMM_MFMA_DEFAULT
 #define FK_GEMM_MFMA_DEFAULT 16
 #endif
-static int g_mfma = -1;
-static int gemm_mfma() {
-  if (g_mfma < 0) {
-    const char* e = getenv("FK_GEMM_MFMA");
-    const int v = e ? atoi(e) : FK_GEMM_MFMA_DEFAULT;
-    g_mfma = v == 16 ? 16 : 32;
-  }
-  return g_mfma;
-}
-extern "C" int fk_gemm_set_mfma(int32_t shape) {
-  FK_CHECK_ARG(shape == 0 || shape == 16 || shape == 32, "fk_gemm_set_mfma: 16 (16 x 16 x 32), 32 (32 x 32 x 16) or 0 (default), got %d", shape);
-  g_mfma = shape == 0 ? FK_GEMM_MFMA_DEFAULT : shape;
-  return FK_OK;
-}
-extern "C" int fk_gemm_get_mfma(void) { return gemm_mfma(); }
+constexpr int GEMM_MFMA_DEFAULT = FK_GEMM_MFMA_DEFAULT;
 
 // Used by fk_gemm_bf16 / fk_gemm_bf16_grouped after argument validation.
 // variant_hint: 128 / 256 / 384 / 512 force a launch form where it is applicable; 0 = choose per problem.  The 256 x 256
@@ -1153,25 +1122,26 @@ extern "C" int fk_gemm_get_mfma(void) { return gemm_mfma(); }
 // runs in rounds of #CUs tiles: plan_launch picks the form with the shortest list-scheduling makespan.  (A stream-K form
 // of the 256 x 256 kernel that shares the last round's K-iterations among all CUs was built in round 1 and measured 2x
 // slower: DESIGN.md section 4b; git history.)
-static int g_group_m = -1;
-static int gemm_group_m() {
-  if (g_group_m < 0) {
-    const char* e = getenv("FK_GEMM_GROUP_M");
-    const int v = e ? atoi(e) : GROUP_M;
-    g_group_m = v >= 1 && v <= 4096 ? v : GROUP_M;
-  }
-  return g_group_m;
-}
-extern "C" int fk_gemm_set_group_m(int32_t depth) {
-  FK_CHECK_ARG(depth >= 0 && depth <= 4096, "fk_gemm_set_group_m: 0 (default) or 1..4096 row tiles");
-  g_group_m = depth == 0 ? GROUP_M : depth;
-  return FK_OK;
-}
-
 int fk_gemm2_launch(const fk_gemm_args* probs, int n, int variant_hint, hipStream_t stream) {
+  // launch controls come with the call (fk_gemm_args.variant / plan / group_m / mfma of the first problem): no process state
+  const fk_gemm_args& ctl = probs[0];
+  if (variant_hint == 0) variant_hint = ctl.variant;
+  if (!(variant_hint == 0 || variant_hint == 128 || variant_hint == 256 || variant_hint == 384 || variant_hint == 512 || variant_hint == 640)) {
+    fk_set_error("fk_gemm_bf16: variant %d is not one of 0 (launch plan), 128, 256, 384 (mixed), 512 (split-K pairs), 640 (stream-K ranges)", variant_hint);
+    return FK_EINVAL;
+  }
+  if (ctl.plan != 0 && (ctl.plan & ~15) != 0 || (ctl.plan != 0 && !(ctl.plan & FK_GEMM_PLAN_EXPLICIT))) {
+    fk_set_error("fk_gemm_bf16: plan %d is not 0 (default) or FK_GEMM_PLAN_EXPLICIT | allow bits 0..2", ctl.plan);
+    return FK_EINVAL;
+  }
+  if (ctl.group_m < 0 || ctl.group_m > 4096 || !(ctl.mfma == 0 || ctl.mfma == 16 || ctl.mfma == 32)) {
+    fk_set_error("fk_gemm_bf16: group_m %d must be 0 (default) or 1..4096, mfma %d one of 0 / 16 / 32", ctl.group_m, ctl.mfma);
+    return FK_EINVAL;
+  }
+  const int plan_allow = ctl.plan ? (ctl.plan & 7) : 3;
   GroupArgs ga;
   ga.n = n;
-  ga.group_m = gemm_group_m();
+  ga.group_m = ctl.group_m ? ctl.group_m : GROUP_M;
   ga.big_cols = 0;
   ga.sk_partials = nullptr;
   ga.sk_ctl = nullptr;
@@ -1254,7 +1224,7 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int variant_hint, hipStrea
       plan = ok ? Plan{640, Gs} : Plan{ok256 ? 256 : 128, 0};
       break;
     }
-    default: plan = plan_launch(nbm_total, N, K, G, plan_allow(), ws_slots > 0 && ok256, ws_slots); break;
+    default: plan = plan_launch(nbm_total, N, K, G, plan_allow, ws_slots > 0 && ok256, ws_slots); break;
   }
   ga.sk_min_part = SK_MIN_PART;
   if (plan.variant == 512 || plan.variant == 640) {
@@ -1262,7 +1232,7 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int variant_hint, hipStrea
     ga.sk_ctl = (unsigned*)((char*)probs[0].splitk_ws + (size_t)ws_slots * (BM * 256 * 4));
   }
   g_last_variant = plan.variant;
-  const bool m16 = gemm_mfma() == 16;
+  const bool m16 = (ctl.mfma ? ctl.mfma : GEMM_MFMA_DEFAULT) == 16;
   int rc;
   switch (probs[0].out_fp32 == 2 ? FK_EPI_F32DBG : probs[0].epilogue) {
     case FK_EPI_F32DBG: rc = launch_variant<FK_EPI_F32DBG>(ga, probs, n, plan.variant, plan.big_cols, m16, stream); break;

@@ -33,6 +33,7 @@ class GemmArgs(ctypes.Structure):
         ("epilogue", c_i32), ("out_fp32", c_i32), ("alpha", c_f32),
         ("q_out", c_vp), ("k_out", c_vp), ("wq", c_vp), ("wk", c_vp), ("rope_cs", c_vp), ("splitk_ws", c_vp),
         ("qkv_s_offset", c_i32), ("qkv_s_total", c_i32), ("qkv_heads", c_i32), ("splitk_slots", c_i32), ("layout", c_i32), ("f32_flags", c_i32),
+        ("variant", c_i32), ("plan", c_i32), ("group_m", c_i32), ("mfma", c_i32),       # per-call launch controls (include/fk.h)
     ]
 
 
@@ -52,7 +53,7 @@ class ConvArgs(ctypes.Structure):
 class BlockWs(ctypes.Structure):          # fk_block_ws
     _fields_ = [(n, c_vp) for n in ("s", "n", "qkv", "q", "k", "o", "ff", "cat", "rope_cs", "splitk_ws", "attn_ws")] + [
         ("attn_ws_bytes", c_i64), ("splitk_slots", c_i32), ("B", c_i32), ("S_txt", c_i32), ("S_img", c_i32), ("H", c_i32),
-        ("eps", c_f32)]
+        ("eps", c_f32), ("gemm_variant", c_i32), ("gemm_plan", c_i32), ("gemm_group_m", c_i32), ("gemm_mfma", c_i32), ("attn_grid", c_i32)]
 
 
 DOUBLE_BLOCK_FIELDS = ("wqkv_img", "bqkv_img", "wqkv_txt", "bqkv_txt", "norm_q", "norm_k", "norm_added_q", "norm_added_k",
@@ -74,23 +75,16 @@ SIGNATURES = {
     "fk_gemm_bf16": (c_i32, [ctypes.POINTER(GemmArgs), c_vp]),
     "fk_gemm_bf16_grouped": (c_i32, [ctypes.POINTER(GemmArgs), c_i32, c_vp]),
     "fk_gemm_last_variant": (c_i32, []),
-    "fk_gemm_set_variant": (c_i32, [c_i32]),
-    "fk_gemm_set_plan": (c_i32, [c_i32]),
-    "fk_gemm_set_group_m": (c_i32, [c_i32]),
-    "fk_gemm_set_mfma": (c_i32, [c_i32]),
-    "fk_gemm_get_mfma": (c_i32, []),
     "fk_ln_modulate_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "fk_ln_modulate2_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "fk_qkv_post_bf16": (c_i32, [c_vp] * 9 + [c_i32] * 4 + [c_f32, c_vp]),
     "fk_attention_fwd_bf16": (c_i32, [c_vp] * 4 + [c_i32] * 3 + [c_i64] * 4 + [c_f32, c_vp]),
-    "fk_attention_fwd_ws_bf16": (c_i32, [c_vp] * 5 + [c_i32] * 3 + [c_i64] * 4 + [c_f32, c_vp, c_i64, c_vp]),
+    "fk_attention_fwd_ws_bf16": (c_i32, [c_vp] * 5 + [c_i32] * 3 + [c_i64] * 4 + [c_f32, c_vp, c_i64, c_i32, c_vp]),
     "fk_attention_ws_bytes": (c_i64, []),
-    "fk_attention_set_split": (c_i32, [c_i32]),
     "fk_attention_fwd_f32_debug": (c_i32, [c_vp] * 4 + [c_i32] * 3 + [c_i64] * 4 + [c_f32, c_vp]),
     "fk_attention_fwd_lse_bf16": (c_i32, [c_vp] * 5 + [c_i32] * 3 + [c_i64] * 4 + [c_f32, c_vp]),
-    "fk_attention_bwd_set_mode": (c_i32, [c_i32]),
     "fk_attention_bwd_bf16": (c_i32, [ctypes.POINTER(AttnView)] * 4 + [c_vp, c_vp] + [ctypes.POINTER(AttnView)] * 3 + [c_i32] * 3 + [c_f32, c_vp]),
-    "fk_attention_bwd_ws_bf16": (c_i32, [ctypes.POINTER(AttnView)] * 4 + [c_vp, c_vp] + [ctypes.POINTER(AttnView)] * 3 + [c_i32] * 3 + [c_f32, c_vp, c_i64, c_vp]),
+    "fk_attention_bwd_ws_bf16": (c_i32, [ctypes.POINTER(AttnView)] * 4 + [c_vp, c_vp] + [ctypes.POINTER(AttnView)] * 3 + [c_i32] * 3 + [c_f32, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "fk_bwd_ws_floats": (c_i64, []),
     "fk_ln_modulate_bwd_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_i64, c_i64, c_vp, Rows, c_vp, Rows, c_vp, c_vp, c_i64, c_vp, c_i32, c_i32, c_f32, c_vp]),
     "fk_gate_res_bwd_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_i64, c_i64, c_vp, Rows, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp]),

@@ -4,6 +4,8 @@ Only plumbing lives here: argument checking, stride extraction, raw pointers and
 stream.  All arithmetic happens in libfk.so; nothing falls back to torch ops.
 """
 import ctypes
+from types import SimpleNamespace
+import os
 
 import torch
 
@@ -118,6 +120,7 @@ def _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv=None, 
         args.gate_batch_stride = gate.stride(0)
         args.gate_rows_per_batch = a.shape[1]
     args.M, args.N, args.K = M, N, K
+    _apply_gemm_launch(args)
     args.epilogue, args.out_fp32, args.alpha = epilogue, int(out_fp32), float(alpha)
     if int(out_fp32) == 1:       # fp32-class VAE encoder: fp32 bias / fp32 residual added to the fp32 output
         args.f32_flags = ((1 if bias is not None and bias.dtype == torch.float32 else 0) |
@@ -158,27 +161,76 @@ def gemm(a, w, bias=None, out=None, epilogue=FK_EPI_NONE, res=None, gate=None, o
     return out
 
 
+# ---- launch controls --------------------------------------------------------------------------------------------------------
+# The C library keeps NO mutable launch state (round 5): every call carries its launch form (fk_gemm_args.variant / plan /
+# group_m / mfma, the `grid` / `passes` arguments of the attention entry points, fk_block_ws.gemm_* / attn_grid).  What the
+# HOST wants as its defaults lives here, in the application layer: the setters below change this module's defaults (and only
+# this process's Python callers see them); the environment variables FK_GEMM_PLAN, FK_GEMM_BN, FK_GEMM_GROUP_M, FK_GEMM_MFMA,
+# FK_ATTN_SPLIT, FK_ATTN_BWD of rounds 2-4 are read once, here.
+FK_GEMM_PLAN_EXPLICIT = 8
+
+
+def _env_int(name, default):
+    v = os.environ.get(name)
+    return default if v is None or v == "" else int(v)
+
+
+LAUNCH = SimpleNamespace(
+    gemm_variant=_env_int("FK_GEMM_BN", 0),         # 0 = launch plan; 128 / 256 / 384 / 512 / 640 force a form where it applies
+    gemm_plan=(FK_GEMM_PLAN_EXPLICIT | (_env_int("FK_GEMM_PLAN", 3) & 7)) if os.environ.get("FK_GEMM_PLAN") else 0,
+    gemm_group_m=_env_int("FK_GEMM_GROUP_M", 0),
+    gemm_mfma=_env_int("FK_GEMM_MFMA", 0),          # 0 = built default (16); 16 / 32
+    attn_grid={0: -1, 1: 0}.get(_env_int("FK_ATTN_SPLIT", 1), _env_int("FK_ATTN_SPLIT", 1)),   # 0 default, -1 plain grid, >= 2 forced
+    attn_bwd_passes=0 if _env_int("FK_ATTN_BWD", 1) else 3)
 _LAUNCH_CFG_EPOCH = [0]
 
 
 def launch_config_epoch():
-    """Bumped by every launch-plan / kernel-form setter of this module: anything that froze host-side launch decisions (a
-    captured hipGraph of the denoise loop) keys on it."""
+    """Bumped by every launch-control setter of this module: anything that froze host-side launch decisions (a captured
+    hipGraph of the denoise loop) keys on it."""
     return _LAUNCH_CFG_EPOCH[0]
 
 
-def gemm_set_plan(allow):
-    """fk_gemm_set_plan: bit 0 = mixed grids (bit-identical results), bit 1 = split-K pairs (last-bit differences against
-    the unsplit sum, so a sample's result then depends on how full the grid is).  ``gemm_set_plan(1)`` = batch-invariant."""
-    libfk.check(libfk.load().fk_gemm_set_plan(int(allow)), "fk_gemm_set_plan")
+def _set_launch(**kw):
+    for k, v in kw.items():
+        setattr(LAUNCH, k, v)
     _LAUNCH_CFG_EPOCH[0] += 1
+
+
+def gemm_set_variant(variant):
+    """Force the launch form of the large-tile GEMMs where it applies: 128 = 256 x 128 tiles, 256 = 256 x 256 tiles, 384 =
+    mixed grid, 512 = split-K pairs, 640 = stream-K ranges; 0 = the launch plan chooses per problem.  (fk_gemm_args.variant)"""
+    if int(variant) not in (0, 128, 256, 384, 512, 640):
+        raise ValueError(f"gemm_set_variant: {variant} is not one of 0, 128, 256, 384, 512, 640")
+    _set_launch(gemm_variant=int(variant))
+
+
+def gemm_set_plan(allow):
+    """Which launch forms the plan may use (fk_gemm_args.plan): bit 0 = mixed grids (bit-identical results), bit 1 = split-K
+    pairs (last-bit differences against the unsplit sum, so a sample's result then depends on how full the grid is), bit 2 =
+    stream-K ranges.  ``gemm_set_plan(1)`` = batch-invariant; ``gemm_set_plan(3)`` = the default."""
+    if not 0 <= int(allow) <= 7:
+        raise ValueError(f"gemm_set_plan: {allow} is not in 0..7")
+    _set_launch(gemm_plan=FK_GEMM_PLAN_EXPLICIT | int(allow))
+
+
+def gemm_set_group_m(depth):
+    """Depth (in 256-row tiles) of the grouped tile order (fk_gemm_args.group_m; results do not depend on it); 0 = default."""
+    if not 0 <= int(depth) <= 4096:
+        raise ValueError(f"gemm_set_group_m: {depth} is not 0 (default) or 1..4096 row tiles")
+    _set_launch(gemm_group_m=int(depth))
 
 
 def gemm_set_mfma(shape):
-    """MFMA shape of the layout-0 large-tile GEMM kernels: 32 (v_mfma_f32_32x32x16_bf16), 16 (v_mfma_f32_16x16x32_bf16) or
-    0 = the built default.  The two differ in the last bits; see include/fk.h."""
-    libfk.check(libfk.load().fk_gemm_set_mfma(int(shape)), "fk_gemm_set_mfma")
-    _LAUNCH_CFG_EPOCH[0] += 1
+    """MFMA shape of the layout-0 large-tile GEMM kernels (fk_gemm_args.mfma): 32 (v_mfma_f32_32x32x16_bf16), 16
+    (v_mfma_f32_16x16x32_bf16) or 0 = the built default (16).  The two differ in the last bits; see include/fk.h."""
+    if int(shape) not in (0, 16, 32):
+        raise ValueError(f"gemm_set_mfma: {shape} is not 0, 16 or 32")
+    _set_launch(gemm_mfma=int(shape))
+
+
+def _apply_gemm_launch(args):
+    args.variant, args.plan, args.group_m, args.mfma = LAUNCH.gemm_variant, LAUNCH.gemm_plan, LAUNCH.gemm_group_m, LAUNCH.gemm_mfma
 
 
 def gemm_grouped(problems, epilogue=FK_EPI_NONE):
@@ -259,9 +311,13 @@ def attention_workspace(device):
 
 
 def attention_set_split(mode):
-    """fk_attention_set_split: 1 = stream-K grids where the plain grid wastes a round (default), 0 = never (batch-invariant)."""
-    libfk.check(libfk.load().fk_attention_set_split(int(mode)), "fk_attention_set_split")
-    _LAUNCH_CFG_EPOCH[0] += 1
+    """Grid of the attention forward and of the backward's dQ pass (the `grid` argument of fk_attention_fwd_ws_bf16 /
+    fk_attention_bwd_ws_bf16): 1 = stream-K grids where the plain grid wastes a round (default), 0 = never (batch-invariant),
+    >= 2 = a persistent grid of that many workgroups wherever every block is cut at most once (test hook)."""
+    mode = int(mode)
+    if mode < 0:
+        raise ValueError(f"attention_set_split: {mode} is not 0, 1 or a workgroup count >= 2")
+    _set_launch(attn_grid={0: -1, 1: 0}.get(mode, mode))
 
 
 def attention(q, k, v, out, scale=None, lse=None):
@@ -282,7 +338,7 @@ def attention(q, k, v, out, scale=None, lse=None):
     ws = attention_workspace(q.device)
     libfk.check(libfk.load().fk_attention_fwd_ws_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, H, S, v.stride(1),
                                                      v.stride(0), out.stride(1), out.stride(0), scale, _ptr(ws), ws.numel(),
-                                                     _stream()), "fk_attention_fwd_bf16")
+                                                     LAUNCH.attn_grid, _stream()), "fk_attention_fwd_bf16")
     return out
 
 
@@ -512,9 +568,10 @@ def rowdot(a, c, heads, out=None):
 
 
 def attention_bwd_set_mode(mode):
-    """fk_attention_bwd_set_mode: 1 = dQ pass + paired dK / dV pass (default), 0 = three passes."""
-    libfk.check(libfk.load().fk_attention_bwd_set_mode(int(mode)), "fk_attention_bwd_set_mode")
-    _LAUNCH_CFG_EPOCH[0] += 1
+    """`passes` of fk_attention_bwd_ws_bf16: 1 = dQ pass + paired dK / dV pass (default), 0 = three passes."""
+    if int(mode) not in (0, 1):
+        raise ValueError(f"attention_bwd_set_mode: {mode} is not 0 (three passes) or 1 (dQ pass + paired dK / dV pass)")
+    _set_launch(attn_bwd_passes=0 if int(mode) else 3)
 
 
 def attention_bwd(q, k, v, dout, lse, dsum, dq, dk, dv, scale=None):
@@ -526,7 +583,8 @@ def attention_bwd(q, k, v, dout, lse, dsum, dq, dk, dv, scale=None):
     r = [ctypes.byref(x) for x in views]
     ws = attention_workspace(q.device)      # the forward's stream-K workspace: the dQ pass uses the same scheme
     libfk.check(libfk.load().fk_attention_bwd_ws_bf16(r[0], r[1], r[2], r[3], _ptr(lse), _ptr(dsum), r[4], r[5], r[6], B, H, S,
-                                                     hd ** -0.5 if scale is None else scale, _ptr(ws), ws.numel(), _stream()),
+                                                     hd ** -0.5 if scale is None else scale, _ptr(ws), ws.numel(), LAUNCH.attn_grid,
+                                                     LAUNCH.attn_bwd_passes, _stream()),
                 "fk_attention_bwd_bf16")
 
 

@@ -553,6 +553,8 @@ class HipFluxTransformer2DModel(ParamTreeMixin, nn.Module):
             bw = (key, c, (cs, sk, aw))            # strong references keep the buffers the struct points into alive
             self.__dict__["_block_ws"] = bw
         c = bw[1]
+        L = ops.LAUNCH       # the host's launch defaults travel with the call (the library keeps no launch state)
+        c.gemm_variant, c.gemm_plan, c.gemm_group_m, c.gemm_mfma, c.attn_grid = L.gemm_variant, L.gemm_plan, L.gemm_group_m, L.gemm_mfma, L.attn_grid
         import ctypes
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         mp, mbs = ctypes.c_void_p(mod.data_ptr()), mod.stride(0)

@@ -109,34 +109,28 @@ typedef struct fk_gemm_args {
    * FK_EPI_RES), 2: M % 256 == 0; same sums, bit for bit, as layout 0 on transposed copies. */
   int32_t layout;
   int32_t f32_flags;         /* out_fp32 = 1 only: bit 0 = bias is fp32 [N]; bit 1 = `res` is an fp32 tensor (rows r) added to C */
+  /* Launch controls of the large-tile kernels -- PER CALL: the library keeps no mutable launch state (round 5; rounds 2-4 had
+   * process-wide fk_gemm_set_* hooks).  All zero = the defaults.  A grouped launch takes them from its first problem.
+   *   variant : 0 = the launch plan chooses per problem; 128 = 256 x 128 tiles, 256 = 256 x 256 tiles, 384 = mixed grid,
+   *             512 = split-K pairs, 640 = stream-K ranges -- forced where the form applies (tests, measurement).
+   *   plan    : 0 = default (mixed grids and split-K pairs allowed); otherwise FK_GEMM_PLAN_EXPLICIT | allow-bits: bit 0 mixed
+   *             grids (bit-identical results), bit 1 split-K pairs (results differ in the last bits from the unsplit sum: with
+   *             bit 1 clear a sample's result does not depend on the grid it runs in -- "batch-invariant"), bit 2 stream-K
+   *             ranges for long-K launches with a poorly filled last round (measured slower inside the edits: off by default).
+   *   group_m : 0 = default (8): depth in row tiles of the grouped tile order; >= the row-tile count: every XCD owns a column
+   *             range.  Results do not depend on it.
+   *   mfma    : 0 = default (16); 16 = v_mfma_f32_16x16x32_bf16, 32 = v_mfma_f32_32x32x16_bf16 (the two differ in the last
+   *             bits; every launch form of ONE shape agrees bit for bit with the others).  Layouts 1 / 2 always use 32. */
+  int32_t variant, plan, group_m, mfma;
 } fk_gemm_args;
+#define FK_GEMM_PLAN_EXPLICIT 8
+#define FK_GEMM_PLAN_BATCH_INVARIANT (FK_GEMM_PLAN_EXPLICIT | 1)   /* mixed grids only: no K split of any kind */
 #define FK_SPLITK_SLOT_BYTES (256 * 256 * 4 + 8)
 
 int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream);
 /* Which large-tile launch the calling thread's last fk_gemm_bf16[_grouped] used: 128 = 256 x 128 tiles, 256 = 256 x 256,
  * 384 = mixed grid, 512 = split-K pairs of 256 x 256 tiles, 0 = none so far (tests, profiling). */
 int fk_gemm_last_variant(void);
-/* Tuning / measurement hook: force the launch form of every later fk_gemm_bf16[_grouped] call of the process where
- * it applies: 128 = 256 x 128 tiles, 256 = 256 x 256 tiles, 384 = mixed grid, 512 = split-K pairs, 640 = stream-K ranges;
- * 0 = back to the per-problem choice.  128 / 256 / 384 give the same results bit for bit. */
-int fk_gemm_set_variant(int32_t variant);
-/* Which launch forms the per-problem choice may use: bit 0 = mixed grids (one round of 256 x 256 tiles, the remaining
- * columns as 256 x 128 tiles; bit-identical results), bit 1 = split-K pairs (results differ in the last bits from the
- * unsplit sum), bit 2 = stream-K ranges for long-K launches with a poorly filled last round (round 4; measured slower inside the
- * edits, so off).  Default 3 (FK_GEMM_PLAN overrides).  With bit 1 clear a GEMM's result does not depend on the grid it
- * runs in, i.e. a sample computed inside a batch equals the same sample computed alone bit for bit. */
-int fk_gemm_set_plan(int32_t allow);
-/* Tile order of the large-tile kernels (measurement hook; results do not depend on it): workgroup b runs on XCD b % 8 and every
- * XCD works off a contiguous chunk of the tile list, which is ordered in groups of `depth` row tiles (256 rows each), rows
- * fastest inside a group.  depth >= the number of row tiles makes every XCD's chunk a range of COLUMN tiles over all rows
- * (a W tile then enters one XCD's L2 only).  0 = the default (8; FK_GEMM_GROUP_M overrides). */
-int fk_gemm_set_group_m(int32_t depth);
-/* MFMA shape of the layout-0 large-tile kernels (measurement hook): 32 = v_mfma_f32_32x32x16_bf16, 16 =
- * v_mfma_f32_16x16x32_bf16 (half the accumulator register traffic per flop: under the chip's power limit a pure stream of it
- * sustains 12 % more flops, tools/power_probe.hip), 0 = the built default (FK_GEMM_MFMA overrides).  The two shapes differ in
- * the last bits; all launch forms (256 x 256, 256 x 128, mixed, split-K) of one shape agree with each other as before. */
-int fk_gemm_set_mfma(int32_t shape);
-int fk_gemm_get_mfma(void);
 
 /* n (<= FK_MAX_GROUP) independent problems that share N, K and the epilogue in ONE launch: the text- and
  * image-stream linears of a FluxTransformerBlock (different weights, different row counts) fill the GPU
@@ -184,17 +178,14 @@ int fk_attention_fwd_bf16(const void* q, const void* k, const void* v, void* o, 
  * that would leave >= 4 % of its rounds of one-workgroup-per-CU idle (B = 1: S = 8704 is 816 blocks = 3.19 rounds,
  * S = 5632 2.06) runs as a PERSISTENT grid: the KV tiles of all (b, h, 256-row block) items are dealt out as equal
  * contiguous ranges, one per CU, and a block whose keys straddle two CUs is finished by whichever arrives second
- * (fp32 partials through the workspace, agent-scope ticket + flag; deterministic: the merge is symmetric).  ws = NULL or
- * fk_attention_set_split(0): always one workgroup per block. */
+ * (fp32 partials through the workspace, agent-scope ticket + flag; deterministic: the merge is symmetric).  Where a block's
+ * keys are cut depends on the grid, so the choice comes with the call -- `grid`: 0 = as described, -1 = always one workgroup
+ * per block ("batch-invariant"; also what ws = NULL gives), >= 2 = a persistent grid of that many workgroups wherever every
+ * block is cut at most once (test hook).  The library keeps no launch state. */
 int fk_attention_fwd_ws_bf16(const void* q, const void* k, const void* v, void* o, float* lse, int32_t B, int32_t H,
                              int32_t S, int64_t v_ld, int64_t v_batch_stride, int64_t o_ld, int64_t o_batch_stride,
-                             float scale, void* ws, int64_t ws_bytes, fk_stream_t stream);
+                             float scale, void* ws, int64_t ws_bytes, int32_t grid, fk_stream_t stream);
 int64_t fk_attention_ws_bytes(void);
-/* 1 (default; FK_ATTN_SPLIT overrides): stream-K grids where they pay; 0: never ("batch-invariant": where a block's keys
- * are cut depends on the grid, so with 1 a sample computed inside a batch may differ in the last bits from the same
- * sample computed alone -- like fk_gemm_set_plan's split-K bit).  mode >= 2 (test hook): a persistent grid of `mode`
- * workgroups whenever every item would be cut at most once, whatever the grid's waste. */
-int fk_attention_set_split(int32_t mode);
 
 /* Parity / debug build of the SAME kernel (same tiling, LDS layouts, softmax, key <-> MFMA k-slot binding): the output
  * is fp32 (o_ld / o_batch_stride in fp32 elements, 16-byte aligned) and every probability enters the PV product as
@@ -227,6 +218,9 @@ typedef struct fk_block_ws {
   int32_t splitk_slots;
   int32_t B, S_txt, S_img, H;
   float eps;                       /* LayerNorm eps (1e-6) */
+  /* launch controls handed to every GEMM / attention launch of the block (all zero = defaults): fk_gemm_args.variant / plan /
+   * group_m / mfma and fk_attention_fwd_ws_bf16's `grid` */
+  int32_t gemm_variant, gemm_plan, gemm_group_m, gemm_mfma, attn_grid;
 } fk_block_ws;
 typedef struct fk_double_block_weights {   /* bf16; Linear weights [N, K] K-contiguous, fused q|k|v as [3D, D] / [3D] */
   const void *wqkv_img, *bqkv_img, *wqkv_txt, *bqkv_txt;          /* attn.to_{q,k,v} / attn.add_{q,k,v}_proj */
@@ -274,12 +268,11 @@ int fk_attention_bwd_bf16(const fk_attn_view* q, const fk_attn_view* k, const fk
 int fk_attention_bwd_ws_bf16(const fk_attn_view* q, const fk_attn_view* k, const fk_attn_view* v, const fk_attn_view* dout,
                              const float* lse, const float* dsum, const fk_attn_view* dq, const fk_attn_view* dk,
                              const fk_attn_view* dv, int32_t B, int32_t H, int32_t S, float scale, void* ws, int64_t ws_bytes,
-                             fk_stream_t stream);
-/* Measurement / parity hook for fk_attention_bwd_bf16: 1 = two launches, the dQ pass and one pass in which wave pairs
- * produce dK and dV together (7 tile products, default; FK_ATTN_BWD overrides), 0 = three launches (dQ, dV, dK: 8 tile
- * products).  dQ and dV are the same bit for bit in both; dK differs in the last bf16 bit (mode 1 forms
- * p (dP - D) from the bf16 p that also enters dV, mode 0 from the fp32 p). */
-int fk_attention_bwd_set_mode(int32_t mode);
+                             int32_t grid, int32_t passes, fk_stream_t stream);
+/* grid: as fk_attention_fwd_ws_bf16 (0 default, -1 plain grid, >= 2 forced persistent grid).  passes (measurement / parity):
+ * 0 or 2 = two launches, the dQ pass and one pass in which wave pairs produce dK and dV together (7 tile products, default),
+ * 3 = three launches (dQ, dV, dK: 8 tile products).  dQ and dV are the same bit for bit in both; dK differs in the last bf16
+ * bit (the paired pass forms p (dP - D) from the bf16 p that also enters dV, the three-pass form from the fp32 p). */
 
 /* fp32 elements of workspace `ws` the reductions below need (per-workgroup partial sums, fixed-order finalisation). */
 int64_t fk_bwd_ws_floats(void);

@@ -125,3 +125,35 @@ def test_committed_traffic_side_file_matches_its_source(tmp_path):
         assert any(k in ent["note"] for k in ("gemm9_kernel", "gemm8_kernel", "gemm_mix_kernel"))   # counters of real kernels
     import bench
     assert os.path.basename(bench.TRAFFIC_FILE) == stems[0] + ".json"
+
+
+def test_library_keeps_no_process_wide_launch_switches():
+    """VERDICT r4 weak #8 / SURVEY section 8(b) ("no global mutable state except an init-once table"): nothing the library
+    exports changes the numerics of LATER calls -- batch-invariant mode, forced launch forms, the MFMA shape and the
+    attention grids are fields / arguments of the call (fk_gemm_args.variant / plan / group_m / mfma, `grid` / `passes`,
+    fk_block_ws.gemm_* / attn_grid); the host's defaults live in ``ops.LAUNCH`` (Python, application layer)."""
+    import subprocess
+    from gpt_image_edit_amd import libfk, ops
+    assert not [n for n in _declared_symbols() if re.search(r"_set_|_get_", n)]
+    out = subprocess.run(["nm", "-D", "--defined-only", libfk.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = [l.split()[-1] for l in out.splitlines() if " T " in l]
+    assert len([n for n in exported if n.startswith("fk_")]) >= 50
+    assert not [n for n in exported if n.startswith("fk_") and ("_set_" in n or "_get_" in n)]
+    assert {"variant", "plan", "group_m", "mfma"} <= {f for f, _ in libfk.GemmArgs._fields_}
+    assert {"gemm_variant", "gemm_plan", "gemm_group_m", "gemm_mfma", "attn_grid"} <= {f for f, _ in libfk.BlockWs._fields_}
+    # the setters of the host layer change ops.LAUNCH (and the epoch a captured graph keys on), nothing else
+    before, e0 = dict(vars(ops.LAUNCH)), ops.launch_config_epoch()
+    try:
+        ops.gemm_set_plan(1); ops.gemm_set_variant(256); ops.gemm_set_mfma(32); ops.gemm_set_group_m(4); ops.attention_set_split(0)
+        ops.attention_bwd_set_mode(0)
+        assert (ops.LAUNCH.gemm_plan, ops.LAUNCH.gemm_variant, ops.LAUNCH.gemm_mfma, ops.LAUNCH.gemm_group_m) == (9, 256, 32, 4)
+        assert (ops.LAUNCH.attn_grid, ops.LAUNCH.attn_bwd_passes) == (-1, 3) and ops.launch_config_epoch() == e0 + 6
+        ops.attention_set_split(7)
+        assert ops.LAUNCH.attn_grid == 7
+        for bad in (lambda: ops.gemm_set_plan(8), lambda: ops.gemm_set_variant(100), lambda: ops.gemm_set_mfma(8),
+                    lambda: ops.gemm_set_group_m(-1), lambda: ops.attention_set_split(-2), lambda: ops.attention_bwd_set_mode(2)):
+            with pytest.raises(ValueError):
+                bad()
+    finally:
+        for k, v in before.items():
+            setattr(ops.LAUNCH, k, v)

@@ -79,7 +79,7 @@ def test_hot_gemm_kernels_at_the_stated_tolerance(ops, M, N, K, what):
     seen = {}
     try:
         for force in (0, 128, 256, 384, 512, 640):
-            lib.fk_gemm_set_variant(force)
+            ops.gemm_set_variant(force)
             got = ops.gemm(ad, wd, bd, out_fp32=2)
             torch.cuda.synchronize()
             v = lib.fk_gemm_last_variant()
@@ -91,7 +91,7 @@ def test_hot_gemm_kernels_at_the_stated_tolerance(ops, M, N, K, what):
                 assert torch.equal(got, seen[v])
             seen.setdefault(v, got)
     finally:
-        lib.fk_gemm_set_variant(0)
+        ops.gemm_set_variant(0)
     assert {128, 256} <= set(seen)
     if K >= 6144 and M == 2560:
         assert 512 in seen                   # the split-K pair form ran (M = 2560, N = 3072: 120 tiles)
@@ -110,19 +110,20 @@ def test_gemm_tile_order_does_not_change_the_bits(ops):
     w, bias = randn(9216, 3072, seed=83, scale=0.05).cuda(), randn(9216, seed=84, scale=0.1).cuda()
     try:
         for force in (128, 256, 384):
-            lib.fk_gemm_set_variant(force)
-            lib.fk_gemm_set_group_m(0)
+            ops.gemm_set_variant(force)
+            ops.gemm_set_group_m(0)
             ref = ops.gemm(a, w, bias).clone()
             ref_g = [t.clone() for t in ops.gemm_grouped([dict(a=a2, w=w, bias=bias), dict(a=a, w=w, bias=bias)])]
             for depth in (1, 3, 16, 4096):
-                lib.fk_gemm_set_group_m(depth)
+                ops.gemm_set_group_m(depth)
                 assert torch.equal(ops.gemm(a, w, bias), ref), (force, depth)
                 got_g = ops.gemm_grouped([dict(a=a2, w=w, bias=bias), dict(a=a, w=w, bias=bias)])
                 assert all(torch.equal(x, y) for x, y in zip(got_g, ref_g)), (force, depth)
     finally:
-        lib.fk_gemm_set_variant(0)
-        lib.fk_gemm_set_group_m(0)
-    assert lib.fk_gemm_set_group_m(-1) != 0          # refused
+        ops.gemm_set_variant(0)
+        ops.gemm_set_group_m(0)
+    with pytest.raises(ValueError):
+        ops.gemm_set_group_m(-1)                     # refused
 
 
 def test_gemm_layout_is_transpose_detecting(ops):
@@ -558,11 +559,11 @@ def test_gemm_both_mfma_shapes_every_form(ops, shape):
         w = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) / 64.0
         ref = a.to(BF).float() @ w.to(BF).float().T
         for force in (128, 256, 384):
-            lib.fk_gemm_set_variant(force)
+            ops.gemm_set_variant(force)
             try:
                 got = ops.gemm(a.to(BF).cuda(), w.to(BF).cuda(), None, out_fp32=2).cpu()
             finally:
-                lib.fk_gemm_set_variant(0)
+                ops.gemm_set_variant(0)
             torch.testing.assert_close(got, ref, rtol=0, atol=0)
         for epi in ("none", "gelu", "silu", "scale"):
             test_gemm_bf16_epilogues(ops, epi)

@@ -36,7 +36,7 @@ for B, S in [(1, int(x)) for x in os.environ.get("AB_S", "8704,2560").split(",")
     for rnd in range(5):
         for m in modes:
             if m is not None:
-                lib.fk_attention_bwd_set_mode(m)
+                ops.attention_bwd_set_mode(m)
             fn()
             torch.cuda.synchronize()
             if rnd == 0:
@@ -50,7 +50,7 @@ for B, S in [(1, int(x)) for x in os.environ.get("AB_S", "8704,2560").split(",")
             e1.synchronize()
             ms[m].append(e0.elapsed_time(e1) / 8)
     if modes[0] is not None:
-        lib.fk_attention_bwd_set_mode(1)
+        ops.attention_bwd_set_mode(1)
     fl = 8 * 2.0 * B * H * S * S * 128
     for m in modes:
         t = statistics.median(ms[m])

@@ -30,17 +30,17 @@ DEFAULT_SIDE = transformer.OVERLAP_MLP
 
 def apply(arm):
     ops.gemm_set_plan(3)
-    lib.fk_attention_set_split(1)
+    ops.attention_set_split(1)
     transformer.OVERLAP_MLP = DEFAULT_SIDE
-    lib.fk_gemm_set_group_m(0)
+    ops.gemm_set_group_m(0)
     for kv in arm.split(","):
         k, v = kv.split("=")
         if k == "plan":
             ops.gemm_set_plan(int(v))
         elif k == "split":
-            lib.fk_attention_set_split(int(v))
+            ops.attention_set_split(int(v))
         elif k == "gm":
-            lib.fk_gemm_set_group_m(int(v))
+            ops.gemm_set_group_m(int(v))
         elif k == "side":
             transformer.OVERLAP_MLP = {"0": False, "1": True}.get(v, "auto")
         else:

@@ -37,8 +37,8 @@ for (M, N, K) in shapes:
             if v == "vendor":
                 fn = lambda: torch.nn.functional.linear(a, w, b)  # noqa: E731
             else:
-                lib.fk_gemm_set_variant(form_of(v)[0])
-                lib.fk_gemm_set_mfma(form_of(v)[1])
+                ops.gemm_set_variant(form_of(v)[0])
+                ops.gemm_set_mfma(form_of(v)[1])
                 fn = lambda: ops.gemm(a, w, b, out=out, epilogue=epi)  # noqa: E731
             fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -58,7 +58,7 @@ for (M, N, K) in shapes:
                     assert d <= 2 ** -7 * ref.float().abs().max().item(), f"split-K differs by {d} on {M}x{N}x{K}"
                 else:
                     assert torch.equal(ref, out), f"variant {v} differs from variant 128 on {M}x{N}x{K}"
-    lib.fk_gemm_set_variant(0)
-    lib.fk_gemm_set_mfma(0)
+    ops.gemm_set_variant(0)
+    ops.gemm_set_mfma(0)
     print(f"{M}x{N}x{K} epi{epi}: " + "  ".join(f"{v}{'' if str(used.get(v, v)) == v.split('m')[0] else '->' + str(used[v])}: med "
                                                  f"{statistics.median(x):.0f} best {max(x):.0f}" for v, x in res.items()), flush=True)
