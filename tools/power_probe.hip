@@ -110,7 +110,7 @@ __global__ __launch_bounds__(NT, WPE) void mfma16_only(const bf16x8_t* __restric
 // image of random data addressed like the GEMM's swizzled rows (conflict-free).  DMA: pieces of 1 KiB per wave and phase
 // (gemm8_kernel: 2) from a 2 MiB source that stays in the XCD's L2.  No barriers: the probe measures power, not a schedule.
 constexpr int LDS_BYTES = 128 * 1024;
-template <int READS, int DMA>
+template <int READS, int DMA, bool M16 = false, int AUX = 0>   // AUX: cache-policy bits of the LDS-DMA loads (2 = nt, 1 = sc0, 16 = sc1)
 __global__ __launch_bounds__(512, 2) void mfma32_lds(const bf16x8_t* __restrict__ src, float* out, int iters, Clocks* clk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -147,13 +147,23 @@ __global__ __launch_bounds__(512, 2) void mfma32_lds(const bf16x8_t* __restrict_
           const int piece = ((it * 8 + ph) * DMA + d) * 8 + wave;   // 1 KiB pieces of the 2 MiB source, 128 KiB ring in LDS
 #if defined(__HIP_DEVICE_COMPILE__)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + LDS_BYTES + 4096 + (piece & 15) * 1024), 16, voff,
-                                                   (piece & 2047) * 1024, 0, 0);
+                                                   (piece & 2047) * 1024, 0, AUX);
 #endif
         }
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i], f[(i + 3 + ph) & 7], acc[i], 0, 0, 0);
+      for (int i = 0; i < 8; ++i) {
+        if constexpr (M16) {   // the same 32 x 32 x 32 of work per accumulator block as four 16 x 16 x 32 instructions (gemm8's M16 form)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4_t c = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[(i + q) & 7], f[(i + 3 + ph + q) & 7], c, 0, 0, 0);
+            acc[i][4 * q] = c[0]; acc[i][4 * q + 1] = c[1]; acc[i][4 * q + 2] = c[2]; acc[i][4 * q + 3] = c[3];
+          }
+        } else {
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i], f[(i + 3 + ph) & 7], acc[i], 0, 0, 0);
+        }
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -205,6 +215,66 @@ __global__ __launch_bounds__(256) void mfma32_lds_4w(const bf16x8_t* __restrict_
   for (int i = 0; i < 16; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[blockIdx.x * 256 + tid] = s;
+}
+
+// A 4-wave GEMM main loop WITHOUT its barriers (upper bound of a hipcc-built one-wave-per-SIMD 256 x 256 kernel): 128 x 128
+// wave tile on 32 x 32 x 16 MFMAs (the 16 x 16 x 32 form does not survive hipcc's AGPR allocation at 256 accumulator registers:
+// ~3 v_accvgpr moves per MFMA in the loop), 8 fragment reads (0.5 per MFMA) and, with DMA, the 16 LDS-DMA pieces per K-tile that
+// a wave of such a kernel issues itself -- in its own instruction stream, next to its MFMAs.
+template <int DMA>
+__global__ __launch_bounds__(256) void skeleton_4w(const bf16x8_t* __restrict__ src, float* out, int iters, Clocks* clk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < LDS_BYTES / 16; i += 256) ((bf16x8_t*)smem)[i] = src[(i + blockIdx.x * 64) & 131071];
+  __syncthreads();
+  f32x16_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int frow = lane & 31, fq = lane >> 5;
+  const int rd0 = frow * 128 + ((fq ^ ((frow >> 1) & 7)) << 4);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 2 << 20, 0x00020000);
+  const int voff = lane * 16;
+  bf16x8_t af[2][4], wf[2][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { af[0][i] = *(const bf16x8_t*)(smem + rd0 + i * 4096); wf[0][i] = *(const bf16x8_t*)(smem + 65536 + rd0 + i * 4096); }
+  stamp(clk, 0);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {       // one K-tile of 64 = four k-steps of 16 MFMAs
+      const int cb = ks & 1, nb = cb ^ 1;
+      const char* blk = smem + (((it * 4 + ks) * 5 + wave * 3) & 3) * 32;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[nb][i] = *(const bf16x8_t*)(blk + rd0 + i * 4096);
+        wf[nb][i] = *(const bf16x8_t*)(blk + 65536 + rd0 + i * 4096);
+        if constexpr (DMA > 0) {           // 4 pieces per k-step = 16 per K-tile and wave (64 KiB per K-tile and workgroup)
+          const int piece = ((it * 4 + ks) * 4 + i) * 4 + wave;
+#if defined(__HIP_DEVICE_COMPILE__)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + LDS_BYTES + 4096 + (piece & 15) * 1024), 16, voff,
+                                                   (piece & 2047) * 1024, 0, 0);
+#endif
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][i], af[cb][j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stamp(clk, 1);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
   out[blockIdx.x * 256 + tid] = s;
 }
 
@@ -292,6 +362,18 @@ int main(int argc, char** argv) {
   sustained("8 waves + 1.00 ds_read_b128 per MFMA", f8, lds8(mfma32_lds<8, 0>, 0), d_clk, seconds);
   sustained("8 waves + 0.75 reads + LDS-DMA at GEMM rate", f8, lds8(mfma32_lds<6, 2>, 16384), d_clk, seconds);
   sustained("8 waves + 0.50 reads + LDS-DMA at GEMM rate", f8, lds8(mfma32_lds<4, 2>, 16384), d_clk, seconds);
+  sustained("8 waves, 16x16x32 + 0.75 reads (gemm8, round 5 default)", f8, lds8(mfma32_lds<6, 0, true>, 0), d_clk, seconds);
+  sustained("8 waves, 16x16x32 + 0.75 reads + LDS-DMA at GEMM rate", f8, lds8(mfma32_lds<6, 2, true>, 16384), d_clk, seconds);
+  sustained("8 waves, 16x16x32 + 0.75 reads + LDS-DMA, nt loads (aux 2)", f8, lds8(mfma32_lds<6, 2, true, 2>, 16384), d_clk, seconds);
+  sustained("8 waves, 16x16x32 + 0.75 reads + LDS-DMA, sc1 loads (aux 16)", f8, lds8(mfma32_lds<6, 2, true, 16>, 16384), d_clk, seconds);
+  {
+    auto k0 = skeleton_4w<0>;
+    auto k1 = skeleton_4w<1>;
+    CHECK(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 4096 + 16384));
+    CHECK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 4096 + 16384));
+    sustained("4-wave 128x128 main loop, no barriers, 0.5 reads, no DMA", f4, [=] { hipLaunchKernelGGL(k0, dim3(cus), dim3(256), LDS_BYTES + 4096 + 16384, 0, d_src, d_out, iters, d_clk); }, d_clk, seconds);
+    sustained("4-wave 128x128 main loop, no barriers, 0.5 reads + own LDS-DMA", f4, [=] { hipLaunchKernelGGL(k1, dim3(cus), dim3(256), LDS_BYTES + 4096 + 16384, 0, d_src, d_out, iters, d_clk); }, d_clk, seconds);
+  }
   {
     auto kern = mfma32_lds_4w<8>;
     CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 4096));
