@@ -19,69 +19,9 @@
 // so V is never transposed in memory.  LDS swizzles (applied on the DMA source address and the read):
 //   K: 16-byte chunk ^= key & 15        (ds_read_b128 over 256-byte rows: conflict-free)
 //   V: 64-byte block ^= key & 3         (the four key rows of a transpose read hit four distinct blocks)
-#include <stdlib.h>
-
-#include <type_traits>
-
-#include "fk_common.h"
+#include "attention_common.h"
 
 namespace {
-
-constexpr int HD = 128;
-constexpr int KVBLK = 64;                       // keys per tile
-constexpr int K_TILE_BYTES = KVBLK * HD * 2;    // 16 KiB
-constexpr int STAGE_BYTES = 2 * K_TILE_BYTES;   // K + V
-
-struct AttnParams {
-  const bf16_t* q;
-  const bf16_t* k;
-  const bf16_t* v;
-  bf16_t* o;
-  int B, H, S;
-  int64_t v_ld, v_bs;  // V row (token) stride / batch stride in elements; head h at column h*128
-  int64_t o_ld, o_bs;
-  float scale_log2;    // scale * log2(e)
-  float* lse;          // optional [B, H, S]: log2-domain log-sum-exp of every row (saved for the backward pass)
-  // Work list: n_items = B * H * ceil(S / 256) (b, h, 256-row block) items of nkt = ceil(S / 64) KV tiles each.
-  // Plain launch: one workgroup per item.  Stream-K launch (attention_fwd_kernel<.., STREAMK = true>): a persistent grid
-  // of G workgroups; workgroup `pos` first takes the items pos, G + pos, ... of sk_rounds whole rounds, then works off
-  // the contiguous range [cut(pos), cut(pos + 1)) of the remaining items' KV-tile units, i.e. the tail of one item, maybe
-  // a whole item, the head of another (see the kernel).
-  int n_items, min_part;
-  int sk_rounds;       // stream-K launch: whole rounds of one item per workgroup in front of the dealt-out tail
-  float* sk_partials;  // stream-K workspace: per cut (G slots) the fp32 partial of one item part ...
-  unsigned* sk_ctl;    // ... and its (ticket, flag) word pair
-};
-constexpr int PART_FLOATS = 256 * 128 + 2 * 512;   // O^T accumulators of 8 waves x 32 rows + (l, m_ref) per lane
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void gbl_void;
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
-
-// buffer form of the LDS-DMA load (descriptor in SGPRs, one 32-bit offset VGPR, SGPR tile offset).  The builtin
-// exists for the device target only; seen by the host pass it silently suppresses the kernel's host stub.
-FK_DEV void buffer_lds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset, int soffset) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_dst, 16, voffset, soffset, 0, 0);
-#else
-  (void)rsrc; (void)lds_dst; (void)voffset; (void)soffset;
-#endif
-}
-FK_DEV s16x4_t lds_tr16(const char* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
-}
-template <int N>
-FK_DEV void wait_vmcnt() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else static_assert(N == 0, "add the vmcnt literal");
-}
-
-#ifndef FK_ATTN_PRIO
-#define FK_ATTN_PRIO 1   // static s_setprio(1) for the younger half of the workgroup (waves NW/2 .. NW-1)
-#endif
 
 // F32OUT (parity / debug build of the same kernel, fk_attention_fwd_f32_debug): the output is written as fp32 and
 // the probabilities enter the PV product as TWO bf16 terms (p = hi + lo, 16 mantissa bits instead of 8), so that
@@ -664,447 +604,6 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void attention_fwd_kernel
 // barrier (timing probe): +1..6 %.  Counters at B = 4, S = 8704: matrix pipe 52 % busy at 1.86 GHz, waves 37 % parked,
 // 32 % issue-stalled, LDS array ~26 % busy, no bank conflicts.
 
-// ---- 4 waves, one per SIMD, 64 query rows per wave (round 5) --------------------------------------------------------------
-// The 8-wave kernel above is issue-bound: per KV tile and wave 32 MFMAs beside ~6.5 other instructions each, and the counters
-// say matrix time and vector time ADD on a SIMD that two waves share.  What moves that bound is fewer
-// non-matrix instructions per MFMA, and the one large item is the operand reads: here a wave owns TWO 32-row query blocks (A, B),
-// so every K fragment and every V^T fragment it reads from LDS feeds two MFMAs -- 0.75 LDS reads per MFMA instead of 1.5 -- and
-// the wave has the SIMD's whole register file (O^T of both blocks, 128 accumulator registers, lives in the AGPR half).
-// With one wave per SIMD nothing else hides the softmax arithmetic, so the wave overlaps it with its OWN matrix work: the two
-// query blocks run as two streams half a step apart.  Per 32-key block k, four groups of 8 MFMAs:
-//     matrix pipe                      vector / LDS work issued in the shadow of those MFMAs
-//     S_A(k)   = K(k) Q_A^T            second half of the exponentials of S_B(k-1), packs;  8 K-fragment reads (kept for S_B)
-//     O_B     += V(k-1) P_B(k-1)       first half of the exponentials of S_A(k)                    (V fragments kept from O_A)
-//     S_B(k)   = K(k) Q_B^T            second half of the exponentials of S_A(k), packs
-//     O_A     += V(k) P_A(k)           first half of the exponentials of S_B(k);            16 V^T transpose reads (kept for O_B)
-// = 32 MFMAs beside 112 vector instructions and 24 LDS reads: ~4.3 per MFMA (the guide's limit for a single wave: 5).  Only
-// registers cross a tile boundary (S_B, V fragments), so the K / V ring, its barrier per tile and the LDS-DMA requests are the
-// 8-wave kernel's.  Every row's sums are formed in the same order as there: the two kernels agree bit for bit, which is the
-// parity test; restart path, ragged last tile, stream-K seam likewise (the seam's partial layout is private to this kernel).
-template <bool STREAMK>
-__global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams p) {
-  constexpr int NW = 4, STAGES = 3, QBLK = 256, LOADS = 32 / NW, KL = LOADS / 2, PF = STAGES - 1;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ql = lane & 31, hh = lane >> 5;
-  const int nqb = (p.S + QBLK - 1) / QBLK;
-  const int nkt = (p.S + KVBLK - 1) / KVBLK;
-  int pos;
-  {
-    const int nwg = gridDim.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    pos = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  }
-  int u = 0, u_end = 0, round = 0;
-  if constexpr (STREAMK) {   // the 8-wave kernel's work list (whole rounds, then the tail dealt out from its end)
-    const unsigned G = gridDim.x;
-    const unsigned U = (unsigned)(p.n_items - p.sk_rounds * (int)G) * (unsigned)nkt;
-    const unsigned qU = U / G, rU = U - qU * G;
-    auto cut = [&](unsigned j) __attribute__((always_inline)) {
-      unsigned c = qU * j + (rU * j) / G;
-      const unsigned r = c % (unsigned)nkt;
-      if (r != 0 && r < (unsigned)p.min_part) c -= r;
-      else if (r != 0 && (unsigned)nkt - r < (unsigned)p.min_part) c += (unsigned)nkt - r;
-      return (int)c;
-    };
-    u = cut(pos);
-    u_end = cut(pos + 1);
-  }
-  const int prow = lane >> 4, pslot = lane & 15;
-  const int tj = (lane & 15) >> 2, tq = lane & 3, tdh = (lane >> 4) & 1;
-  const int v_rd = K_TILE_BYTES + (4 * hh + tj) * 256 + tdh * 32 + tq * 8;
-  const int k_rd = ql * 256;
-  const int k_sw = ql & 15;
-
-  for (;;) {
-  int item = pos, kt0 = 0, kt1 = nkt;
-  if constexpr (STREAMK) {
-    if (round < p.sk_rounds) {
-      item = round * (int)gridDim.x + pos;
-      ++round;
-    } else {
-      if (u >= u_end) break;
-      const int ti = (unsigned)(u_end - 1) / (unsigned)nkt;
-      item = p.sk_rounds * (int)gridDim.x + ti;
-      kt1 = u_end - ti * nkt;
-      kt0 = max(u - ti * nkt, 0);
-      u_end -= kt1 - kt0;
-    }
-  }
-  const int qb = item % nqb;
-  const int bh = item / nqb;
-  const int b = bh / p.H, h = bh - b * p.H;
-  const int q_row0 = qb * QBLK + wave * 64;              // rows q_row0 + 32 X + ql, X = 0 (block A), 1 (block B)
-  const bf16_t* Kg = p.k + (int64_t)bh * p.S * HD;
-  const bf16_t* Vg = p.v + (int64_t)b * p.v_bs + h * HD;
-
-  bf16x8_t qfA[8], qfB[8];
-  {
-    const bf16_t* qa = p.q + ((int64_t)bh * p.S + min(q_row0 + ql, p.S - 1)) * HD + 8 * hh;
-    const bf16_t* qbp = p.q + ((int64_t)bh * p.S + min(q_row0 + 32 + ql, p.S - 1)) * HD + 8 * hh;
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      qfA[kk] = *(const bf16x8_t*)(qa + 16 * kk);
-      qfB[kk] = *(const bf16x8_t*)(qbp + 16 * kk);
-    }
-  }
-  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, p.S * HD * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_v =
-      __builtin_amdgcn_make_buffer_rsrc((void*)Vg, 0, (int)(((int64_t)(p.S - 1) * p.v_ld + HD) * 2), 0x00020000);
-  int k_voff[KL], v_voff[KL];
-#pragma unroll
-  for (int i = 0; i < KL; ++i) {
-    const int r = (wave * KL + i) * 4 + prow;
-    k_voff[i] = (r * HD + ((pslot ^ (r & 15)) << 3)) * 2;
-    const int vcol = ((((pslot >> 2) ^ (r & 3)) << 5) + ((pslot & 3) << 3));
-    v_voff[i] = (int)((r * p.v_ld + vcol) * 2);
-  }
-  const int k_tile_bytes = KVBLK * HD * 2, v_tile_bytes = (int)(KVBLK * p.v_ld * 2);
-  auto issue_tile = [&](int kt, int stage) __attribute__((always_inline)) {
-    char* sb = smem + stage * STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < KL; ++i) {
-      buffer_lds16(rs_k, sb + (wave * KL + i) * 1024, k_voff[i], kt * k_tile_bytes);
-      buffer_lds16(rs_v, sb + K_TILE_BYTES + (wave * KL + i) * 1024, v_voff[i], kt * v_tile_bytes);
-    }
-  };
-
-  f32x16_t oA[4], oB[4];
-  constexpr float REF_BIAS = 24.0f;
-  float mA = 0.f, mB = 0.f, lA = 0.f, lB = 0.f;
-  int st_cur = 0, st_pf = PF;
-  auto fill = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int s = 0; s < PF; ++s)
-      if (kt0 + s < kt1) issue_tile(kt0 + s, s);
-    st_cur = 0;
-    st_pf = PF;
-  };
-  auto acquire_tile = [&](int kt) __attribute__((always_inline)) {
-    if (kt + PF - 1 < kt1) wait_vmcnt<(PF - 1) * LOADS>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (kt + PF < kt1) issue_tile(kt + PF, st_pf);
-    return smem + st_cur * STAGE_BYTES;
-  };
-  auto release_tile = [&]() __attribute__((always_inline)) {
-    st_cur = (st_cur == STAGES - 1) ? 0 : st_cur + 1;
-    st_pf = (st_pf == STAGES - 1) ? 0 : st_pf + 1;
-  };
-  auto k_frag = [&](const char* sb, int kb, int kk) __attribute__((always_inline)) {
-    return *(const bf16x8_t*)(sb + k_rd + kb * 8192 + (((2 * kk + hh) ^ k_sw) << 4));
-  };
-  auto v_frag = [&](const char* sb, int st, int df) __attribute__((always_inline)) {
-    const char* vp = sb + v_rd + st * 4096 + ((df ^ tj) << 6);
-    const s16x4_t lo = lds_tr16(vp);
-    const s16x4_t hi = lds_tr16(vp + 2048);
-    bf16x8_t vf;
-    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-    return vf;
-  };
-  auto mask_block = [&](f32x16_t& s, int kt, int kb) __attribute__((always_inline)) {
-    const int kbase = kt * KVBLK + 32 * kb + 4 * hh;
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (kbase + (r & 3) + 8 * (r >> 2) >= p.S) s[r] = -1.0e30f;
-  };
-  auto block_max = [&](const f32x16_t& s) __attribute__((always_inline)) {
-    float mx = s[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-    return fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2;
-  };
-  // half of a block's softmax numerators (registers [8 half, 8 half + 8)) + the packed P^T fragment of that 16-key step
-  auto expo_half = [&](f32x16_t& s, int half, float nm, float& psum, bf16x8_t& pf) __attribute__((always_inline)) {
-    const int r0 = 8 * half;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float pv = __builtin_amdgcn_exp2f(fmaf(s[r0 + e], p.scale_log2, nm));
-      s[r0 + e] = pv;
-      psum += pv;
-    }
-    u32x4_t pw;
-    pw[0] = pack_bf2(s[r0 + 0], s[r0 + 1]);
-    pw[1] = pack_bf2(s[r0 + 2], s[r0 + 3]);
-    pw[2] = pack_bf2(s[r0 + 4], s[r0 + 5]);
-    pw[3] = pack_bf2(s[r0 + 6], s[r0 + 7]);
-    pf = __builtin_bit_cast(bf16x8_t, pw);
-  };
-  // pins: one MFMA, then its share of the group's vector / transcendental / LDS work (the order hipcc would otherwise pick puts
-  // the whole softmax behind the MFMAs)
-#define FK_PIN_MFMA_VALU()                                      \
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \
-  __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);            \
-  __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);            \
-  __builtin_amdgcn_sched_group_barrier(0x002, 2, 0)
-
-  // pipeline registers
-  bf16x8_t kf[8], vfr[8];
-  f32x16_t sA, sB;
-  bf16x8_t pA0, pA1, pB0, pB1;
-
-  // One 32-key block kb of the tile at sb: the four groups of the table above.
-  auto do_block = [&](const char* sb, int kt, int kb, auto mask_tag, auto first_tag) __attribute__((always_inline)) {
-    constexpr bool MASK = decltype(mask_tag)::value, FIRST = decltype(first_tag)::value;
-    // ---- group 1: S_A(k) under the second half of E_B(k-1) -----------------------------------------------------------------
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) kf[kk] = k_frag(sb, kb, kk);
-    {
-      const float nmB = -mB;
-      expo_half(sB, 1, nmB, lB, pB1);
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qfA[kk], kk == 0 ? f32x16_t{} : sA, 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        FK_PIN_MFMA_VALU();
-      }
-    }
-    if constexpr (MASK) mask_block(sA, kt, kb);
-    if constexpr (FIRST) {
-      if (kb == 0) mA = block_max(sA) + REF_BIAS;
-    }
-    // ---- group 2: O_B += V(k-1) P_B(k-1) under the first half of E_A(k) --------------------------------------------------
-    {
-      const float nmA = -mA;
-      expo_half(sA, 0, nmA, lA, pA0);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        oB[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[i], (i >> 2) ? pB1 : pB0, oB[i & 3], 0, 0, 0);
-        FK_PIN_MFMA_VALU();
-      }
-    }
-    // ---- group 3: S_B(k) under the second half of E_A(k) -----------------------------------------------------------------
-    {
-      const float nmA = -mA;
-      expo_half(sA, 1, nmA, lA, pA1);
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        sB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qfB[kk], kk == 0 ? f32x16_t{} : sB, 0, 0, 0);
-        FK_PIN_MFMA_VALU();
-      }
-    }
-    if constexpr (MASK) mask_block(sB, kt, kb);
-    if constexpr (FIRST) {
-      if (kb == 0) mB = block_max(sB) + REF_BIAS;
-    }
-    // ---- group 4: O_A += V(k) P_A(k) under the first half of E_B(k); the V^T fragments stay for O_B -----------------------
-#pragma unroll
-    for (int i = 0; i < 8; ++i) vfr[i] = v_frag(sb, 2 * kb + (i >> 2), i & 3);
-    {
-      const float nmB = -mB;
-      expo_half(sB, 0, nmB, lB, pB0);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        oA[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[i], (i >> 2) ? pA1 : pA0, oA[i & 3], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        FK_PIN_MFMA_VALU();
-      }
-    }
-  };
-#undef FK_PIN_MFMA_VALU
-  auto do_tile = [&](int kt, auto mask_tag, auto first_tag) __attribute__((always_inline)) {
-    const char* sb = acquire_tile(kt);
-    do_block(sb, kt, 0, mask_tag, first_tag);
-    do_block(sb, kt, 1, mask_tag, std::false_type{});
-    release_tile();
-  };
-  // start of a pass: an empty "previous block" of stream B (numerators and V fragments zero: O_B += 0)
-  auto prime = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sB[r] = -3.0e38f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) vfr[i] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-    pB0 = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-  };
-  // end of a pass: the pending half of stream B
-  auto drain = [&]() __attribute__((always_inline)) {
-    expo_half(sB, 1, -mB, lB, pB1);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      oB[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[i], (i >> 2) ? pB1 : pB0, oB[i & 3], 0, 0, 0);
-  };
-
-  using TT = std::true_type;
-  using FF = std::false_type;
-  const bool ragged = p.S % KVBLK != 0;
-  const bool last_masked = ragged && kt1 == nkt;
-  int* const wg_flag = (int*)(smem + STAGES * STAGE_BYTES);
-  auto run_tiles = [&](auto first_tag) __attribute__((always_inline)) {
-    const int last = kt1 - 1;
-    prime();
-    if (kt0 == last) {
-      if (last_masked) do_tile(kt0, TT{}, first_tag);
-      else do_tile(kt0, FF{}, first_tag);
-    } else {
-      do_tile(kt0, FF{}, first_tag);
-      for (int kt = kt0 + 1; kt < last; ++kt) do_tile(kt, FF{}, FF{});
-      if (last_masked) do_tile(last, TT{}, FF{});
-      else do_tile(last, FF{}, FF{});
-    }
-    drain();
-  };
-  // plain S^T block (the restart's K-only pre-pass): query block X of the wave against key block kb
-  auto scores_plain = [&](const char* sb, int kb, const bf16x8_t (&qf)[8]) __attribute__((always_inline)) {
-    f32x16_t s;
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk)
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_frag(sb, kb, kk), qf[kk], kk == 0 ? f32x16_t{} : s, 0, 0, 0);
-    return s;
-  };
-  bool overflow = false;
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    if (attempt == 1) {
-      fill();
-      mA = -3.0e38f;
-      mB = -3.0e38f;
-      for (int kt = kt0; kt < kt1; ++kt) {
-        const char* sb = acquire_tile(kt);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          f32x16_t a = scores_plain(sb, kb, qfA), c = scores_plain(sb, kb, qfB);
-          if (last_masked && kt == kt1 - 1) { mask_block(a, kt, kb); mask_block(c, kt, kb); }
-          mA = fmaxf(mA, block_max(a));
-          mB = fmaxf(mB, block_max(c));
-        }
-        release_tile();
-      }
-      __syncthreads();
-    }
-    fill();
-    lA = 0.f;
-    lB = 0.f;
-    overflow = false;
-#pragma unroll
-    for (int df = 0; df < 4; ++df)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { oA[df][r] = 0.f; oB[df][r] = 0.f; }
-    if (attempt == 0) run_tiles(TT{});
-    else run_tiles(FF{});
-    if (attempt == 0) {
-      float mag = fabsf(lA) + fabsf(lB);
-#pragma unroll
-      for (int df = 0; df < 4; ++df)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mag += fabsf(oA[df][r]) + fabsf(oB[df][r]);
-      overflow = __builtin_amdgcn_ballot_w64(!(mag <= 3.0e38f)) != 0;
-      __syncthreads();
-      if (tid == 0) *wg_flag = 0;
-      __syncthreads();
-      if (overflow && lane == 0) atomicOr(wg_flag, 1);
-      __syncthreads();
-      if (*wg_flag == 0) break;
-    }
-  }
-
-  if constexpr (STREAMK) {
-    if (kt0 > 0 || kt1 < nkt) {
-      typedef __attribute__((address_space(1))) unsigned gu32;
-      const int slot = kt1 < nkt ? pos + 1 : pos;
-      gu32* const ctl = (gu32*)(p.sk_ctl + 2 * (size_t)slot);
-      const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(p.sk_partials + (size_t)slot * PART_FLOATS), 0, PART_FLOATS * 4, 0x00020000);
-      __syncthreads();
-      if (tid == 0) *(volatile unsigned*)smem = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      const unsigned ticket = __builtin_amdgcn_readfirstlane(*(volatile unsigned*)smem);
-      constexpr int LM_OFF = 32 * 256 * 16;      // (l, m_ref) pairs behind the 2 x 16 pieces of 256 threads
-      if ((ticket & 1u) == 0) {
-#pragma unroll
-        for (int r = 0; r < 32; ++r) {
-          const f32x16_t& a = r < 16 ? oA[(r & 15) >> 2] : oB[(r & 15) >> 2];
-          const int q4 = r & 3;
-          const u32x4_t v = {__float_as_uint(a[4 * q4]), __float_as_uint(a[4 * q4 + 1]), __float_as_uint(a[4 * q4 + 2]),
-                             __float_as_uint(a[4 * q4 + 3])};
-          __builtin_amdgcn_raw_buffer_store_b128(v, rs_p, tid * 16, r * (256 * 16), 16);
-        }
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(lA), __float_as_uint(mA)}, rs_p, LM_OFF + tid * 8, 0, 16);
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(lB), __float_as_uint(mB)}, rs_p, LM_OFF + (256 + tid) * 8, 0, 16);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(ctl + 1, ticket + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        continue;
-      }
-      if (tid == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket && spins < (1 << 22)) {
-          __builtin_amdgcn_s_sleep(8);
-          ++spins;
-        }
-        *(volatile unsigned*)smem = spins >= (1 << 22);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-      __syncthreads();
-      const bool gave_up = *(volatile unsigned*)smem != 0;
-      auto merge = [&](f32x16_t (&o)[4], float& l_run, float& m_ref, int X) __attribute__((always_inline)) {
-        const u32x2_t lm = __builtin_amdgcn_raw_buffer_load_b64(rs_p, LM_OFF + (X * 256 + tid) * 8, 0, 16);
-        const float l_o = __uint_as_float(lm[0]), m_o = __uint_as_float(lm[1]);
-        const float m_new = fmaxf(m_ref, m_o);
-        const float w_s = m_ref == m_new ? 1.0f : __builtin_amdgcn_exp2f(m_ref - m_new);
-        const float w_o = m_o == m_new ? 1.0f : __builtin_amdgcn_exp2f(m_o - m_new);
-#pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += 4) {
-          u32x4_t v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, tid * 16, (X * 16 + r0 + e) * (256 * 16), 16);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            f32x16_t& a = o[(r0 + e) >> 2];
-            const int q4 = (r0 + e) & 3;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              a[4 * q4 + j] = __fadd_rn(__fmul_rn(a[4 * q4 + j], w_s), __fmul_rn(__uint_as_float(v[e][j]), w_o));
-          }
-        }
-        l_run = __fadd_rn(__fmul_rn(l_run, w_s), __fmul_rn(l_o, w_o));
-        if (gave_up) l_run = __builtin_nanf("");
-        m_ref = m_new;
-      };
-      merge(oA, lA, mA, 0);
-      merge(oB, lB, mB, 1);
-    }
-  }
-
-  // ---- finalize (per query block, as the 8-wave kernel does for its one) ----------------------------------------------------
-  auto finalize = [&](const f32x16_t (&o)[4], float l_run, float m_ref, int q_row) __attribute__((always_inline)) {
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l_tot;
-    if (p.lse && hh == 0 && q_row < p.S) p.lse[(int64_t)bh * p.S + q_row] = m_ref + __builtin_amdgcn_logf(l_tot);
-    bf16_t* const orow = p.o + (int64_t)b * p.o_bs + (int64_t)min(q_row, p.S - 1) * p.o_ld + h * HD;
-    const bool wide = ((p.o_ld | p.o_bs) & 7) == 0 && ((uintptr_t)p.o & 15) == 0;
-#pragma unroll
-    for (int df = 0; df < 4; ++df)
-#pragma unroll
-      for (int g = 0; g < 4; g += 2) {
-        u32x2_t a, c;
-        a[0] = pack_bf2(o[df][4 * g + 0] * inv, o[df][4 * g + 1] * inv);
-        a[1] = pack_bf2(o[df][4 * g + 2] * inv, o[df][4 * g + 3] * inv);
-        c[0] = pack_bf2(o[df][4 * g + 4] * inv, o[df][4 * g + 5] * inv);
-        c[1] = pack_bf2(o[df][4 * g + 6] * inv, o[df][4 * g + 7] * inv);
-        if (wide) {
-#if defined(__HIP_DEVICE_COMPILE__)
-          const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], c[0], false, false);
-          const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], c[1], false, false);
-          const u32x4_t w = {r0[0], r1[0], r0[1], r1[1]};
-          if (q_row < p.S) *(u32x4_t*)(orow + 32 * df + 8 * g + 8 * hh) = w;
-#endif
-        } else if (q_row < p.S) {
-          *(u32x2_t*)(orow + 32 * df + 8 * g + 4 * hh) = a;
-          *(u32x2_t*)(orow + 32 * df + 8 * (g + 1) + 4 * hh) = c;
-        }
-      }
-  };
-  finalize(oA, lA, mA, q_row0 + ql);
-  finalize(oB, lB, mB, q_row0 + 32 + ql);
-  if constexpr (!STREAMK) break;
-  else __syncthreads();
-  }   // passes
-}
-
 template <int NW, bool F32OUT, bool ILV, bool STREAMK>
 int launch(const AttnParams& p, int grid, hipStream_t stream) {
   constexpr int SMEM = 3 * STAGE_BYTES + 16;   // ring + the restart flag word
@@ -1115,15 +614,6 @@ int launch(const AttnParams& p, int grid, hipStream_t stream) {
   return FK_OK;
 }
 
-template <bool STREAMK>
-int launch4(const AttnParams& p, int grid, hipStream_t stream) {
-  constexpr int SMEM = 3 * STAGE_BYTES + 16;
-  auto kern = attention_fwd4_kernel<STREAMK>;
-  FK_ENSURE_MAX_LDS(kern, SMEM, "fk_attention_fwd_bf16 (4 waves x 64 rows)");
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), SMEM, stream, p);
-  FK_CHECK_LAUNCH("fk_attention_fwd_bf16 (4 waves x 64 rows)");
-  return FK_OK;
-}
 // FK_ATTN_KERNEL=4|8 (read once; A/B and tests): the two kernels give the same bits, so the choice is a launch decision like
 // the instruction order (FK_ATTN_ILV).  Default: 8 until the 4-wave kernel is measured faster.
 static int attn_kernel_choice() {
@@ -1220,10 +710,10 @@ int attention_entry(const void* q, const void* k, const void* v, void* o, int32_
     // read its tickets from what a 256-workgroup launch used as partial storage), partials behind them
     p.sk_ctl = (unsigned*)ws;
     p.sk_partials = (float*)((char*)ws + ATTN_CTL_BYTES);
-    if (attn_kernel_choice() == 4) return launch4<true>(p, G, stream);
+    if (attn_kernel_choice() == 4) return fk_attention_fwd4_launch(p, G, true, stream);
     return use_interleaved(p) ? launch<8, false, true, true>(p, G, stream) : launch<8, false, false, true>(p, G, stream);
   }
-  if (attn_kernel_choice() == 4) return launch4<false>(p, (int)n_items, stream);
+  if (attn_kernel_choice() == 4) return fk_attention_fwd4_launch(p, (int)n_items, false, stream);
   return use_interleaved(p) ? launch<8, false, true, false>(p, (int)n_items, stream)
                             : launch<8, false, false, false>(p, (int)n_items, stream);
 }

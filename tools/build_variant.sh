@@ -8,7 +8,7 @@ make -s
 out=../../build_ab/$name/gpt_image_edit_amd
 mkdir -p $out /tmp/fk_variant_$name
 extra=""
-[ "$src" = attention_bwd.hip ] && extra="-fno-slp-vectorize"
+{ [ "$src" = attention_bwd.hip ] || [ "$src" = attention_fwd4.hip ]; } && extra="-fno-slp-vectorize"
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -Wno-unused-result $extra "$@" -c $src -o /tmp/fk_variant_$name/${src%.hip}.o
 objs=$(ls *.o | grep -v "^${src%.hip}.o$")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs /tmp/fk_variant_$name/${src%.hip}.o -o $out/libfk_gfx950.so
