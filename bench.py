@@ -57,7 +57,7 @@ WORKLOADS = {
 }
 EXTRA_WORKLOAD = "single_1024x1024_28step"
 CFG3_WORKLOAD = "cfg3_batch32_1024x1024_28step"
-TRAFFIC_FILE = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"))
+TRAFFIC_FILE = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"))
                      if os.path.exists(f)), os.path.join(ROOT, "profiles", "r04_traffic.json"))
 
 
