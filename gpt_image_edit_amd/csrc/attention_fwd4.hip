@@ -159,52 +159,52 @@ __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
     return fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2;
   };
-  // half of a block's softmax numerators (registers [8 half, 8 half + 8)) + the packed P^T fragment of that 16-key step
-  auto expo_half = [&](f32x16_t& s, int half, float nm, float& psum, bf16x8_t& pf) __attribute__((always_inline)) {
-    const int r0 = 8 * half;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float pv = __builtin_amdgcn_exp2f(fmaf(s[r0 + e], p.scale_log2, nm));
-      s[r0 + e] = pv;
-      psum += pv;
-    }
-    u32x4_t pw;
-    pw[0] = pack_bf2(s[r0 + 0], s[r0 + 1]);
-    pw[1] = pack_bf2(s[r0 + 2], s[r0 + 3]);
-    pw[2] = pack_bf2(s[r0 + 4], s[r0 + 5]);
-    pw[3] = pack_bf2(s[r0 + 6], s[r0 + 7]);
-    pf = __builtin_bit_cast(bf16x8_t, pw);
-  };
-  // pins: one MFMA, then its share of the group's vector / transcendental / LDS work (the order hipcc would otherwise pick puts
-  // the whole softmax behind the MFMAs)
-#define FK_PIN_MFMA_VALU()                                      \
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \
-  __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);            \
-  __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);            \
-  __builtin_amdgcn_sched_group_barrier(0x002, 2, 0)
-#define FK_GROUP_FENCE() __builtin_amdgcn_sched_barrier(0)
-
   // pipeline registers
   bf16x8_t kf[8], vfr[8];
   f32x16_t sA, sB;
   bf16x8_t pA0, pA1, pB0, pB1;
 
-  // One 32-key block kb of the tile at sb: the four groups of the table above.  Operand fragments are read a whole group AHEAD
-  // of their first MFMA (with one wave per SIMD nothing else hides an LDS round trip: a read issued right in front of its MFMA
-  // costs the wave ~100 cycles, 24 times per tile -- the first form of this kernel did that and ran 11 % below the 8-wave one):
-  // the K fragments of the NEXT block arrive under O_A's MFMAs (group 4), this block's V^T fragments under S_B's (group 3).
+  // ---- hand-placed groups ------------------------------------------------------------------------------------------------
+  // hipcc's own schedule of this loop (pins by sched_group_barrier) clusters the MFMAs and parks the S^T blocks in AGPRs, which
+  // the vector unit cannot read (64 v_accvgpr_read per tile): 0.92-0.94 x the 8-wave kernel.  Here every group is written as
+  // its eight MFMA slots in program order -- one MFMA, then that slot's share of the other block's softmax (one scale-and-shift
+  // FMA, one exponential, one row-sum add, a pack every second slot) and of the fragment reads -- with a scheduling fence per
+  // slot, so the source order IS the issue order; and the S^T chains are inline-asm MFMAs on VGPR accumulators (the builtin's
+  // result class is the compiler's choice).  hipcc sees neither the matrix instruction nor its hazards inside an asm statement:
+  // the chain ends in the wait states an XDL result needs before a vector instruction may read it.
+#define FK_SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
+  auto s_mfma = [&](f32x16_t& acc, const bf16x8_t& a, const bf16x8_t& b, bool first) __attribute__((always_inline)) {
+    if (first) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  };
+  auto s_ready = [&](f32x16_t& acc) __attribute__((always_inline)) {   // XDL write -> VALU read of the same registers
+    asm volatile("s_nop 7\n\ts_nop 4" : "+v"(acc));
+  };
+  // slot i of a half (elements r0 .. r0 + 7 of block s): scale + exponential of element i, row sum of element i - 1, pack of
+  // the pair finished one slot earlier; the last slot also finishes what is pending
+  auto e_slot = [&](f32x16_t& s, int r0, int i, float nm, float& psum, u32x4_t& pw) __attribute__((always_inline)) {
+    s[r0 + i] = __builtin_amdgcn_exp2f(fmaf(s[r0 + i], p.scale_log2, nm));
+    if (i > 0) psum += s[r0 + i - 1];
+    if (i >= 2 && (i & 1) == 0) pw[(i - 2) >> 1] = pack_bf2(s[r0 + i - 2], s[r0 + i - 1]);
+    if (i == 7) {
+      psum += s[r0 + 7];
+      pw[3] = pack_bf2(s[r0 + 6], s[r0 + 7]);
+    }
+  };
   auto groups123 = [&](const char* sb, int kt, int kb, auto mask_tag, auto first_tag) __attribute__((always_inline)) {
     constexpr bool MASK = decltype(mask_tag)::value, FIRST = decltype(first_tag)::value;
     // ---- group 1: S_A(k) under the second half of E_B(k-1) -----------------------------------------------------------------
     {
       const float nmB = -mB;
-      expo_half(sB, 1, nmB, lB, pB1);
+      u32x4_t pw;
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qfA[kk], kk == 0 ? f32x16_t{} : sA, 0, 0, 0);
-        FK_PIN_MFMA_VALU();
+      for (int i = 0; i < 8; ++i) {
+        s_mfma(sA, kf[i], qfA[i], i == 0);
+        e_slot(sB, 8, i, nmB, lB, pw);
+        FK_SLOT_FENCE();
       }
-      FK_GROUP_FENCE();
+      pB1 = __builtin_bit_cast(bf16x8_t, pw);
+      s_ready(sA);
     }
     if constexpr (MASK) mask_block(sA, kt, kb);
     if constexpr (FIRST) {
@@ -213,28 +213,28 @@ __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams
     // ---- group 2: O_B += V(k-1) P_B(k-1) under the first half of E_A(k) --------------------------------------------------
     {
       const float nmA = -mA;
-      expo_half(sA, 0, nmA, lA, pA0);
+      u32x4_t pw;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         oB[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[i], (i >> 2) ? pB1 : pB0, oB[i & 3], 0, 0, 0);
-        FK_PIN_MFMA_VALU();
+        e_slot(sA, 0, i, nmA, lA, pw);
+        FK_SLOT_FENCE();
       }
-      FK_GROUP_FENCE();
+      pA0 = __builtin_bit_cast(bf16x8_t, pw);
     }
-    // ---- group 3: S_B(k) under the second half of E_A(k); this block's V^T fragments arrive (4 transpose reads per MFMA over
-    //      the first four MFMAs, so that all of them have landed when the group ends) -----------------------------------------
+    // ---- group 3: S_B(k) under the second half of E_A(k); this block's V^T fragments arrive, one per slot ---------------------
     {
       const float nmA = -mA;
-      expo_half(sA, 1, nmA, lA, pA1);
+      u32x4_t pw;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) vfr[i] = v_frag(sb, 2 * kb + (i >> 2), i & 3);
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        sB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qfB[kk], kk == 0 ? f32x16_t{} : sB, 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        FK_PIN_MFMA_VALU();
+      for (int i = 0; i < 8; ++i) {
+        s_mfma(sB, kf[i], qfB[i], i == 0);
+        vfr[i] = v_frag(sb, 2 * kb + (i >> 2), i & 3);
+        e_slot(sA, 8, i, nmA, lA, pw);
+        FK_SLOT_FENCE();
       }
-      FK_GROUP_FENCE();
+      pA1 = __builtin_bit_cast(bf16x8_t, pw);
+      s_ready(sB);
     }
     if constexpr (MASK) mask_block(sB, kt, kb);
     if constexpr (FIRST) {
@@ -245,21 +245,17 @@ __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams
   auto group4 = [&](const char* nsb, int nkb, auto next_tag) __attribute__((always_inline)) {
     constexpr bool NEXT = decltype(next_tag)::value;
     const float nmB = -mB;
-    expo_half(sB, 0, nmB, lB, pB0);
-    if constexpr (NEXT) {
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) kf[kk] = k_frag(nsb, nkb, kk);
-    }
+    u32x4_t pw;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       oA[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[i], (i >> 2) ? pA1 : pA0, oA[i & 3], 0, 0, 0);
-      if constexpr (NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      FK_PIN_MFMA_VALU();
+      if constexpr (NEXT) kf[i] = k_frag(nsb, nkb, i);
+      e_slot(sB, 0, i, nmB, lB, pw);
+      FK_SLOT_FENCE();
     }
-    FK_GROUP_FENCE();
+    pB0 = __builtin_bit_cast(bf16x8_t, pw);
   };
-#undef FK_PIN_MFMA_VALU
-#undef FK_GROUP_FENCE
+#undef FK_SLOT_FENCE
   // A tile = its two blocks.  The first block's K fragments are read right behind the tile's barrier (the one LDS round trip
   // per tile that nothing hides: acquiring the next tile early enough to prefetch them under the previous group made hipcc's
   // register allocation collapse -- 179 spilled registers); the second block's arrive under the first block's group 4.
@@ -283,7 +279,10 @@ __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams
   };
   // end of a pass: the pending half of stream B
   auto drain = [&]() __attribute__((always_inline)) {
-    expo_half(sB, 1, -mB, lB, pB1);
+    u32x4_t pw;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e_slot(sB, 8, i, -mB, lB, pw);
+    pB1 = __builtin_bit_cast(bf16x8_t, pw);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       oB[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[i], (i >> 2) ? pB1 : pB0, oB[i & 3], 0, 0, 0);

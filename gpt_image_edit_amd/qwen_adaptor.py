@@ -274,5 +274,4 @@ def bench_prompt_encode(device, batch=1, repeats=3):
     torch.cuda.empty_cache()
     return {"T_prompt_s": t_vlm + te["T_t5_clip_s"], "T_qwen_s": t_vlm, "T_t5_clip_s": te["T_t5_clip_s"], "runs_s": times,
             "vlm_tokens": L, "vlm_params": n_par, "text_encoders": te,
-            "what": "random-init Qwen2.5-VL-7B (cli.py:199-234: LM forward + task head, denoise_embeds forward + HIP projector; "
-                    "448^2 image + 44 text tokens) + random-init T5-XXL (256 tokens) / CLIP-L encode_prompt; stock transformers models"}
+            "what": "random-init Qwen2.5-VL-7B (cli.py:199-234, 448^2 image + 44 tokens) + T5-XXL (256 tokens) / CLIP-L encode_prompt"}
