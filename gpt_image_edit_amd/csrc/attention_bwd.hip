@@ -88,6 +88,10 @@ FK_DEV void buffer_lds(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset, 
   (void)rsrc; (void)lds_dst; (void)voffset; (void)soffset;
 #endif
 }
+template <int BYTES>
+FK_DEV void buffer_lds(const BufDesc& d, char* lds_dst, int voffset, int soffset) {
+  buffer_lds_opaque<BYTES>(d, lds_addr_of(lds_dst), voffset, soffset);
+}
 FK_DEV s16x4_t lds_tr16(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
 }
@@ -199,12 +203,11 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
 
   // ---- LDS-DMA of the streamed tiles: piece = 4 rows x 256 B, lane -> (row = lane / 16, 16-byte slot = lane % 16) ---
   auto rsrc_of = [&](const TView& t) __attribute__((always_inline)) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(t.p + (int64_t)b * t.bs + (int64_t)h * t.hs), 0,
-                                             (int)(((int64_t)(p.S - 1) * t.ld + HD) * 2), 0x00020000);
+    return make_dma_desc(t.p + (int64_t)b * t.bs + (int64_t)h * t.hs, ((int64_t)(p.S - 1) * t.ld + HD) * 2);
   };
-  const __amdgpu_buffer_rsrc_t rs_0 = rsrc_of(T0), rs_1 = rsrc_of(T1);
-  const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lse + (int64_t)bh * p.S), 0, p.S * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dsum + (int64_t)bh * p.S), 0, p.S * 4, 0x00020000);
+  const DmaDesc rs_0 = rsrc_of(T0), rs_1 = rsrc_of(T1);
+  const DmaDesc rs_l = make_dma_desc(p.lse + (int64_t)bh * p.S, (int64_t)p.S * 4);
+  const DmaDesc rs_d = make_dma_desc(p.dsum + (int64_t)bh * p.S, (int64_t)p.S * 4);
   // byte offset of source row q for LDS row r: the swizzle follows the LDS row
   auto voff = [&](const TView& t, int q, int r) __attribute__((always_inline)) { return (int)((q * t.ld + ((pslot ^ swz(r)) << 3)) * 2); };
   int v0[2], v1[2];
@@ -477,12 +480,11 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
   // ---- LDS-DMA of the query tiles: image 0 = Q, image 1 = dO, then lse and D of the 64 queries ------------------------
   const int prow = lane >> 4, pslot = lane & 15;
   auto rsrc_of = [&](const TView& t) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(t.p + (int64_t)b * t.bs + (int64_t)h * t.hs), 0,
-                                             (int)(((int64_t)(p.S - 1) * t.ld + HD) * 2), 0x00020000);
+    return make_dma_desc(t.p + (int64_t)b * t.bs + (int64_t)h * t.hs, ((int64_t)(p.S - 1) * t.ld + HD) * 2);
   };
-  const __amdgpu_buffer_rsrc_t rs_0 = rsrc_of(p.q), rs_1 = rsrc_of(p.dout);
-  const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lse + (int64_t)bh * p.S), 0, p.S * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dsum + (int64_t)bh * p.S), 0, p.S * 4, 0x00020000);
+  const DmaDesc rs_0 = rsrc_of(p.q), rs_1 = rsrc_of(p.dout);
+  const DmaDesc rs_l = make_dma_desc(p.lse + (int64_t)bh * p.S, (int64_t)p.S * 4);
+  const DmaDesc rs_d = make_dma_desc(p.dsum + (int64_t)bh * p.S, (int64_t)p.S * 4);
   const int nt = (p.S + CBLK - 1) / CBLK;
   const bool ragged = p.S % CBLK != 0;
   auto voff = [&](const TView& t, int q, int r) { return (int)((q * t.ld + ((pslot ^ swz(r)) << 3)) * 2); };

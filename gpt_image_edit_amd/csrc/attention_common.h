@@ -51,6 +51,9 @@ FK_DEV void buffer_lds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset
   (void)rsrc; (void)lds_dst; (void)voffset; (void)soffset;
 #endif
 }
+FK_DEV void buffer_lds16(const BufDesc& d, char* lds_dst, int voffset, int soffset) {
+  buffer_lds_opaque<16>(d, lds_addr_of(lds_dst), voffset, soffset);
+}
 FK_DEV s16x4_t lds_tr16(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
 }

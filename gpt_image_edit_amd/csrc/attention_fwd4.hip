@@ -5,6 +5,16 @@
 
 namespace {
 
+// Build-time switches of the experiments behind DESIGN.md section 4.0's attention table (defaults = what measured best):
+#ifndef FK_A4_DMA
+#define FK_A4_DMA 2      // a tile's 8 LDS-DMA requests: 0 in front of the first K-fragment reads, 1 behind them (under their
+#endif                   // latency), 2 one per MFMA slot of the tile's first group
+#ifndef FK_A4_EARLY
+#define FK_A4_EARLY 1    // 1: V^T fragments read one group earlier (behind the MFMA that frees the register), K likewise
+#endif
+constexpr int A4_STAGES = 3, A4_DMA = FK_A4_DMA;
+constexpr bool A4_EARLY = FK_A4_EARLY != 0;
+
 // ---- 4 waves, one per SIMD, 64 query rows per wave (round 5) --------------------------------------------------------------
 // The 8-wave kernel above is issue-bound: per KV tile and wave 32 MFMAs beside ~6.5 other instructions each, and the counters
 // say matrix time and vector time ADD on a SIMD that two waves share.  What moves that bound is fewer
@@ -24,7 +34,7 @@ namespace {
 // parity test; restart path, ragged last tile, stream-K seam likewise (the seam's partial layout is private to this kernel).
 template <bool STREAMK>
 __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams p) {
-  constexpr int NW = 4, STAGES = 3, QBLK = 256, LOADS = 32 / NW, KL = LOADS / 2, PF = STAGES - 1;
+  constexpr int NW = 4, STAGES = A4_STAGES, QBLK = 256, LOADS = 32 / NW, KL = LOADS / 2, PF = STAGES - 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -92,39 +102,40 @@ __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams
       qfB[kk] = *(const bf16x8_t*)(qbp + 16 * kk);
     }
   }
-  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, p.S * HD * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_v =
-      __builtin_amdgcn_make_buffer_rsrc((void*)Vg, 0, (int)(((int64_t)(p.S - 1) * p.v_ld + HD) * 2), 0x00020000);
-  int k_voff[KL], v_voff[KL];
-#pragma unroll
-  for (int i = 0; i < KL; ++i) {
-    const int r = (wave * KL + i) * 4 + prow;
-    k_voff[i] = (r * HD + ((pslot ^ (r & 15)) << 3)) * 2;
-    const int vcol = ((((pslot >> 2) ^ (r & 3)) << 5) + ((pslot & 3) << 3));
-    v_voff[i] = (int)((r * p.v_ld + vcol) * 2);
-  }
+  const DmaDesc rs_k = make_dma_desc(Kg, (int64_t)p.S * HD * 2);
+  const DmaDesc rs_v = make_dma_desc(Vg, ((int64_t)(p.S - 1) * p.v_ld + HD) * 2);
+  // LDS-DMA requests: a piece = 4 rows x 256 B (lane -> row prow, 16-byte slot pslot); wave w moves pieces w, w + 4, w + 8,
+  // w + 12 of a tile's 16.  Interleaved like that the swizzle term of the K source address (r & 15 = 4 w + prow) and the V
+  // one (r & 3 = prow) are the same for all four pieces: ONE lane offset each, the piece selected through the scalar offset
+  // (two lane constants live across the tile loop instead of eight -- the loop has no register to spare).
+  const int k_voff0 = ((wave * 4 + prow) * HD + ((pslot ^ (wave * 4 + prow)) << 3)) * 2;
+  const int v_voff0 = (int)(((wave * 4 + prow) * p.v_ld + ((((pslot >> 2) ^ prow) << 5) + ((pslot & 3) << 3))) * 2);
   const int k_tile_bytes = KVBLK * HD * 2, v_tile_bytes = (int)(KVBLK * p.v_ld * 2);
+  const int v_piece_step = (int)(16 * p.v_ld * 2);       // pieces w + 4 i: 16 rows apart
   auto issue_tile = [&](int kt, int stage) __attribute__((always_inline)) {
     char* sb = smem + stage * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < KL; ++i) {
-      buffer_lds16(rs_k, sb + (wave * KL + i) * 1024, k_voff[i], kt * k_tile_bytes);
-      buffer_lds16(rs_v, sb + K_TILE_BYTES + (wave * KL + i) * 1024, v_voff[i], kt * v_tile_bytes);
+      buffer_lds16(rs_k, sb + (i * NW + wave) * 1024, k_voff0, kt * k_tile_bytes + i * 4096);
+      buffer_lds16(rs_v, sb + K_TILE_BYTES + (i * NW + wave) * 1024, v_voff0, kt * v_tile_bytes + i * v_piece_step);
     }
   };
 
   f32x16_t oA[4], oB[4];
   constexpr float REF_BIAS = 24.0f;
-  float mA = 0.f, mB = 0.f, lA = 0.f, lB = 0.f;
+  float mA = 0.f, mB = 0.f, lA = 0.f, lB = 0.f, tA = 0.f, tB = 0.f;   // exponent references, running and tile row sums
   int st_cur = 0, st_pf = PF;
+  // The ring.  Forms 0 / 1 request a tile only if the pass has it (counted waits with a tail case); form 2 requests EVERY
+  // tile slot -- past the pass's end the last tile again, which nobody reads -- so that exactly 8 requests per tile are in
+  // flight and one counted wait serves every tile.
   auto fill = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < PF; ++s)
-      if (kt0 + s < kt1) issue_tile(kt0 + s, s);
+      if (A4_DMA == 2 || kt0 + s < kt1) issue_tile(min(kt0 + s, kt1 - 1), s);
     st_cur = 0;
     st_pf = PF;
   };
-  auto acquire_tile = [&](int kt) __attribute__((always_inline)) {
+  auto acquire_tile = [&](int kt) __attribute__((always_inline)) {      // the restart's pre-pass (fill_plain in front of it)
     if (kt + PF - 1 < kt1) wait_vmcnt<(PF - 1) * LOADS>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
@@ -162,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams
   // pipeline registers
   bf16x8_t kf[8], vfr[8];
   f32x16_t sA, sB;
-  bf16x8_t pA0, pA1, pB0, pB1;
+  u32x4_t pA[2], pB[2];      // packed numerators of the block in flight: keys 0..15 / 16..31 of the block
 
   // ---- hand-placed groups ------------------------------------------------------------------------------------------------
   // hipcc's own schedule of this loop (pins by sched_group_barrier) clusters the MFMAs and parks the S^T blocks in AGPRs, which
@@ -171,121 +182,156 @@ __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams
   // FMA, one exponential, one row-sum add, a pack every second slot) and of the fragment reads -- with a scheduling fence per
   // slot, so the source order IS the issue order; and the S^T chains are inline-asm MFMAs on VGPR accumulators (the builtin's
   // result class is the compiler's choice).  hipcc sees neither the matrix instruction nor its hazards inside an asm statement:
-  // the chain ends in the wait states an XDL result needs before a vector instruction may read it.
+  // an XDL result needs 12 wait states before a vector instruction may read it (hipcc puts s_nop 11 between the two when they
+  // are adjacent).  The softmax of a block therefore starts in the SECOND slot of the group behind its chain -- the first slot
+  // holds the last step of the other stream's half instead -- which leaves 6 to 8 instructions between the chain's last MFMA
+  // and the first read (hipcc moves a slot's MFMA about inside its fences); e_wait tops that up.  (As first written the softmax started in the first slot behind 13 idle states: four
+  // times a tile the matrix pipe stood still for them.)
 #define FK_SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
   auto s_mfma = [&](f32x16_t& acc, const bf16x8_t& a, const bf16x8_t& b, bool first) __attribute__((always_inline)) {
     if (first) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
     else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
   };
-  auto s_ready = [&](f32x16_t& acc) __attribute__((always_inline)) {   // XDL write -> VALU read of the same registers
+  auto s_ready = [&](f32x16_t& acc) __attribute__((always_inline)) {   // the full distance (mask / first-block maximum)
     asm volatile("s_nop 7\n\ts_nop 4" : "+v"(acc));
   };
-  // slot i of a half (elements r0 .. r0 + 7 of block s): scale + exponential of element i, row sum of element i - 1, pack of
-  // the pair finished one slot earlier; the last slot also finishes what is pending
-  auto e_slot = [&](f32x16_t& s, int r0, int i, float nm, float& psum, u32x4_t& pw) __attribute__((always_inline)) {
-    s[r0 + i] = __builtin_amdgcn_exp2f(fmaf(s[r0 + i], p.scale_log2, nm));
-    if (i > 0) psum += s[r0 + i - 1];
-    if (i >= 2 && (i & 1) == 0) pw[(i - 2) >> 1] = pack_bf2(s[r0 + i - 2], s[r0 + i - 1]);
-    if (i == 7) {
-      psum += s[r0 + 7];
-      pw[3] = pack_bf2(s[r0 + 6], s[r0 + 7]);
-    }
+  auto e_wait = [&](f32x16_t& acc) __attribute__((always_inline)) {    // 6 + the >= 6 instructions hipcc leaves in between
+    asm volatile("s_nop 5" : "+v"(acc));
   };
-  auto groups123 = [&](const char* sb, int kt, int kb, auto mask_tag, auto first_tag) __attribute__((always_inline)) {
+  // Step t (0..15) of a block's softmax: scale + exponential of element t, row sum of element t - 1, pack of the pair that
+  // element t - 1 completed; step 16 is what is left after the last exponential.  The row sums are formed exactly as the 8-wave
+  // kernel forms them -- a tile's 32 numerators summed in element order from zero (first block kb = 0, then kb = 1), the tile
+  // sum then added to the running sum -- whatever slots the steps land in: bit-identical l, hence lse and O.
+  auto e_step = [&](f32x16_t& s, int t, int kb, float nm, float& tsum, float& lrun, u32x4_t (&pk)[2]) __attribute__((always_inline)) {
+    if (t < 16) s[t] = __builtin_amdgcn_exp2f(fmaf(s[t], p.scale_log2, nm));
+    if (t == 1 && kb == 0) tsum = s[0];
+    else if (t > 0) tsum += s[t - 1];
+    if (t == 16 && kb == 1) lrun += tsum;
+    if (t >= 2 && (t & 1) == 0) pk[(t - 2) >> 3][((t - 2) >> 1) & 3] = pack_bf2(s[t - 2], s[t - 1]);
+  };
+  auto pfrag = [&](const u32x4_t& w) __attribute__((always_inline)) { return __builtin_bit_cast(bf16x8_t, w); };
+  // request i (0..7) of the tile that goes into stage st_pf: K piece i / 2 (even i) or V piece i / 2 (odd i) of this wave
+  auto issue_piece = [&](int kt, int i) __attribute__((always_inline)) {
+    char* sb = smem + st_pf * STAGE_BYTES;
+    const int pc = i >> 1;
+    if ((i & 1) == 0) buffer_lds16(rs_k, sb + (pc * NW + wave) * 1024, k_voff0, kt * k_tile_bytes + pc * 4096);
+    else buffer_lds16(rs_v, sb + K_TILE_BYTES + (pc * NW + wave) * 1024, v_voff0, kt * v_tile_bytes + pc * v_piece_step);
+  };
+  // Slot j of a group runs: j = 0 the pending step of the stream that was in the previous group, j >= 1 step base + j - 1 of
+  // this group's stream.
+  //   group 1  S_A(k)     | B(k-1): step 7 ; steps 8..14                    (+ form 2: the next tile's requests, one per slot)
+  //   group 2  PV_B(k-1)  | B(k-1): steps 15, 16 ; A(k): steps 0..6
+  //   group 3  S_B(k)     | A(k): step 7 ; steps 8..14                      + this block's V^T fragments, one per slot
+  //   group 4  PV_A(k)    | A(k): steps 15, 16 ; B(k): steps 0..6           + the next block's K fragments, one per slot
+  // (FK_A4_EARLY moves the V^T reads to group 2 and the second block's K reads to group 3, each behind the MFMA that was the
+  //  register's last reader.)
+  auto groups123 = [&](const char* sb, int kt, int kb, int kt_req, auto mask_tag, auto first_tag) __attribute__((always_inline)) {
     constexpr bool MASK = decltype(mask_tag)::value, FIRST = decltype(first_tag)::value;
-    // ---- group 1: S_A(k) under the second half of E_B(k-1) -----------------------------------------------------------------
     {
       const float nmB = -mB;
-      u32x4_t pw;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         s_mfma(sA, kf[i], qfA[i], i == 0);
-        e_slot(sB, 8, i, nmB, lB, pw);
+        e_step(sB, 7 + i, kb ^ 1, nmB, tB, lB, pB);
+        if (A4_DMA == 2 && kb == 0) issue_piece(kt_req, i);
         FK_SLOT_FENCE();
       }
-      pB1 = __builtin_bit_cast(bf16x8_t, pw);
-      s_ready(sA);
     }
+    if constexpr (MASK || FIRST) s_ready(sA);
     if constexpr (MASK) mask_block(sA, kt, kb);
     if constexpr (FIRST) {
       if (kb == 0) mA = block_max(sA) + REF_BIAS;
     }
-    // ---- group 2: O_B += V(k-1) P_B(k-1) under the first half of E_A(k) --------------------------------------------------
     {
-      const float nmA = -mA;
-      u32x4_t pw;
+      const float nmA = -mA, nmB = -mB;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        oB[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[i], (i >> 2) ? pB1 : pB0, oB[i & 3], 0, 0, 0);
-        e_slot(sA, 0, i, nmA, lA, pw);
+        oB[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[i], pfrag(pB[i >> 2]), oB[i & 3], 0, 0, 0);
+        if constexpr (A4_EARLY) vfr[i] = v_frag(sb, 2 * kb + (i >> 2), i & 3);
+        if (i == 0) {
+          e_step(sB, 15, kb ^ 1, nmB, tB, lB, pB);
+          e_step(sB, 16, kb ^ 1, nmB, tB, lB, pB);
+        } else {
+          if (i == 1 && !(MASK || FIRST)) e_wait(sA);
+          e_step(sA, i - 1, kb, nmA, tA, lA, pA);
+        }
         FK_SLOT_FENCE();
       }
-      pA0 = __builtin_bit_cast(bf16x8_t, pw);
     }
-    // ---- group 3: S_B(k) under the second half of E_A(k); this block's V^T fragments arrive, one per slot ---------------------
     {
       const float nmA = -mA;
-      u32x4_t pw;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         s_mfma(sB, kf[i], qfB[i], i == 0);
-        vfr[i] = v_frag(sb, 2 * kb + (i >> 2), i & 3);
-        e_slot(sA, 8, i, nmA, lA, pw);
+        if constexpr (!A4_EARLY) vfr[i] = v_frag(sb, 2 * kb + (i >> 2), i & 3);
+        else if (kb == 0) kf[i] = k_frag(sb, 1, i);
+        e_step(sA, 7 + i, kb, nmA, tA, lA, pA);
         FK_SLOT_FENCE();
       }
-      pA1 = __builtin_bit_cast(bf16x8_t, pw);
-      s_ready(sB);
     }
+    if constexpr (MASK || FIRST) s_ready(sB);
     if constexpr (MASK) mask_block(sB, kt, kb);
     if constexpr (FIRST) {
       if (kb == 0) mB = block_max(sB) + REF_BIAS;
     }
   };
-  // ---- group 4: O_A += V(k) P_A(k) under the first half of E_B(k); the next block's K fragments (rows at nsb, block nkb) arrive
-  auto group4 = [&](const char* nsb, int nkb, auto next_tag) __attribute__((always_inline)) {
+  // group 4; the S_B chain is >= 18 instructions away from its first reader here (fragment reads and their waits in between):
+  // no e_wait (tools/a4_census.py and tests/test_kernel_resources.py check both distances in the generated code)
+  auto group4 = [&](const char* nsb, int nkb, int kb, auto next_tag) __attribute__((always_inline)) {
     constexpr bool NEXT = decltype(next_tag)::value;
-    const float nmB = -mB;
-    u32x4_t pw;
+    const float nmA = -mA, nmB = -mB;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      oA[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[i], (i >> 2) ? pA1 : pA0, oA[i & 3], 0, 0, 0);
-      if constexpr (NEXT) kf[i] = k_frag(nsb, nkb, i);
-      e_slot(sB, 0, i, nmB, lB, pw);
+      oA[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[i], pfrag(pA[i >> 2]), oA[i & 3], 0, 0, 0);
+      if constexpr (NEXT && !A4_EARLY) kf[i] = k_frag(nsb, nkb, i);
+      if (i == 0) {
+        e_step(sA, 15, kb, nmA, tA, lA, pA);
+        e_step(sA, 16, kb, nmA, tA, lA, pA);
+      } else {
+        if (i == 1 && A4_EARLY) e_wait(sB);
+        e_step(sB, i - 1, kb, nmB, tB, lB, pB);
+      }
       FK_SLOT_FENCE();
     }
-    pB0 = __builtin_bit_cast(bf16x8_t, pw);
   };
 #undef FK_SLOT_FENCE
-  // A tile = its two blocks.  The first block's K fragments are read right behind the tile's barrier (the one LDS round trip
-  // per tile that nothing hides: acquiring the next tile early enough to prefetch them under the previous group made hipcc's
-  // register allocation collapse -- 179 spilled registers); the second block's arrive under the first block's group 4.
+  // A tile = its two blocks.  The first block's K fragments are read right behind the tile's barrier -- the one LDS round trip
+  // per tile that nothing hides; the tile's LDS-DMA requests are issued under it (form 1) or spread over the first group
+  // (form 2).  Moving the barrier to the middle of the tile, so that these fragments too arrive under the previous group, was
+  // tried: the extra addressing (two stage bases per tile) costs more issue slots than the round trip (0.90-0.95 x, call I).
   auto do_tile = [&](int kt, auto mask_tag, auto first_tag) __attribute__((always_inline)) {
-    const char* sb = acquire_tile(kt);
+    if (A4_DMA == 2 || kt + PF - 1 < kt1) wait_vmcnt<(PF - 1) * LOADS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    const char* sb = smem + st_cur * STAGE_BYTES;
+    if (A4_DMA == 0 && kt + PF < kt1) issue_tile(kt + PF, st_pf);
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) kf[kk] = k_frag(sb, 0, kk);
-    groups123(sb, kt, 0, mask_tag, first_tag);
-    group4(sb, 1, std::true_type{});
-    groups123(sb, kt, 1, mask_tag, std::false_type{});
-    group4(sb, 0, std::false_type{});
+    if (A4_DMA == 1 && kt + PF < kt1) issue_tile(kt + PF, st_pf);
+    groups123(sb, kt, 0, min(kt + PF, kt1 - 1), mask_tag, first_tag);
+    group4(sb, 1, 0, std::true_type{});
+    groups123(sb, kt, 1, 0, mask_tag, std::false_type{});
+    group4(sb, 0, 1, std::false_type{});
     release_tile();
   };
-  // start of a pass: an empty "previous block" of stream B (numerators and V fragments zero: O_B += 0)
+  // start of a pass: an empty "previous block" of stream B, stopped where group 1 picks a block up -- steps 0..6 done
+  // (numerators zero), elements 7..15 still scores (-3e38: their exponentials are zero); V fragments zero: O_B += 0
   auto prime = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sB[r] = -3.0e38f;
+    for (int r = 0; r < 16; ++r) sB[r] = r < 7 ? 0.f : -3.0e38f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) vfr[i] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-    pB0 = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    pB[0] = u32x4_t{0, 0, 0, 0};
+    pB[1] = u32x4_t{0, 0, 0, 0};
+    tB = 0.f;      // the empty block counts as the second block of a tile: its zero tile sum joins l_B in group 2
   };
-  // end of a pass: the pending half of stream B
+  // end of a pass: what stream B still owes (steps 7..16 of its last block, that block's PV)
   auto drain = [&]() __attribute__((always_inline)) {
-    u32x4_t pw;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) e_slot(sB, 8, i, -mB, lB, pw);
-    pB1 = __builtin_bit_cast(bf16x8_t, pw);
+    for (int t = 7; t <= 16; ++t) e_step(sB, t, 1, -mB, tB, lB, pB);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      oB[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[i], (i >> 2) ? pB1 : pB0, oB[i & 3], 0, 0, 0);
+      oB[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[i], pfrag(pB[i >> 2]), oB[i & 3], 0, 0, 0);
   };
 
   using TT = std::true_type;
@@ -306,6 +352,7 @@ __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams
       else do_tile(last, FF{}, FF{});
     }
     drain();
+    if (A4_DMA == 2) wait_vmcnt<0>();     // the two repeat requests behind the last tile: nothing may land after the pass
   };
   // plain S^T block (the restart's K-only pre-pass): query block X of the wave against key block kb
   auto scores_plain = [&](const char* sb, int kb, const bf16x8_t (&qf)[8]) __attribute__((always_inline)) {
@@ -467,7 +514,7 @@ __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams
 
 template <bool STREAMK>
 int launch4(const AttnParams& p, int grid, hipStream_t stream) {
-  constexpr int SMEM = 3 * STAGE_BYTES + 16;
+  constexpr int SMEM = A4_STAGES * STAGE_BYTES + 16;
   auto kern = attention_fwd4_kernel<STREAMK>;
   FK_ENSURE_MAX_LDS(kern, SMEM, "fk_attention_fwd_bf16 (4 waves x 64 rows)");
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), SMEM, stream, p);

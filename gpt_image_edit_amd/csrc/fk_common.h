@@ -59,6 +59,45 @@ FK_DEV float silu_f(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// ---- LDS-DMA request as one opaque statement ---------------------------------------------------------------------------------
+// hipcc knows that __builtin_amdgcn_raw_ptr_buffer_load_lds writes LDS and, having no alias information for it, puts
+// s_waitcnt vmcnt(0) in front of the next LDS read it cannot prove disjoint -- inside a tile loop that is a wait for the
+// prefetch just issued (the attention kernels' steady loops all carried one, 6 to 16 MFMAs behind their requests).  A kernel
+// that orders its ring itself (counted vmcnt + barrier before a stage is read) issues the request through this form: the
+// compiler sees neither a load nor an LDS write, its own vmcnt counts stay conservative (requests retire in order), and the
+// descriptor is spelled out because the opaque resource type is no asm operand.  FK_OPAQUE_DMA=0 restores the builtin (A/B).
+#ifndef FK_OPAQUE_DMA
+#define FK_OPAQUE_DMA 1
+#endif
+struct BufDesc { u32x4_t w; };
+FK_DEV BufDesc make_buf_desc(const void* base, unsigned bytes) {
+  const uint64_t a = (uint64_t)base;
+  return BufDesc{u32x4_t{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u}};
+}
+template <int BYTES>
+FK_DEV void buffer_lds_opaque(const BufDesc& d, unsigned lds_addr, int voffset, int soffset) {
+  static_assert(BYTES == 16 || BYTES == 4, "LDS-DMA piece: 16 or 4 bytes per lane");
+  // M0: hipcc sets it next to each of its own uses; the s_nop is the SALU-write-M0 -> LDS-DMA wait state it also emits
+  if constexpr (BYTES == 16)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voffset), "s"(d.w), "s"(soffset) : "memory");
+  else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voffset), "s"(d.w), "s"(soffset) : "memory");
+}
+FK_DEV unsigned lds_addr_of(const char* lds_ptr) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)lds_ptr;
+}
+#if FK_OPAQUE_DMA
+typedef BufDesc DmaDesc;
+FK_DEV DmaDesc make_dma_desc(const void* base, int64_t bytes) { return make_buf_desc(base, (unsigned)bytes); }
+#else
+typedef __amdgpu_buffer_rsrc_t DmaDesc;
+FK_DEV DmaDesc make_dma_desc(const void* base, int64_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+#endif
+
 FK_DEV int64_t fk_row_offset(const fk_rows& r, int64_t m) {
   if (r.rows_per_batch <= 0) return m * r.ld;
   int64_t b = m / r.rows_per_batch;

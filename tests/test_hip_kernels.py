@@ -421,6 +421,53 @@ def test_attention(ops, B, H, S):
     assert torch.equal(out2[..., :H * 128], out[..., :H * 128]) and out2[..., H * 128:].abs().max().item() == 0
 
 
+_TWO_KERNELS_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from gpt_image_edit_amd import ops
+BF = torch.bfloat16
+outs = {}
+for B, H, S, lse_on in [(1, 2, 64, False), (2, 3, 75, True), (1, 2, 300, False), (2, 2, 257, True), (1, 1, 1000, False),
+                        (1, 24, 2560, True), (1, 24, 5632, False), (2, 24, 4096, True)]:
+    g = torch.Generator(device="cuda").manual_seed(1000 * S + B)
+    q = torch.randn(B, H, S, 128, device="cuda", generator=g).to(BF)
+    k = torch.randn(B, H, S, 128, device="cuda", generator=g).to(BF)
+    if S == 300:
+        k[:, :, 200] = q[:, :, 17] * 2.0
+        k[:, :, 290] = q[:, :, 150] * 40.0       # late large logit: the exponent-overflow restart
+    qkv = torch.randn(B, S, 3 * H * 128, device="cuda", generator=g).to(BF)
+    o = torch.zeros(B, S, H * 128, device="cuda", dtype=BF)
+    if lse_on:
+        lse = torch.zeros(B, H, S, device="cuda", dtype=torch.float32)
+        ops.attention_lse(q, k, qkv[:, :, 2 * H * 128:], o, lse)
+        outs[f"lse_{B}_{H}_{S}"] = lse.cpu()
+    else:
+        ops.attention(q, k, qkv[:, :, 2 * H * 128:], o)
+    outs[f"o_{B}_{H}_{S}"] = o.cpu()
+torch.save(outs, sys.argv[2])
+"""
+
+
+@pytest.mark.gpu
+def test_attention_two_kernels_agree_bit_for_bit(tmp_path):
+    """The 4-wave x 64-row forward (default) and the 8-wave x 32-row one are independent implementations of the same sums in
+    the same order: every output element and every saved log-sum-exp must be IDENTICAL -- short, ragged, restart, plain-grid
+    and stream-K shapes.  The library reads FK_ATTN_KERNEL once, so each kernel runs in its own process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for kern in ("4", "8"):
+        out = tmp_path / f"k{kern}.pt"
+        env = dict(os.environ, FK_ATTN_KERNEL=kern)
+        subprocess.run([sys.executable, "-c", _TWO_KERNELS_SCRIPT, root, str(out)], check=True, env=env, timeout=600)
+        res[kern] = torch.load(out)
+    assert res["4"].keys() == res["8"].keys() and len(res["4"]) >= 12
+    for name in res["4"]:
+        a, b = res["4"][name], res["8"][name]
+        assert torch.equal(a, b), f"{name}: {(a.float() - b.float()).abs().max().item()} max difference between the kernels"
+        assert torch.isfinite(a.float()).all() and a.float().abs().max().item() > 0
+
+
 @pytest.mark.parametrize("B,H,S", [(1, 2, 64), (2, 3, 75), (1, 2, 300), (1, 4, 2560), (2, 2, 257)])
 def test_attention_fp32_debug_output_at_stated_tolerance(ops, B, H, S):
     """fk_attention_fwd_f32_debug = the same kernel with fp32 output and P entering PV as hi + lo bf16 terms: tiling,

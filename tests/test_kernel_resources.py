@@ -79,3 +79,40 @@ def test_hot_kernels_keep_their_accumulators_in_registers(src, tmp_path):
             n_mfma = sum("v_mfma" in x for x in k_loop)
             assert n_mfma == (128 if "16x16x32" in "".join(k_loop) else 64)      # 32 x 32 x 16: 64 per two K-tiles; 16 x 16 x 32: 128
             assert not any("scratch_" in x for x in k_loop), f"{lines[a][:70]}: scratch traffic inside the K loop"
+
+
+def test_attention_fwd4_hand_placed_hazards_and_steady_loop(tmp_path):
+    """attention_fwd4_kernel issues its S^T chains as inline-asm MFMAs, whose hazards hipcc cannot see: an XDL result needs 12
+    wait states before a vector instruction reads it.  Read the generated code: every chain's last MFMA is >= 12 issue states
+    (instructions + s_nop states, the hazard recognizer's own count) away from the first VALU read of its accumulator; and the
+    steady-state tile loop (64 MFMAs) carries no AGPR copies, no scratch traffic and no wait for ALL vector-memory requests
+    (the LDS-DMA prefetch in flight)."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("a4_census", os.path.join(os.path.dirname(CSRC), "..", "tools", "a4_census.py"))
+    census = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(census)
+    out = tmp_path / "attention_fwd4.s"
+    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "-Wno-unused-value", "-Wno-unused-result",
+           "-S", "--cuda-device-only", os.path.join(CSRC, "attention_fwd4.hip"), "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    text = out.read_text()
+    steady = 0
+    for tag in ("ILb0E", "ILb1E"):
+        name = "_ZN12_GLOBAL__N_121attention_fwd4_kernel%sEEv10AttnParams" % tag
+        i = text.index(name + ":")
+        body = text[i:text.index(".Lfunc_end", i)]
+        chains = 0
+        for lab, ins in census.blocks_of(body):
+            if sum(x.startswith("v_mfma") for x in ins) < 32:
+                continue
+            for at, states, reader in census.hazard_distances(ins):
+                chains += 1
+                assert states >= 12, f"{tag} {lab}: {states} states between the chain's last MFMA (#{at}) and `{reader}`"
+            n_mfma = sum(x.startswith("v_mfma") for x in ins)
+            if (n_mfma == 64 and not any("accvgpr" in x for x in ins) and not any("scratch_" in x for x in ins)
+                    and not any("vmcnt(0)" in x for x in ins)):
+                steady += 1
+        assert chains >= 8, f"{tag}: only {chains} asm chains found"
+    assert steady >= 2, "no clean 64-MFMA tile body found (AGPR copies, scratch or vmcnt(0) in every one)"
