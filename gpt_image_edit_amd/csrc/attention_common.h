@@ -66,6 +66,18 @@ FK_DEV void wait_vmcnt() {
   else static_assert(N == 0, "add the vmcnt literal");
 }
 
+// a w_a + b w_b of the stream-K seam, both products ROUNDED before the sum: the two parts of a cut item must merge to the same
+// bits whichever of them arrives second.  __fmul_rn / __fadd_rn are plain operators to hipcc, and under its default
+// -ffp-contract=fast-honor-pragmas the expression became v_mul + v_fmac -- one product exact, the other rounded, i.e. a
+// result that depends on the arrival order in about one merged row in five (found when the two forward kernels, which
+// happen to meet in opposite orders, disagreed in 18 of 17 M output elements at S = 5632).
+FK_DEV float merge2(float a, float wa, float b, float wb) {
+#pragma clang fp contract(off)
+  const float pa = a * wa;
+  const float pb = b * wb;
+  return pa + pb;
+}
+
 #ifndef FK_ATTN_PRIO
 #define FK_ATTN_PRIO 1   // static s_setprio(1) for the younger half of the workgroup (waves NW/2 .. NW-1)
 #endif

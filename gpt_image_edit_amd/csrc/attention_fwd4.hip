@@ -464,10 +464,10 @@ __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams
             const int q4 = (r0 + e) & 3;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              a[4 * q4 + j] = __fadd_rn(__fmul_rn(a[4 * q4 + j], w_s), __fmul_rn(__uint_as_float(v[e][j]), w_o));
+              a[4 * q4 + j] = merge2(a[4 * q4 + j], w_s, __uint_as_float(v[e][j]), w_o);
           }
         }
-        l_run = __fadd_rn(__fmul_rn(l_run, w_s), __fmul_rn(l_o, w_o));
+        l_run = merge2(l_run, w_s, l_o, w_o);
         if (gave_up) l_run = __builtin_nanf("");
         m_ref = m_new;
       };
