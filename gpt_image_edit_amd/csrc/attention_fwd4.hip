@@ -15,23 +15,28 @@ namespace {
 constexpr int A4_STAGES = 3, A4_DMA = FK_A4_DMA;
 constexpr bool A4_EARLY = FK_A4_EARLY != 0;
 
-// ---- 4 waves, one per SIMD, 64 query rows per wave (round 5) --------------------------------------------------------------
-// The 8-wave kernel above is issue-bound: per KV tile and wave 32 MFMAs beside ~6.5 other instructions each, and the counters
-// say matrix time and vector time ADD on a SIMD that two waves share.  What moves that bound is fewer
-// non-matrix instructions per MFMA, and the one large item is the operand reads: here a wave owns TWO 32-row query blocks (A, B),
-// so every K fragment and every V^T fragment it reads from LDS feeds two MFMAs -- 0.75 LDS reads per MFMA instead of 1.5 -- and
-// the wave has the SIMD's whole register file (O^T of both blocks, 128 accumulator registers, lives in the AGPR half).
-// With one wave per SIMD nothing else hides the softmax arithmetic, so the wave overlaps it with its OWN matrix work: the two
-// query blocks run as two streams half a step apart.  Per 32-key block k, four groups of 8 MFMAs:
-//     matrix pipe                      vector / LDS work issued in the shadow of those MFMAs
-//     S_A(k)   = K(k) Q_A^T            second half of the exponentials of S_B(k-1), packs;  8 K-fragment reads (kept for S_B)
-//     O_B     += V(k-1) P_B(k-1)       first half of the exponentials of S_A(k)                    (V fragments kept from O_A)
-//     S_B(k)   = K(k) Q_B^T            second half of the exponentials of S_A(k), packs
-//     O_A     += V(k) P_A(k)           first half of the exponentials of S_B(k);            16 V^T transpose reads (kept for O_B)
-// = 32 MFMAs beside 112 vector instructions and 24 LDS reads: ~4.3 per MFMA (the guide's limit for a single wave: 5).  Only
-// registers cross a tile boundary (S_B, V fragments), so the K / V ring, its barrier per tile and the LDS-DMA requests are the
-// 8-wave kernel's.  Every row's sums are formed in the same order as there: the two kernels agree bit for bit, which is the
-// parity test; restart path, ragged last tile, stream-K seam likewise (the seam's partial layout is private to this kernel).
+// ---- 4 waves, one per SIMD, 64 query rows per wave (round 5; the default forward) --------------------------------------------
+// The 8-wave kernel of attention_fwd.hip is issue-bound: per KV tile and wave 32 MFMAs beside ~6.5 other instructions each, and
+// the counters say matrix time and vector time ADD on a SIMD that two waves share.  What moves that
+// bound is fewer non-matrix instructions per MFMA, and the one large item is the operand reads: here a wave owns TWO 32-row
+// query blocks (A, B), so every K fragment and every V^T fragment it reads from LDS feeds two MFMAs -- 0.75 LDS reads per
+// MFMA instead of 1.5 -- and the wave has the SIMD's whole register file (O^T of both blocks, 128 accumulator registers, lives
+// in the AGPR half).  With one wave per SIMD nothing else hides the softmax arithmetic, so the wave overlaps it with its OWN
+// matrix work: the two query blocks run as two streams half a step apart.  Per 32-key block k, four groups of 8 MFMA slots
+// (the table in front of groups123 has the exact step-to-slot map):
+//     matrix pipe                      issued in the shadow of those MFMAs, one share per slot
+//     S_A(k)   = K(k) Q_A^T            softmax steps 7..14 of S_B(k-1);   first block of a tile: the next tile's 8 LDS-DMA requests
+//     O_B     += V(k-1) P_B(k-1)       last steps of S_B(k-1), steps 0..6 of S_A(k);   this block's 8 V^T fragments (16 tr reads)
+//     S_B(k)   = K(k) Q_B^T            steps 7..14 of S_A(k);             first block of a tile: the second block's 8 K fragments
+//     O_A     += V(k) P_A(k)           last steps of S_A(k), steps 0..6 of S_B(k)
+// Per tile (64 MFMAs): 224 vector instructions, 48 LDS reads, 8 requests = 4.4 per MFMA, ~445 instructions with the waits,
+// address adds and scalar work hipcc adds (the guide's budget for a single wave: 5 besides the MFMA).  Measured:
+// 62 % matrix-pipe busy at 1.76 GHz against the 8-wave kernel's 52 % at 1.84 GHz, 1.13-1.31 PF/s = 1.05-1.14 x.
+// Only registers cross a tile boundary (S_B, its packed numerators, the V fragments), so the K / V ring and its barrier per
+// tile are the 8-wave kernel's.  Every row's sums are formed in the same order as there (tile sums, then the running sum): the
+// two kernels agree bit for bit -- outputs and log-sum-exps, plain and stream-K grids -- which is the parity test
+// (tests/test_hip_kernels.py::test_attention_two_kernels_agree_bit_for_bit); restart path, ragged last tile and stream-K seam
+// likewise (the seam's partial layout is private to this kernel).
 template <bool STREAMK>
 __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams p) {
   constexpr int NW = 4, STAGES = A4_STAGES, QBLK = 256, LOADS = 32 / NW, KL = LOADS / 2, PF = STAGES - 1;
