@@ -443,6 +443,12 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_kernel(const BwdParams p
 // producers work on query tile i, the consumers on tile i - 1 (whose p the producers stored in iteration i - 1), the DMA
 // fetches tile i + 1 into the stage the consumers left in iteration i - 1; one workgroup barrier per iteration orders all
 // three.  LDS: 3 stages x (Q | dO | lse, D) + 32 KiB of packed p = 132 608 B.
+// STREAMK (round 5): the dQ pass's persistent grid and seam for this pass too.  An item = 128 keys of one (b, h), its units the
+// nt query tiles it walks; 1 632 items at S = 8704 are 6.4 rounds of 256 workgroups (run as 7: 9 % of the CU time idle).  The
+// two parts of a cut item ADD their fp32 accumulators (the producers' dV^T, the consumers' dK^T) through the cut's workspace
+// slot: commutative, so still deterministic.  Built, parity-green, and no faster than the plain grid (the launcher has the
+// numbers): not the default.
+template <bool STREAMK>
 __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -460,8 +466,46 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     t0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   }
-  const int rb = t0 % nrb;
-  const int bh = t0 / nrb;
+  const int nt = (p.S + CBLK - 1) / CBLK;
+  const bool ragged = p.S % CBLK != 0;
+  int u = 0, u_end = 0, round = 0;      // the work list of attention_bwd_kernel<.., STREAMK>
+  if constexpr (STREAMK) {
+    const unsigned G = gridDim.x;
+    const unsigned U = (unsigned)(p.n_items - p.sk_rounds * (int)G) * (unsigned)nt;
+    const unsigned qU = U / G, rU = U - qU * G;
+    auto cut = [&](unsigned j) __attribute__((always_inline)) {
+      unsigned c = qU * j + (rU * j) / G;
+      const unsigned r = c % (unsigned)nt;
+      if (r != 0 && r < (unsigned)p.min_part) c -= r;
+      else if (r != 0 && (unsigned)nt - r < (unsigned)p.min_part) c += (unsigned)nt - r;
+      return (int)c;
+    };
+    u = cut(t0);
+    u_end = cut(t0 + 1);
+  }
+#if FK_BWD_PRIO == 1
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // as in attention_bwd_kernel: the consumers
+#elif FK_BWD_PRIO == 2
+  if (wave < 4) __builtin_amdgcn_s_setprio(1);    // the producers
+#endif
+
+  for (;;) {   // one pass per (item, query-tile range); a plain launch makes exactly one
+  int item = t0, tb = 0, te = nt;
+  if constexpr (STREAMK) {
+    if (round < p.sk_rounds) {
+      item = round * (int)gridDim.x + t0;
+      ++round;
+    } else {
+      if (u >= u_end) break;
+      const int ti = (unsigned)(u_end - 1) / (unsigned)nt;
+      item = p.sk_rounds * (int)gridDim.x + ti;
+      te = u_end - ti * nt;
+      tb = max(u - ti * nt, 0);
+      u_end -= te - tb;
+    }
+  }
+  const int rb = item % nrb;
+  const int bh = item / nrb;
   const int b = bh / p.H, h = bh - b * p.H;
 
   // ---- stationary row operand: K rows for the producer, V rows for the consumer ----------------------------------------
@@ -485,8 +529,6 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
   const DmaDesc rs_0 = rsrc_of(p.q), rs_1 = rsrc_of(p.dout);
   const DmaDesc rs_l = make_dma_desc(p.lse + (int64_t)bh * p.S, (int64_t)p.S * 4);
   const DmaDesc rs_d = make_dma_desc(p.dsum + (int64_t)bh * p.S, (int64_t)p.S * 4);
-  const int nt = (p.S + CBLK - 1) / CBLK;
-  const bool ragged = p.S % CBLK != 0;
   auto voff = [&](const TView& t, int q, int r) { return (int)((q * t.ld + ((pslot ^ swz(r)) << 3)) * 2); };
   int v0[2], v1[2];
 #pragma unroll
@@ -636,14 +678,9 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
   };
 
   char* const pbuf = smem + STAGES * STAGE_BYTES + pair * 8192 + lane * 16;
-  issue_tile(0, 0);
-#if FK_BWD_PRIO == 1
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // as in attention_bwd_kernel: the consumers
-#elif FK_BWD_PRIO == 2
-  if (wave < 4) __builtin_amdgcn_s_setprio(1);    // the producers
-#endif
+  issue_tile(tb, 0);
 
-  // Iteration i = 0 .. nt of BOTH roles: wait for the own DMA pieces of tile i and the own p stores of tile i - 1, meet,
+  // Iteration i = tb .. te of BOTH roles: wait for the own DMA pieces of tile i and the own p stores of tile i - 1, meet,
   // start the DMA of tile i + 1 into the stage the consumers left in iteration i - 1.  The roles run separate loops (one
   // accumulator live range each, no copies where they would join); the barrier counts arrivals, not program counters.
   int st_pro = 0, st_con = STAGES - 1, st_dma = 1;   // stages of tiles i, i - 1, i + 1
@@ -651,33 +688,92 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (i + 1 < nt) issue_tile(i + 1, st_dma);
+    if (i + 1 < te) issue_tile(i + 1, st_dma);
   };
   auto rotate = [&]() {
     st_con = st_pro;
     st_pro = st_dma;
     st_dma = (st_dma == STAGES - 1) ? 0 : st_dma + 1;
   };
+  const bool masked_last = ragged && te == nt;       // the ragged tile is the item's last one
   if (producer) {
-    const int n_plain = ragged ? nt - 1 : nt;
-    for (int i = 0; i < n_plain; ++i) {
+    const int n_plain = masked_last ? te - 1 : te;
+    for (int i = tb; i < n_plain; ++i) {
       meet(i);
-      producer_plain(smem + st_pro * STAGE_BYTES, pbuf + (i & 1) * 4096, i, std::false_type{});
+      producer_plain(smem + st_pro * STAGE_BYTES, pbuf + ((i - tb) & 1) * 4096, i, std::false_type{});
       rotate();
     }
-    if (ragged) {
+    if (masked_last) {
       meet(nt - 1);
-      producer_plain(smem + st_pro * STAGE_BYTES, pbuf + ((nt - 1) & 1) * 4096, nt - 1, std::true_type{});
+      producer_plain(smem + st_pro * STAGE_BYTES, pbuf + ((nt - 1 - tb) & 1) * 4096, nt - 1, std::true_type{});
       rotate();
     }
-    meet(nt);
+    meet(te);
   } else {
-    meet(0);
+    meet(tb);
     rotate();
-    for (int i = 1; i <= nt; ++i) {
+    for (int i = tb + 1; i <= te; ++i) {
       meet(i);
-      consumer_plain(smem + st_con * STAGE_BYTES, pbuf + ((i - 1) & 1) * 4096);
+      consumer_plain(smem + st_con * STAGE_BYTES, pbuf + ((i - 1 - tb) & 1) * 4096);
       rotate();
+    }
+  }
+
+  // ---- the seam of a cut item (attention_bwd_kernel has the protocol): the part that finishes first leaves its accumulators
+  // in the cut's slot, the second adds them to its own and stores the item
+  if constexpr (STREAMK) {
+    if (tb > 0 || te < nt) {                        // workgroup-uniform
+      typedef __attribute__((address_space(1))) unsigned gu32;
+      const int slot = te < nt ? t0 + 1 : t0;
+      gu32* const ctl = (gu32*)(p.sk_ctl + 2 * (size_t)slot);
+      const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.sk_partials + (size_t)slot * PART_FLOATS), 0, PART_FLOATS * 4, 0x00020000);
+      __syncthreads();   // every wave is done with the ring and the hand-over buffer: the first word now carries the ticket
+      if (tid == 0) *(volatile unsigned*)smem = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const unsigned ticket = __builtin_amdgcn_readfirstlane(*(volatile unsigned*)smem);
+      if ((ticket & 1u) == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const f32x16_t& a = acc[r >> 2];
+          const int q4 = r & 3;
+          const u32x4_t v = {__float_as_uint(a[4 * q4]), __float_as_uint(a[4 * q4 + 1]), __float_as_uint(a[4 * q4 + 2]),
+                             __float_as_uint(a[4 * q4 + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs_p, tid * 16, r * (512 * 16), /*sc1: write through*/ 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(ctl + 1, ticket + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        continue;
+      }
+      if (tid == 0) {
+        int spins = 0;    // bounded: a corrupted workspace ends in NaN rows, not in a hung device
+        while (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket && spins < (1 << 22)) {
+          __builtin_amdgcn_s_sleep(8);
+          ++spins;
+        }
+        *(volatile unsigned*)smem = spins >= (1 << 22);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+      const bool gave_up = *(volatile unsigned*)smem != 0;
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += 4) {
+        u32x4_t v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, tid * 16, (r0 + e) * (512 * 16), /*sc1*/ 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f32x16_t& a = acc[(r0 + e) >> 2];
+          const int q4 = (r0 + e) & 3;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[4 * q4 + j] += __uint_as_float(v[e][j]);   // fp32 addition commutes: symmetric
+        }
+      }
+      if (gave_up)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = __builtin_nanf("");
     }
   }
 
@@ -697,6 +793,9 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
         *(u32x2_t*)(op + 32 * df + 8 * g) = pk;
       }
   }
+  if constexpr (!STREAMK) break;
+  else __syncthreads();   // every wave is done with the ring, the hand-over buffer and the ticket word
+  }   // passes
 }
 
 template <int MODE, bool STREAMK = false>
@@ -723,12 +822,13 @@ int bwd_cu_count() {
 constexpr int BWD_MIN_PART = 8;
 constexpr int BWD_CTL_BYTES = 16384;   // = ATTN_CTL_BYTES of attention_fwd.hip
 
-int launch_dkv(const BwdParams& p, hipStream_t stream) {
+template <bool STREAMK>
+int launch_dkv(const BwdParams& p, hipStream_t stream, int grid = 0) {
   constexpr int SMEM = STAGES * STAGE_BYTES + PBUF_BYTES;
-  auto kern = attention_bwd_dkv_kernel;
+  auto kern = attention_bwd_dkv_kernel<STREAMK>;
   FK_ENSURE_MAX_LDS(kern, SMEM, "fk_attention_bwd_bf16");
   const int nrb = (p.S + 127) / 128;
-  hipLaunchKernelGGL(kern, dim3(nrb * p.H * p.B), dim3(512), SMEM, stream, p);
+  hipLaunchKernelGGL(kern, dim3(STREAMK ? grid : nrb * p.H * p.B), dim3(512), SMEM, stream, p);
   FK_CHECK_LAUNCH("fk_attention_bwd_bf16");
   return FK_OK;
 }
@@ -764,32 +864,35 @@ static int attention_bwd_entry(const fk_attn_view* q, const fk_attn_view* k, con
     p.out = (bf16_t*)o.p; p.o_ld = o.ld; p.o_hs = o.head_stride; p.o_bs = o.batch_stride;
   };
   set_out(*dq);
-  // dQ pass: stream-K grid where one workgroup per 256-row item would waste >= 4 % of its rounds of CUs (attention_fwd.hip)
-  int rc;
-  {
-    const int64_t n_items = (int64_t)((S + 255) / 256) * H * B, nt = (S + CBLK - 1) / CBLK;
-    const int mode = grid == 0 ? 1 : (grid < 0 ? 0 : grid);
-    const int G = mode >= 2 ? (mode < bwd_cu_count() ? mode : bwd_cu_count()) : bwd_cu_count();
+  // Stream-K grid where one workgroup per item would waste >= 4 % of its rounds of CUs (attention_fwd.hip); items of `rows` rows
+  const int mode = grid == 0 ? 1 : (grid < 0 ? 0 : grid);
+  const int G = mode >= 2 ? (mode < bwd_cu_count() ? mode : bwd_cu_count()) : bwd_cu_count();
+  const int64_t nt = (S + CBLK - 1) / CBLK;
+  auto stream_k = [&](int rows) {      // fills p.n_items / sk_rounds / ... and says whether the persistent grid is to be used
+    const int64_t n_items = (int64_t)((S + rows - 1) / rows) * H * B;
     const int64_t rounds = (n_items + G - 1) / G;
     const bool wasteful = mode >= 2 || (n_items > G && (rounds * G - n_items) * 25 >= rounds * G);
     int sk_rounds = (int)(n_items / G) - 1;
     while (sk_rounds >= 0 && (n_items - (int64_t)sk_rounds * G) * nt < (int64_t)G * (nt + 2 * BWD_MIN_PART)) --sk_rounds;
     const int64_t need = BWD_CTL_BYTES + (int64_t)G * PART_FLOATS * 4;
-    if (mode && wasteful && sk_rounds >= 0 && ws && ws_bytes >= need && G <= BWD_CTL_BYTES / 8 && n_items * nt < (1ll << 31)) {
-      FK_CHECK_ARG((uintptr_t)ws % 16 == 0, "fk_attention_bwd_ws_bf16: workspace must be 16-byte aligned");
-      p.n_items = (int)n_items; p.sk_rounds = sk_rounds; p.min_part = BWD_MIN_PART;
-      p.sk_ctl = (unsigned*)ws;                                   // the forward's layout: control words first (16 KiB)
-      p.sk_partials = (float*)((char*)ws + BWD_CTL_BYTES);
-      rc = launch_bwd<MODE_DQ, true>(p, stream, G);
-    } else {
-      rc = launch_bwd<MODE_DQ>(p, stream);
-    }
-  }
+    if (!(mode && wasteful && sk_rounds >= 0 && ws && ws_bytes >= need && G <= BWD_CTL_BYTES / 8 && n_items * nt < (1ll << 31)))
+      return false;
+    p.n_items = (int)n_items; p.sk_rounds = sk_rounds; p.min_part = BWD_MIN_PART;
+    p.sk_ctl = (unsigned*)ws;                                   // the forward's layout: control words first (16 KiB)
+    p.sk_partials = (float*)((char*)ws + BWD_CTL_BYTES);
+    return true;
+  };
+  FK_CHECK_ARG(!ws || (uintptr_t)ws % 16 == 0, "fk_attention_bwd_ws_bf16: workspace must be 16-byte aligned");
+  int rc = stream_k(256) ? launch_bwd<MODE_DQ, true>(p, stream, G) : launch_bwd<MODE_DQ>(p, stream);
   if (rc != FK_OK) return rc;
   if (passes != 3) {
     set_out(*dk);
     p.out2 = (bf16_t*)dv->p; p.o2_ld = dv->ld; p.o2_hs = dv->head_stride; p.o2_bs = dv->batch_stride;
-    return launch_dkv(p, stream);
+    // The paired pass keeps the plain grid by default: on the persistent grid (same workspace -- the two launches are ordered
+    // on the stream, tickets are monotonic per cut) the seams' 128 KiB partials cost what the 9 % of idle CU time would return
+    // (S = 8704: 2.91 against 2.89-2.91 ms per call; S = 2560, 1.9 rounds: 0.276 against 0.264;
+    // profiles/r05_attention_bwd_dkv_streamk_ab.txt).  A forced grid (>= 2 workgroups, the test hook) takes it.
+    return mode >= 2 && stream_k(128) ? launch_dkv<true>(p, stream, G) : launch_dkv<false>(p, stream);
   }
   set_out(*dv);
   rc = launch_bwd<MODE_DV>(p, stream);

@@ -8,10 +8,15 @@ namespace {
 // Build-time switches of the experiments behind DESIGN.md section 4.0's attention table (defaults = what measured best):
 #ifndef FK_A4_DMA
 #define FK_A4_DMA 2      // a tile's 8 LDS-DMA requests: 0 in front of the first K-fragment reads, 1 behind them (under their
-#endif                   // latency), 2 one per MFMA slot of the tile's first group
+#endif                   // latency), 2 one per MFMA slot of the tile's first group, 3 four in each block's third group, 4 two in the first and third group of each block
 #ifndef FK_A4_EARLY
 #define FK_A4_EARLY 1    // 1: V^T fragments read one group earlier (behind the MFMA that frees the register), K likewise
 #endif
+#ifndef FK_A4_EWAIT
+#define FK_A4_EWAIT 2    // idle states in front of a block's first softmax step (s_nop operand; the hazard needs 12 states in all)
+#endif
+#define FK_STR2(x) #x
+#define FK_STR(x) FK_STR2(x)
 constexpr int A4_STAGES = 3, A4_DMA = FK_A4_DMA;
 constexpr bool A4_EARLY = FK_A4_EARLY != 0;
 
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams
   auto fill = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < PF; ++s)
-      if (A4_DMA == 2 || kt0 + s < kt1) issue_tile(min(kt0 + s, kt1 - 1), s);
+      if (A4_DMA >= 2 || kt0 + s < kt1) issue_tile(min(kt0 + s, kt1 - 1), s);
     st_cur = 0;
     st_pf = PF;
   };
@@ -200,8 +205,8 @@ __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams
   auto s_ready = [&](f32x16_t& acc) __attribute__((always_inline)) {   // the full distance (mask / first-block maximum)
     asm volatile("s_nop 7\n\ts_nop 4" : "+v"(acc));
   };
-  auto e_wait = [&](f32x16_t& acc) __attribute__((always_inline)) {    // 6 + the >= 6 instructions hipcc leaves in between
-    asm volatile("s_nop 5" : "+v"(acc));
+  auto e_wait = [&](f32x16_t& acc) __attribute__((always_inline)) {    // FK_A4_EWAIT + 1 states + the >= 10 instructions in between
+    asm volatile("s_nop " FK_STR(FK_A4_EWAIT) : "+v"(acc));
   };
   // Step t (0..15) of a block's softmax: scale + exponential of element t, row sum of element t - 1, pack of the pair that
   // element t - 1 completed; step 16 is what is left after the last exponential.  The row sums are formed exactly as the 8-wave
@@ -239,6 +244,7 @@ __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams
         s_mfma(sA, kf[i], qfA[i], i == 0);
         e_step(sB, 7 + i, kb ^ 1, nmB, tB, lB, pB);
         if (A4_DMA == 2 && kb == 0) issue_piece(kt_req, i);
+        if (A4_DMA == 4 && (i & 3) == 2) issue_piece(kt_req, 4 * kb + (i >> 2));        // form 4: two requests in groups 1 and 3 of each block
         FK_SLOT_FENCE();
       }
     }
@@ -270,6 +276,8 @@ __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams
         s_mfma(sB, kf[i], qfB[i], i == 0);
         if constexpr (!A4_EARLY) vfr[i] = v_frag(sb, 2 * kb + (i >> 2), i & 3);
         else if (kb == 0) kf[i] = k_frag(sb, 1, i);
+        if (A4_DMA == 3 && (i & 1)) issue_piece(kt_req, (i >> 1) + 4 * kb);      // form 3: four requests in each block's group 3
+        if (A4_DMA == 4 && (i & 3) == 2) issue_piece(kt_req, 4 * kb + 2 + (i >> 2));
         e_step(sA, 7 + i, kb, nmA, tA, lA, pA);
         FK_SLOT_FENCE();
       }
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams
   // (form 2).  Moving the barrier to the middle of the tile, so that these fragments too arrive under the previous group, was
   // tried: the extra addressing (two stage bases per tile) costs more issue slots than the round trip (0.90-0.95 x, call I).
   auto do_tile = [&](int kt, auto mask_tag, auto first_tag) __attribute__((always_inline)) {
-    if (A4_DMA == 2 || kt + PF - 1 < kt1) wait_vmcnt<(PF - 1) * LOADS>();
+    if (A4_DMA >= 2 || kt + PF - 1 < kt1) wait_vmcnt<(PF - 1) * LOADS>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     const char* sb = smem + st_cur * STAGE_BYTES;
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams
     if (A4_DMA == 1 && kt + PF < kt1) issue_tile(kt + PF, st_pf);
     groups123(sb, kt, 0, min(kt + PF, kt1 - 1), mask_tag, first_tag);
     group4(sb, 1, 0, std::true_type{});
-    groups123(sb, kt, 1, 0, mask_tag, std::false_type{});
+    groups123(sb, kt, 1, min(kt + PF, kt1 - 1), mask_tag, std::false_type{});
     group4(sb, 0, 1, std::false_type{});
     release_tile();
   };
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(256, 1) void attention_fwd4_kernel(const AttnParams
       else do_tile(last, FF{}, FF{});
     }
     drain();
-    if (A4_DMA == 2) wait_vmcnt<0>();     // the two repeat requests behind the last tile: nothing may land after the pass
+    if (A4_DMA >= 2) wait_vmcnt<0>();     // the two repeat requests behind the last tile: nothing may land after the pass
   };
   // plain S^T block (the restart's K-only pre-pass): query block X of the wave against key block kb
   auto scores_plain = [&](const char* sb, int kb, const bf16x8_t (&qf)[8]) __attribute__((always_inline)) {
