@@ -35,9 +35,12 @@ from . import ops
 BF16 = torch.bfloat16
 # K-major GEMM operands (fk_gemm_args.layout 1 / 2): gradients read weights and activations as they lie in memory instead of
 # physically transposed copies (same results bit for bit).  FK_BWD_K_MAJOR: 0 = copies everywhere, 1 = weight gradients read
-# dY and X token-major (layout 2), 2 = data gradients read the stored weight as well (layout 1: no W^T copies, 24 GB less
-# at the cost of a slower operand path -- DESIGN.md section 4a).
-K_MAJOR = int(os.environ.get("FK_BWD_K_MAJOR", "1"))
+# dY and X token-major (layout 2), 2 (default since round 5) = data gradients read the stored weight as well (layout 1: no W^T
+# copies, 17 GB less).  Until round 5 the K-major kernels carried a compiler-inserted wait for ALL LDS-DMA requests in front
+# of every group's first transpose read and ran 12-40 % below the row-major form; with the requests hidden from hipcc
+# (fk_common.h, buffer_lds_opaque) they match it, and level 2 is the fastest step: 492 (level 1, before) -> 481 (level 1) ->
+# 470 ms (level 2) on one box (profiles/r05_train_step_kmajor.txt, profiles/r05_gemm_kmajor_opaque_dma_ab.txt).
+K_MAJOR = int(os.environ.get("FK_BWD_K_MAJOR", "2"))
 
 
 def _pad64(n):

@@ -81,6 +81,14 @@ FK_DEV void buffer_lds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, int voffset
 #endif
 }
 
+// K-major operand paths only: the request as an opaque statement (fk_common.h).  Their transpose reads are builtins on LDS
+// pointers hipcc has no alias information for, so behind the builtin request it waited for ALL outstanding requests in front of
+// every group's first transpose read (s_waitcnt vmcnt(0) beside the kernel's own counted wait, three times per K-tile pair);
+// the row-major default forms never had that wait and keep the builtin.
+FK_DEV void buffer_lds16(const BufDesc& d, char* lds_dst, int voffset, int soffset) {
+  buffer_lds_opaque<16>(d, lds_addr_of(lds_dst), voffset, soffset);
+}
+
 template <int N>
 FK_DEV void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -471,6 +479,8 @@ FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, 
       (void*)((const bf16_t*)p.A + (AT ? (int64_t)m0 : fk_row_offset(p.a, m0))), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((const bf16_t*)p.W + (WT ? (int64_t)n0 : (int64_t)n0 * p.ldw)), 0, 0x7fffffff, 0x00020000);
+  const BufDesc od_a = make_buf_desc((const bf16_t*)p.A + (AT ? (int64_t)m0 : fk_row_offset(p.a, m0)), 0x7fffffffu);   // K-major forms
+  const BufDesc od_w = make_buf_desc((const bf16_t*)p.W + (WT ? (int64_t)n0 : (int64_t)n0 * p.ldw), 0x7fffffffu);
   int a_voff[2][2], w_voff[2][2];   // [half][piece]
   {
     const TileRows arow(p.a, m0);
@@ -495,12 +505,22 @@ FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, 
     char* dst = smem + buf * C::BUF_BYTES + which * C::HALF_BYTES + wave * 2048;
     if (which < 2) {
       const int koff = (AT ? 0 : kbase) + ktc * kstep_a;
-      buffer_lds16(rs_a, dst, a_voff[which][0], koff);
-      buffer_lds16(rs_a, dst + 1024, a_voff[which][1], koff);
+      if constexpr (AT || WT) {
+        buffer_lds16(od_a, dst, a_voff[which][0], koff);
+        buffer_lds16(od_a, dst + 1024, a_voff[which][1], koff);
+      } else {
+        buffer_lds16(rs_a, dst, a_voff[which][0], koff);
+        buffer_lds16(rs_a, dst + 1024, a_voff[which][1], koff);
+      }
     } else {
       const int koff = (WT ? 0 : kbase) + ktc * kstep_w;
-      buffer_lds16(rs_w, dst, w_voff[which - 2][0], koff);
-      buffer_lds16(rs_w, dst + 1024, w_voff[which - 2][1], koff);
+      if constexpr (AT || WT) {
+        buffer_lds16(od_w, dst, w_voff[which - 2][0], koff);
+        buffer_lds16(od_w, dst + 1024, w_voff[which - 2][1], koff);
+      } else {
+        buffer_lds16(rs_w, dst, w_voff[which - 2][0], koff);
+        buffer_lds16(rs_w, dst + 1024, w_voff[which - 2][1], koff);
+      }
     }
   };
 

@@ -10,5 +10,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 torch.cuda.set_device(0)
-r = bench.train_step_bench(torch.device("cuda", 0), steps=int(os.environ.get("TRAIN_STEPS", "3")), warmup=int(os.environ.get("TRAIN_WARMUP", "2")))
+r = bench.train_step_bench(torch.device("cuda", 0), steps=int(os.environ.get("TRAIN_STEPS", "3")), warmup=int(os.environ.get("TRAIN_WARMUP", "2")),
+                           e2e=os.environ.get("TRAIN_E2E", "1") != "0")
 print(json.dumps(r))
