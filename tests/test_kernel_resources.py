@@ -79,6 +79,24 @@ def test_hot_kernels_keep_their_accumulators_in_registers(src, tmp_path):
             n_mfma = sum("v_mfma" in x for x in k_loop)
             assert n_mfma == (128 if "16x16x32" in "".join(k_loop) else 64)      # 32 x 32 x 16: 64 per two K-tiles; 16 x 16 x 32: 128
             assert not any("scratch_" in x for x in k_loop), f"{lines[a][:70]}: scratch traffic inside the K loop"
+        # No instantiation's K loop may wait for ALL vector-memory requests: the loop's LDS-DMA prefetch is in flight there and
+        # the kernels order their ring with counted waits.  hipcc inserts exactly that wait in front of an LDS read it cannot
+        # prove disjoint from a builtin LDS-DMA request (the K-major forms' transpose reads, until round 5: 12-40 % of the kernel).
+        starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN12_GLOBAL__N_1\d+gemm(8|9|_mix|8_streamk)_kernel\w+:", l)]
+        assert len(starts) >= 10
+        for a in starts:
+            e = next(i for i in range(a, len(lines)) if lines[i].startswith(".Lfunc_end"))
+            body = lines[a:e]
+            labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+            loops = []
+            for i, l in enumerate(body):
+                m = re.search(r"(?:s_cbranch_\w+|s_branch) (\.LBB\d+_\d+)", l)
+                if m and m.group(1) in labels and labels[m.group(1)] < i and sum("v_mfma" in x for x in body[labels[m.group(1)]:i]) >= 32:
+                    loops.append((labels[m.group(1)], i))
+            if not loops:
+                continue
+            lo, hi = min(loops, key=lambda ab: ab[1] - ab[0])
+            assert not any("vmcnt(0)" in x for x in body[lo:hi]), f"{lines[a][:80]}: s_waitcnt vmcnt(0) inside the K loop"
 
 
 def test_attention_fwd4_hand_placed_hazards_and_steady_loop(tmp_path):
