@@ -580,7 +580,11 @@ def main():
                    "S_cond": inp["S_cond"], "seq_len": S, "num_inference_steps": 28, "guidance_scale": 3.5,
                    "blocks": "19 double + 38 single", "parallelism": f"dp{world}"},
         "ms_per_step_hip_events": timed_edits.hip_event_ms,
-        "host": {"enqueue_ms_per_step": timed_edits.host_enqueue_s * 1e3, "denoise_loop_as_hipgraph": bool(pipe.use_graph)},
+        "host": {"enqueue_ms_per_step": timed_edits.host_enqueue_s * 1e3, "denoise_loop_as_hipgraph": bool(pipe.use_graph),
+                 # which of the bit-identical kernel forms this run used (defaults unless the environment says otherwise)
+                 "attention_forward": os.environ.get("FK_ATTN_KERNEL", "4") + " waves",
+                 "gemm_mfma": "16x16x32" if getattr(__import__("gpt_image_edit_amd.ops", fromlist=["LAUNCH"]).LAUNCH, "gemm_mfma", 0) in (0, 16) else "32x32x16",
+                 "train_bwd_k_major": int(os.environ.get("FK_BWD_K_MAJOR", "2"))},
         "dist": {"world_size": dist.get_world_size() if world > 1 else 1,
                  "backend": (dist.get_backend() + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else "none (single process)",
                  "collective": "one all_gather_into_tensor of the packed final latents per step" if world > 1 else None},
