@@ -1,6 +1,11 @@
 """Contract benchmark: edited images / second of the FLUX-Kontext hot path on N MI355X (one process per GPU).
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a launcher (WORLD_SIZE unset) re-executes itself as `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...` (`self_launch_argv`), i.e. the reference's
+own launch form (`univa/eval/gedit/step1_gen_samples.py:82-92`: torchrun + `init_process_group`); under a launcher
+(WORLD_SIZE set) it runs as one rank.
 
 A "step" is ONE full edit of the hot path over one batch of synthetic inputs already resident in HBM:
 condition-image VAE encode -> 28 x (MMDiT forward + fused Euler update) -> VAE decode
@@ -16,16 +21,20 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     : the dominant kernel family (bf16 MFMA GEMM, all epilogues): algorithmic FLOPs of its
                  launches in one edit / their summed duration, measured live with HIP events on the
                  launch stream in an instrumented edit after the timed region; `traffic` = HBM bytes per
-                 launch of the family's dominant kernel from the committed PMC passes (profiles/r02_traffic.json);
+                 launch of the family's dominant kernel from the committed PMC passes (`TRAFFIC_FILE`: the newest
+                 profiles/rNN_traffic.json);  `roofline.workloads` = the headline numbers of EVERY workload of the run;
   cpu_baseline : the CPU oracle (fp32 torch restatement, `oracle/`) timed on this box's host cores
-                 (N = 1, rank 0 only): ONE full-depth denoise step at the workload's size + VAE encode + decode,
-                 i.e. BASELINE.json configs[0] with 1 of its 4 steps executed; the 4- and 28-step figures are
-                 stated as extrapolations of that;
+                 (N = 1, rank 0 only): BASELINE.json configs[0] as defined -- all FOUR denoise steps at full depth
+                 + VAE encode + decode executed (`--cpu-baseline cfg1`, the default; ~4.5 min of host time);
+                 the 28-step figure is stated as an extrapolation of the executed steps;
   extra        : the 1024 x 1024 half of BASELINE.json's metric (`single_1024x1024_28step`, same run, after the
-                 timed region: 1 warm-up + 3 timed edits per GPU, its own roofline) and the prompt-encode time
-                 T_prompt / T_e2e of SURVEY.md section 8(d);
+                 timed region: 1 warm-up + 3 timed edits per GPU, its own roofline), the CLI's ~1 MP condition
+                 shape (`cfg2cli_512x512_cond1mp_28step`, S = 5632; N = 1), cfg 3 (B = 32 at 1024^2: 1 warm-up batch
+                 + 3 timed batches, HIP-event median; N = 1), for N > 1 a cfg 4 slice (4 edits per GPU at 1024^2) and
+                 the prompt-encode time T_prompt / T_e2e of SURVEY.md section 8(d);
   extra.cfg5_* : one stage-2 optimisation step of the denoiser (BASELINE.json configs[4]) on this GPU, samples/s;
-  dist         : world size and backend as torch.distributed reports them.
+  dist         : world size and backend as torch.distributed reports them + `rccl_ranks_seen`, the rank ids an
+                 actual `all_gather_into_tensor` returned.
 
 Other workloads (`--workload`): cfg 3 (`cfg3_batch32_1024x1024_28step`), cfg 4 (`cfg4_batch256_dp8`: 32 edits per
 GPU, weak; `--scaling strong` keeps `--global-batch` fixed and shards it `items[rank::world]` like the reference's
@@ -57,7 +66,9 @@ WORKLOADS = {
 }
 EXTRA_WORKLOAD = "single_1024x1024_28step"
 CFG3_WORKLOAD = "cfg3_batch32_1024x1024_28step"
-TRAFFIC_FILE = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"))
+CLI_WORKLOAD = "cfg2cli_512x512_cond1mp_28step"
+CFG4_SLICE_WORKLOAD = "cfg4_slice4_1024x1024_28step"
+TRAFFIC_FILE = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"))
                      if os.path.exists(f)), os.path.join(ROOT, "profiles", "r04_traffic.json"))
 
 
@@ -517,6 +528,29 @@ def workload_summary(value, ms_per_step, rl=None, **more):
     return d
 
 
+def self_launch_argv(n_gpus, argv, port, script=None):
+    """The command `python bench.py --gpus N ...` turns into when no launcher started it: one process per GPU under
+    torch.distributed.run on this node (127.0.0.1 rendezvous: the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def ranks_seen(world, device, backend):
+    """Rank ids as ONE all_gather_into_tensor returns them (nccl = RCCL: on the GPUs; gloo smoke: host tensors)."""
+    dev = device if backend == "nccl" else "cpu"
+    mine = torch.tensor([dist.get_rank()], device=dev, dtype=torch.int32)
+    out = torch.full((world,), -1, device=dev, dtype=torch.int32)
+    dist.all_gather_into_tensor(out, mine)
+    return [int(v) for v in out.cpu()]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -536,11 +570,18 @@ def main():
     if args.no_cpu_baseline:
         args.cpu_baseline = "none"
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started the way the 1-GPU bench is: become the launcher (step1_gen_samples.py:82-92 is torchrun + init_process_group)
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+        raise SystemExit(subprocess.call(self_launch_argv(args.gpus, sys.argv[1:], _free_port()), env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     # one process per GPU; FK_BENCH_BACKEND=gloo (+ ranks sharing a GPU) exists only to smoke-test the N > 1
     # code path on a 1-GPU box
     backend = os.environ.get("FK_BENCH_BACKEND", "nccl")
@@ -586,6 +627,7 @@ def main():
                  "gemm_mfma": "16x16x32" if getattr(__import__("gpt_image_edit_amd.ops", fromlist=["LAUNCH"]).LAUNCH, "gemm_mfma", 0) in (0, 16) else "32x32x16",
                  "train_bwd_k_major": int(os.environ.get("FK_BWD_K_MAJOR", "2"))},
         "dist": {"world_size": dist.get_world_size() if world > 1 else 1,
+                 "rccl_ranks_seen": ranks_seen(world, device, backend) if world > 1 else [0],
                  "backend": (dist.get_backend() + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else "none (single process)",
                  "collective": "one all_gather_into_tensor of the packed final latents per step" if world > 1 else None},
     }
@@ -596,42 +638,54 @@ def main():
         result["roofline"]["instrumented_denoise_steps"] = i_steps
         summaries[args.workload] = workload_summary(result["value"], result["ms_per_step"], result["roofline"], unit="images/s")
 
-    # ---- the 1024^2 half of BASELINE.json's metric, in the same run (every rank: weak scaling at 1024^2) ------------
+    # ---- the other workloads of BASELINE.json in the same run ----------------------------------------------------------
     extra = {}
-    if not args.no_extra and args.workload != EXTRA_WORKLOAD and WORKLOADS[args.workload][0] == 1:
-        inp2 = make_inputs(EXTRA_WORKLOAD, device, seed=142 + rank)
-        k2 = 3
-        el2 = timed_edits(pipe, inp2, k2, 1, world, device, backend)
-        ex = {"value": world * k2 / el2, "unit": "images/s", "n_gpus": world, "steps": k2, "warmup": 1,
-              "ms_per_step": el2 / k2 * 1e3, "scaling": "weak",
-              "config": {"workload": EXTRA_WORKLOAD, "batch_per_gpu": 1, "height": 1024, "width": 1024,
-                         "seq_len": inp2["S_txt"] + inp2["S_tgt"] + inp2["S_cond"], "num_inference_steps": 28}}
-        ex["ms_per_step_hip_events"] = timed_edits.hip_event_ms
+
+    def extra_workload(name, k, warm, seed, i_steps=28, all_ranks=True):
+        """`k` timed steps (after `warm`) of workload `name` on every rank (weak scaling) or on this process only; own
+        roofline from an instrumented pass of `i_steps` denoise steps; headline numbers into `roofline.workloads`."""
+        w = world if all_ranks else 1
+        inp_x = make_inputs(name, device, seed=seed + rank)
+        torch.cuda.reset_peak_memory_stats(device)
+        el = timed_edits(pipe, inp_x, k, warm, w, device, backend)
+        Bx = inp_x["B"]
+        ex = {"value": w * Bx * k / el, "unit": "images/s", "n_gpus": w, "steps": k, "warmup": warm,
+              "ms_per_step": el / k * 1e3, "scaling": "weak", "ms_per_step_hip_events": timed_edits.hip_event_ms,
+              "config": {"workload": name, "batch_per_gpu": Bx, "global_batch": w * Bx, "height": inp_x["H"], "width": inp_x["W"],
+                         "seq_len": inp_x["S_txt"] + inp_x["S_tgt"] + inp_x["S_cond"], "num_inference_steps": 28},
+              "peak_memory_gb": torch.cuda.max_memory_allocated(device) / 1e9}
         if rank == 0 and not args.no_roofline:
-            ex["roofline"] = roofline_of(instrumented_edit(pipe, inp2), EXTRA_WORKLOAD)
-            summaries[EXTRA_WORKLOAD] = workload_summary(ex["value"], ex["ms_per_step"], ex["roofline"], unit="images/s")
-            ex["roofline"] = _slim_roofline(ex["roofline"])
-        extra[EXTRA_WORKLOAD] = ex
-        del inp2
-    if rank == 0 and world == 1 and not args.no_extra and WORKLOADS[args.workload][0] == 1 and os.environ.get("FK_BENCH_CFG3", "1") != "0":
-        # BASELINE.json configs[2] (B = 32 at 1024^2: one GPU's share of the reference's batch runs) in the same run: ONE timed
-        # batch, no warm-up batch of that shape (a batch takes ~2 min; its first-call allocations are < 1 % of it), then a
-        # 4-step instrumented pass of the same batch for its roofline (per-launch HIP events; M = 278 528 rows per GEMM)
+            rl = roofline_of(instrumented_edit(pipe, inp_x, i_steps), name)
+            more = {"instrumented_denoise_steps": i_steps} if i_steps != 28 else {}
+            summaries[name] = workload_summary(ex["value"], ex["ms_per_step"], rl, unit="images/s", steps=k, warmup=warm,
+                                               ms_median_hip_events=round(ex["ms_per_step_hip_events"]["median"], 2), **more)
+            ex["roofline"] = dict(_slim_roofline(rl), **more)
+        extra[name] = ex
+
+    single = WORKLOADS[args.workload][0] == 1 and not args.no_extra
+    if single and args.workload != EXTRA_WORKLOAD:
+        # the 1024^2 half of BASELINE.json's metric (every rank: weak scaling at 1024^2)
+        extra_workload(EXTRA_WORKLOAD, 3, 1, seed=142)
+    if single and world > 1 and os.environ.get("FK_BENCH_CFG4", "1") != "0":
+        # BASELINE.json configs[3] (batch 256 over 8 GPUs) as a 4-per-GPU slice: the N > 1 curve at 1024^2 with B > 1
         try:
-            inp3 = make_inputs(CFG3_WORKLOAD, device, seed=242)
-            el3 = timed_edits(pipe, inp3, 1, 0, 1, device, backend)
-            ex3 = {"value": 32 / el3, "unit": "images/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": el3 * 1e3,
-                   "config": {"workload": CFG3_WORKLOAD, "batch_per_gpu": 32, "height": 1024, "width": 1024,
-                              "seq_len": inp3["S_txt"] + inp3["S_tgt"] + inp3["S_cond"], "num_inference_steps": 28},
-                   "peak_memory_gb": torch.cuda.max_memory_allocated(device) / 1e9}
-            if not args.no_roofline:
-                ex3["roofline"] = roofline_of(instrumented_edit(pipe, inp3, 4), CFG3_WORKLOAD)
-                ex3["roofline"]["instrumented_denoise_steps"] = 4
-                summaries[CFG3_WORKLOAD] = workload_summary(ex3["value"], ex3["ms_per_step"], ex3["roofline"], unit="images/s",
-                                                            instrumented_denoise_steps=4)
-                ex3["roofline"] = _slim_roofline(ex3["roofline"])
-            extra[CFG3_WORKLOAD] = ex3
-            del inp3
+            extra_workload(CFG4_SLICE_WORKLOAD, 2, 1, seed=342)
+        except Exception as e:
+            extra[CFG4_SLICE_WORKLOAD] = {"error": f"{type(e).__name__}: {e}"}
+    if single and rank == 0 and world == 1 and args.workload != CLI_WORKLOAD:
+        # the shape the reference CLI really runs for a 512^2 request: condition image resized to ~1 MP (flux_pipeline.py:960-972)
+        try:
+            extra_workload(CLI_WORKLOAD, 3, 1, seed=442)
+        except Exception as e:
+            extra[CLI_WORKLOAD] = {"error": f"{type(e).__name__}: {e}"}
+    if single and rank == 0 and world == 1 and os.environ.get("FK_BENCH_CFG3", "1") != "0":
+        # BASELINE.json configs[2] (B = 32 at 1024^2: one GPU's share of the reference's batch runs) by SURVEY.md section
+        # 8(d)'s protocol: 1 warm-up batch + 3 timed batches (HIP-event median beside the wall-clock mean; a batch takes
+        # ~2 min), then a 4-step instrumented pass of the same batch for its roofline (M = 278 528 rows per GEMM).
+        # FK_BENCH_CFG3_STEPS=k,w shortens it for builder runs.
+        try:
+            k3, w3 = (int(v) for v in os.environ.get("FK_BENCH_CFG3_STEPS", "3,1").split(","))
+            extra_workload(CFG3_WORKLOAD, k3, w3, seed=242, i_steps=4)
         except Exception as e:
             extra[CFG3_WORKLOAD] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()

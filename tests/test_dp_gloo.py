@@ -59,3 +59,66 @@ def test_unshard_order_single_process():
         assert [gathered[order[i]] for i in range(n)] == list(range(n))
     x = torch.randn(2, 3, 4)
     assert dp.all_gather_latents(x) is x  # no process group: identity
+
+
+def test_bench_launches_itself_for_more_than_one_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a launcher becomes `python -m torch.distributed.run ... bench.py --gpus N ...`
+    (the reference's generators are torchrun programs: univa/eval/gedit/step1_gen_samples.py:82-92)."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    argv = bench.self_launch_argv(8, ["--gpus", "8", "--steps", "2", "--warmup", "1"], 29511)
+    assert argv[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in argv and "--nproc-per-node=8" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[argv.index("--master-port") + 1] == "29511"
+    i = argv.index(os.path.abspath(bench.__file__))
+    assert argv[i + 1:] == ["--gpus", "8", "--steps", "2", "--warmup", "1"]
+
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-extra"])
+    try:
+        bench.main()
+        raise AssertionError("main() must hand over to the launcher")
+    except SystemExit as e:
+        assert e.code == 7                                    # the launcher's return code is the bench's
+    assert "--nproc-per-node=2" in seen["cmd"] and seen["cmd"][-7:] == ["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-extra"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under a launcher a mismatching --gpus is refused, not re-launched
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    try:
+        bench.main()
+        raise AssertionError("WORLD_SIZE=4 with --gpus 2 must be refused")
+    except SystemExit as e:
+        assert "WORLD_SIZE=4" in str(e.code)
+
+
+def _ranks_worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    dist.init_process_group("gloo")
+    out_q.put((rank, bench.ranks_seen(world, torch.device("cpu"), "gloo")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_ranks_seen_comes_from_a_collective_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ranks_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, [0, 1]), (1, [0, 1])]
