@@ -77,7 +77,11 @@ FK_DEV BufDesc make_buf_desc(const void* base, unsigned bytes) {
 template <int BYTES>
 FK_DEV void buffer_lds_opaque(const BufDesc& d, unsigned lds_addr, int voffset, int soffset) {
   static_assert(BYTES == 16 || BYTES == 4, "LDS-DMA piece: 16 or 4 bytes per lane");
-  // M0: hipcc sets it next to each of its own uses; the s_nop is the SALU-write-M0 -> LDS-DMA wait state it also emits
+  // M0: hipcc sets it next to each of its own uses; the s_nop is the SALU-write-M0 -> LDS-DMA wait state it also emits.
+  // M0 is NOT in the clobber list: clang treats it as a reserved register ("may not be preserved ... undefined behaviour"
+  // warning on every instantiation).  The rule instead: a kernel issues ALL of its LDS-DMA requests through this form or ALL
+  // through the builtin (the GEMM / attention files pick the form per kernel instantiation with `if constexpr`), and uses no
+  // other M0 consumer (s_sendmsg, GWS, ds_*_gs) -- then no compiler-managed M0 value is ever live across the statement.
   if constexpr (BYTES == 16)
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(lds_addr), "v"(voffset), "s"(d.w), "s"(soffset) : "memory");

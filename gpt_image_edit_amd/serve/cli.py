@@ -210,7 +210,8 @@ def smart_resize(height, width, factor=28, min_pixels=4 * 28 * 28, max_pixels=16
 def vision_inputs(conversation):
     """``process_vision_info(conversation)[0]`` of the reference's cli (:189): every image entry of the conversation, in
     order, opened as RGB and resized (PIL's default filter, bicubic) to ``smart_resize`` of its own size under the
-    entry's ``min_pixels`` / ``max_pixels`` -- so that a 448 x 448-pixel budget yields the 16 x 16 merged-patch grid
+    entry's ``min_pixels`` / ``max_pixels`` (or of the entry's ``resized_height`` x ``resized_width`` when it names them:
+    ``univa/eval/gedit/step1_gen_samples.py:119-124``) -- so that a 448 x 448-pixel budget yields the 16 x 16 merged-patch grid
     (256 image tokens for a square image) whatever the processor's own defaults are.  None when there is no image."""
     from PIL import Image
     out = []
@@ -221,6 +222,8 @@ def vision_inputs(conversation):
             img = c["image"] if isinstance(c["image"], Image.Image) else Image.open(c["image"])
             img = img.convert("RGB")
             w, h = img.size
+            if "resized_height" in c and "resized_width" in c:      # a forced size wins over the pixel budget (gedit generator)
+                h, w = c["resized_height"], c["resized_width"]
             rh, rw = smart_resize(h, w, 28, c.get("min_pixels", 4 * 28 * 28), c.get("max_pixels", 16384 * 28 * 28))
             out.append(img.resize((rw, rh)))
     return out or None

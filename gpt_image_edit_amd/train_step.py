@@ -201,8 +201,9 @@ class DenoiserTrainStep:
 
     def discard(self):
         """Drop the gradients of the backward passes since the last optimiser step (a step that is deliberately skipped, e.g.
-        a non-finite loss; the reference's ``optimizer.zero_grad()``, train_denoiser.py:1180).  With ``sharded=True`` every
-        rank must call it (it finishes the reductions in flight).  Without it a skipped backward pass would be summed into the
+        a non-finite loss; the reference's ``optimizer.zero_grad()``, train_denoiser.py:1180).  With ``sharded=True`` it finishes
+        the reduce-scatters already in flight and starts none; the decision to skip must be the same on every rank (take it
+        on an all-reduced loss or flag).  Without it a skipped backward pass would be summed into the
         next step as a further micro-batch."""
         if self.opt is not None:
             self.opt.zero_grad()

@@ -311,8 +311,13 @@ class ShardedAdamW:
     def zero_grad(self):
         """Discard every gradient taken in since the last ``step()`` (a backward pass whose step is deliberately skipped, e.g.
         a non-finite loss -- the reference's ``optimizer.zero_grad()``, train_denoiser.py:1180): reductions in flight are
-        finished first (every rank must call this, like ``step()``), then the chunks and the micro-batch count are reset."""
-        self._flush()
+        finished first, then the chunks and the micro-batch count are reset.  No NEW collective is started: buckets whose
+        reduce-scatter has not been launched are simply dropped, so the call costs no traffic and a rank may make it without
+        the others entering a collective for it.  What the ranks must still agree on is the DECISION to skip (every rank runs
+        the same backward passes, so the launched buckets match): take it on an all-reduced loss / flag, as DeepSpeed's
+        overflow check does -- a rank that alone skips ``step()`` leaves the others waiting in step()'s all-gather."""
+        for b in sorted(self._work):                      # launched by every rank during the same backward pass: completes
+            self._finish(b)
         self.grad_slice.zero_()
         self._begin()
 

@@ -99,3 +99,53 @@ def test_gen_samples_single_process_and_parser(tmp_path):
     res = gen_samples.run(args, _edit_fn(calls), rank=0, world=1)
     assert calls == [1, 2] and res["done"] == ["a", "b"] and sorted(os.listdir(tmp_path / "o")) == ["a.png", "b.png"]
     assert gen_samples.set_seed(42, 3) == 45
+
+
+def test_gedit_turn_and_sizes_follow_the_reference_generator(tmp_path):
+    """The conversation and the edit size of one GEdit item as ``univa/eval/gedit/step1_gen_samples.py:95-131`` builds them.
+    Expected sizes: the reference's own ``pick_ratio(oh, ow, 'any_17ratio')`` + ``compute_size(rw, rh, stride=16,
+    anchor_pixels=...)`` executed in the build container (``univa.utils.anyres_util`` imports there)."""
+    from PIL import Image
+
+    from gpt_image_edit_amd.eval import gen_samples
+    from gpt_image_edit_amd.serve import cli
+    expected = {  # (width, height) of the input -> (gen_h, gen_w) at 1024^2 and at 512^2 anchor pixels
+        (640, 480): ((880, 1184), (432, 592)), (480, 640): ((1184, 880), (592, 432)), (1024, 1024): ((1024, 1024), (512, 512)),
+        (1920, 1080): ((752, 1392), (368, 688)), (500, 1500): ((1552, 656), (768, 320)), (333, 777): ((1552, 656), (768, 320)),
+        (1000, 700): ((832, 1248), (416, 624)),
+    }
+    for (w, h), (big, small) in expected.items():
+        path = str(tmp_path / f"in_{w}x{h}.png")
+        Image.new("RGB", (w, h), (w % 256, h % 256, 7)).save(path)
+        assert gen_samples.gedit_size(path, 1024, 1024) == (448, 448) + big
+        assert gen_samples.gedit_size(path, 512, 512) == (448, 448) + small
+        # the cli's rule (dynamic_resize on stride 32, 11-ratio family) is a different function: not what this generator uses
+        convo, paths = gen_samples.build_turn("make it snow", path)
+        assert paths == [path] and len(convo) == 1 and convo[0]["role"] == "user"
+        kinds = [c["type"] for c in convo[0]["content"]]
+        assert kinds == ["image", "text"]                                   # image entries first, then the text
+        entry = convo[0]["content"][0]
+        assert (entry["resized_height"], entry["resized_width"]) == (448, 448) and "min_pixels" not in entry
+        (seen,) = cli.vision_inputs(convo)
+        assert seen.size == (448, 448)                                      # forced square whatever the input's aspect
+    convo, paths = gen_samples.build_turn("two", "a.png", "b.png")
+    assert [c["type"] for c in convo[0]["content"]] == ["image", "image", "text"] and paths == ["a.png", "b.png"]
+    convo, paths = gen_samples.build_turn("", "a.png")
+    assert [c["type"] for c in convo[0]["content"]] == ["image"]
+    args = gen_samples.build_parser().parse_args(["--model_path", "m", "--flux_path", "f", "--gedit_prompt_path", "p", "--output_dir", "o"])
+    assert args.joint_with_t5 and not args.only_use_t5 and args.num_images_per_prompt == 1
+
+
+def test_gather_latents_without_latents_is_refused_up_front(tmp_path):
+    from gpt_image_edit_amd.eval import gen_samples
+    import pytest
+    with open(tmp_path / "p.json", "w") as f:
+        json.dump({"k0": {"prompt": "x#0", "id": "a.png"}}, f)
+    args = SimpleNamespace(gedit_prompt_path=str(tmp_path / "p.json"), gedit_image_dir="", output_dir=str(tmp_path / "out"),
+                           gather_latents=True, latents_out=None)
+    with pytest.raises(RuntimeError, match="holds 0 latents"):
+        gen_samples.run(args, lambda prompt, path: (np.zeros((4, 4, 3), np.uint8), None), rank=0, world=1)
+    a = gen_samples.build_parser().parse_args(["--model_path", "m", "--flux_path", "f", "--gedit_prompt_path", "p", "--output_dir", "o",
+                                               "--gather_latents", "--t5_only"])
+    with pytest.raises(SystemExit, match="t5_only"):
+        gen_samples.main(a)

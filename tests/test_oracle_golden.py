@@ -246,3 +246,98 @@ def test_scheduler_shift_pinned_to_the_references_own_restatement(golden_dir):
         assert float(s.sigmas[-1]) == 0.0
     # mu at the two BASELINE resolutions, as the reference's calculate_shift gives them (helpers.npz pins the function)
     assert helpers.calculate_shift(4096) == pytest.approx(1.15) and helpers.calculate_shift(1024) == pytest.approx(0.63, abs=5e-3)
+
+
+# ---- the diffusers pin (oracle/make_golden_diffusers.py; the fixtures can only be made where diffusers is installed) ----------
+def _diffusers_fixture(golden_dir, name):
+    path = os.path.join(golden_dir, f"diffusers_{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"parity unpinned (fixture absent): tests/golden/diffusers_{name}.npz is written by "
+                    "`python oracle/make_golden_diffusers.py` where diffusers==0.32.2 is installed")
+    return np.load(path)
+
+
+def _oracle_mmdit_case(case, dt):
+    from oracle import make_golden_diffusers as mg
+    dtype = getattr(torch, dt)
+    cfg = case["cfg"]
+    sd = {k: v.to(dtype) for k, v in flux_spec.synthetic_state(flux_spec.flux_param_shapes(cfg), seed=case["weight_seed"]).items()}
+    inp = mg.mmdit_inputs(case, dtype)
+    return mmdit.flux_forward(sd, inp["hidden_states"], inp["encoder_hidden_states"], inp["pooled_projections"], inp["timestep"],
+                              inp["img_ids"], inp["txt_ids"], inp["guidance"], config=cfg, return_intermediates=True)
+
+
+@pytest.mark.parametrize("name", ["tiny", "width"])
+def test_diffusers_mmdit_cases_run_on_the_oracle(name):
+    """The cases of the pin script execute on the oracle (inputs regenerate from their seeds, every tapped tensor exists):
+    what a maintainer's fixture will be compared with.  Not a parity claim."""
+    from oracle import make_golden_diffusers as mg
+    case = mg.MMDIT_CASES[name]
+    y, inter = _oracle_mmdit_case(case, "float32")
+    s_img = 2 * case["grid"][0] * case["grid"][1]
+    assert y.shape == (case["batch"], s_img, case["cfg"].get("out_channels") or case["cfg"]["in_channels"]) and torch.isfinite(y).all()
+    for i in range(case["cfg"]["num_layers"]):
+        assert inter[f"double{i}.h"].shape[1] == s_img and inter[f"double{i}.c"].shape[1] == case["s_txt"]
+    for i in range(case["cfg"]["num_single_layers"]):
+        assert inter[f"single{i}.s"].shape[1] == s_img + case["s_txt"]
+
+
+def test_oracle_matches_diffusers_fixture_mmdit(golden_dir):
+    from oracle import make_golden_diffusers as mg
+    g = _diffusers_fixture(golden_dir, "mmdit")
+    for name, case in mg.MMDIT_CASES.items():
+        for dt in case["dtypes"]:
+            y, inter = _oracle_mmdit_case(case, dt)
+            # fp32: two fp32 executions of the same graph (different kernels: 1e-4 relative); bf16: same rounding points, the
+            # matmul accumulation order may differ by a bf16 ulp here and there
+            tol = dict(rtol=1e-4, atol=1e-5) if dt == "float32" else dict(rtol=2e-2, atol=2e-2)
+            torch.testing.assert_close(y.float(), torch.from_numpy(g[f"{name}.{dt}.out"]), **tol)
+            for key, val in inter.items():
+                fk = f"{name}.{dt}.{key}"
+                if fk in g.files:
+                    torch.testing.assert_close(val.float(), torch.from_numpy(g[fk]), **tol)
+            n_taps = sum(1 for f in g.files if f.startswith(f"{name}.{dt}.double") or f.startswith(f"{name}.{dt}.single"))
+            assert n_taps == 2 * case["cfg"]["num_layers"] + case["cfg"]["num_single_layers"]
+
+
+def test_oracle_matches_diffusers_fixture_vae(golden_dir):
+    from oracle import make_golden_diffusers as mg
+    g = _diffusers_fixture(golden_dir, "vae")
+    sd = flux_spec.synthetic_state(flux_spec.vae_param_shapes(mg.VAE_CASE["cfg"]), seed=mg.VAE_CASE["weight_seed"])
+    z, im = mg.vae_inputs()
+    torch.testing.assert_close(ovae.encode_moments(sd, im), torch.from_numpy(g["moments"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(ovae.encode_mode(sd, im), torch.from_numpy(g["mode"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(ovae.decode(sd, z), torch.from_numpy(g["decode"]), rtol=1e-4, atol=1e-5)
+
+
+def test_oracle_matches_diffusers_fixture_scheduler(golden_dir):
+    from oracle import make_golden_diffusers as mg
+    g = _diffusers_fixture(golden_dir, "sched")
+    for n, mu in mg.SCHED_CASES:
+        ts, sg = osched.shifted_sigmas(n, mu)
+        assert np.array_equal(ts.numpy(), g[f"timesteps.{n}.{mu}"]) and np.array_equal(sg.numpy(), g[f"sigmas.{n}.{mu}"])
+        s = FlowMatchEulerDiscreteScheduler()                       # the product's host scheduler, same arguments
+        s.set_timesteps(sigmas=np.linspace(1.0, 1 / n, n), mu=mu, device="cpu")
+        assert np.array_equal(s.timesteps.numpy(), g[f"timesteps.{n}.{mu}"]) and np.array_equal(s.sigmas.numpy(), g[f"sigmas.{n}.{mu}"])
+    n, mu = mg.SCHED_CASES[0]
+    _, sg = osched.shifted_sigmas(n, mu)
+    for dt in ("float32", "bfloat16"):
+        v, x = (t.to(getattr(torch, dt)) for t in mg.sched_step_inputs())
+        for i in range(3):
+            x = osched.euler_step(v, sg[i], sg[i + 1], x)
+            assert np.array_equal(x.float().numpy(), g[f"step{i}.{dt}"])    # one fma per element: bit-exact
+
+
+def test_diffusers_vae_and_scheduler_cases_run_on_the_oracle():
+    from oracle import make_golden_diffusers as mg
+    sd = flux_spec.synthetic_state(flux_spec.vae_param_shapes(mg.VAE_CASE["cfg"]), seed=mg.VAE_CASE["weight_seed"])
+    z, im = mg.vae_inputs()
+    assert ovae.encode_moments(sd, im).shape == (1, 8, 4, 6) and ovae.decode(sd, z).shape == (1, 3, 32, 48)
+    v, x = mg.sched_step_inputs()
+    _, sg = osched.shifted_sigmas(*mg.SCHED_CASES[0])
+    assert osched.euler_step(v.bfloat16(), sg[0], sg[1], x.bfloat16()).dtype == torch.bfloat16
+    try:
+        import diffusers  # noqa: F401
+    except ImportError:
+        with pytest.raises(SystemExit, match="diffusers is not installed"):      # the script says why it cannot run here
+            mg.main()
