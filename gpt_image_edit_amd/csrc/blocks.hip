@@ -35,6 +35,7 @@ void set_ws(fk_gemm_args& g, const fk_block_ws& ws) {   // ops._gemm_args: only 
 // launch controls of the block's GEMMs (fk_block_ws.gemm_*): a grouped launch reads them from its first problem
 void ctl(fk_gemm_args& g, const fk_block_ws& ws) {
   g.variant = ws.gemm_variant; g.plan = ws.gemm_plan; g.group_m = ws.gemm_group_m; g.mfma = ws.gemm_mfma;
+  g.variant_used = ws.gemm_variant_used;
 }
 
 fk_gemm_args gemm(const View& a, const void* w, const void* bias, const View& c, int M, int N, int K, int epi) {

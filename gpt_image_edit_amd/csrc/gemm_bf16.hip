@@ -347,6 +347,7 @@ extern "C" int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const int rc = validate_gemm(p);
   if (rc != FK_OK) return rc;
+  if (p.variant_used) *p.variant_used = 0;   // the large-tile launcher overwrites it with the form it chose
   if (p.layout != 0) {   // K-major operands: the 256 x 256 ping-pong kernel only (it reports what it cannot take)
     FK_CHECK_ARG(!p.out_fp32, "fk_gemm_bf16: layout %d has bf16 output only", p.layout);
     const int rc2 = fk_gemm2_launch(&p, 1, 0, stream);
@@ -402,6 +403,7 @@ extern "C" int fk_gemm_bf16_grouped(const fk_gemm_args* args, int32_t n, fk_stre
   }
   hipStream_t stream = (hipStream_t)stream_;
   int rc2 = FK_E2BIG_STRIDES;
+  if (args[0].variant_used) *args[0].variant_used = 0;
   if (args[0].layout != 0) {
     rc2 = fk_gemm2_launch(args, n, 0, stream);
     if (rc2 == FK_E2BIG_STRIDES) {

@@ -1121,9 +1121,11 @@ Plan plan_launch(long nbm, int N, int K, int G, int allow, bool have_ws, int ws_
 }
 }  // namespace
 
-static thread_local int g_last_variant = 0;
-// 128 / 256: the 256 x 128 / 256 x 256 kernel, 384: mixed grid, 512: split-K pairs, 0: none of the large-tile kernels yet
-int fk_gemm_last_variant(void) { return g_last_variant; }
+// fk_gemm_args.variant_used (OUT, optional): 128 / 256: the 256 x 128 / 256 x 256 kernel, 384: mixed grid, 512: split-K pairs,
+// 640: stream-K ranges.  The library keeps no record of its own.
+static inline void report_variant(const fk_gemm_args* probs, int v) {
+  if (probs[0].variant_used) *probs[0].variant_used = v;
+}
 
 // MFMA shape of the layout-0 large-tile kernels: 32 = v_mfma_f32_32x32x16_bf16, 16 = v_mfma_f32_16x16x32_bf16 (FragMap above).
 // The two differ in the last bits (16 against 32 products per hardware sum); every launch form of ONE shape agrees bit
@@ -1204,7 +1206,7 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int variant_hint, hipStrea
         return FK_EUNSUPPORTED;
       }
     }
-    g_last_variant = 256;
+    report_variant(probs, 256);
     if (lay == 1 && probs[0].epilogue == FK_EPI_RES) return launch8<FK_EPI_RES, 256, false, 1>(ga, probs, n, stream);
     if (lay == 1) return launch8<FK_EPI_NONE, 256, false, 1>(ga, probs, n, stream);
     if (lay == 2) return launch8<FK_EPI_NONE, 256, false, 2>(ga, probs, n, stream);
@@ -1251,7 +1253,7 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int variant_hint, hipStrea
     ga.sk_partials = (float*)probs[0].splitk_ws;
     ga.sk_ctl = (unsigned*)((char*)probs[0].splitk_ws + (size_t)ws_slots * (BM * 256 * 4));
   }
-  g_last_variant = plan.variant;
+  report_variant(probs, plan.variant);
   const bool m16 = (ctl.mfma ? ctl.mfma : GEMM_MFMA_DEFAULT) == 16;
   int rc;
   switch (probs[0].out_fp32 == 2 ? FK_EPI_F32DBG : probs[0].epilogue) {
@@ -1266,7 +1268,7 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int variant_hint, hipStrea
     default: fk_set_error("fk_gemm_bf16: unknown epilogue %d", probs[0].epilogue); return FK_EUNSUPPORTED;
   }
   if (rc == FK_E2BIG_STRIDES && plan.variant == 384) {   // degenerate XCD split of a mixed grid: plain 256 x 128 grid
-    g_last_variant = 128;
+    report_variant(probs, 128);
     return fk_gemm2_launch(probs, n, 128, stream);
   }
   return rc;

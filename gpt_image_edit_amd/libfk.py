@@ -34,6 +34,7 @@ class GemmArgs(ctypes.Structure):
         ("q_out", c_vp), ("k_out", c_vp), ("wq", c_vp), ("wk", c_vp), ("rope_cs", c_vp), ("splitk_ws", c_vp),
         ("qkv_s_offset", c_i32), ("qkv_s_total", c_i32), ("qkv_heads", c_i32), ("splitk_slots", c_i32), ("layout", c_i32), ("f32_flags", c_i32),
         ("variant", c_i32), ("plan", c_i32), ("group_m", c_i32), ("mfma", c_i32),       # per-call launch controls (include/fk.h)
+        ("variant_used", ctypes.POINTER(c_i32)),                                         # OUT, optional: the launch form used
     ]
 
 
@@ -53,7 +54,8 @@ class ConvArgs(ctypes.Structure):
 class BlockWs(ctypes.Structure):          # fk_block_ws
     _fields_ = [(n, c_vp) for n in ("s", "n", "qkv", "q", "k", "o", "ff", "cat", "rope_cs", "splitk_ws", "attn_ws")] + [
         ("attn_ws_bytes", c_i64), ("splitk_slots", c_i32), ("B", c_i32), ("S_txt", c_i32), ("S_img", c_i32), ("H", c_i32),
-        ("eps", c_f32), ("gemm_variant", c_i32), ("gemm_plan", c_i32), ("gemm_group_m", c_i32), ("gemm_mfma", c_i32), ("attn_grid", c_i32)]
+        ("eps", c_f32), ("gemm_variant", c_i32), ("gemm_plan", c_i32), ("gemm_group_m", c_i32), ("gemm_mfma", c_i32), ("attn_grid", c_i32),
+        ("gemm_variant_used", ctypes.POINTER(c_i32))]
 
 
 DOUBLE_BLOCK_FIELDS = ("wqkv_img", "bqkv_img", "wqkv_txt", "bqkv_txt", "norm_q", "norm_k", "norm_added_q", "norm_added_k",
@@ -74,7 +76,6 @@ class SingleBlockWeights(ctypes.Structure):   # fk_single_block_weights
 SIGNATURES = {
     "fk_gemm_bf16": (c_i32, [ctypes.POINTER(GemmArgs), c_vp]),
     "fk_gemm_bf16_grouped": (c_i32, [ctypes.POINTER(GemmArgs), c_i32, c_vp]),
-    "fk_gemm_last_variant": (c_i32, []),
     "fk_ln_modulate_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "fk_ln_modulate2_bf16": (c_i32, [c_vp, Rows, c_vp, Rows, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_f32, c_vp]),
     "fk_qkv_post_bf16": (c_i32, [c_vp] * 9 + [c_i32] * 4 + [c_f32, c_vp]),

@@ -4,6 +4,7 @@ Only plumbing lives here: argument checking, stride extraction, raw pointers and
 stream.  All arithmetic happens in libfk.so; nothing falls back to torch ops.
 """
 import ctypes
+import threading
 from types import SimpleNamespace
 import os
 
@@ -70,6 +71,24 @@ def splitk_workspace(device):
     return ws, SPLITK_SLOTS
 
 
+_VARIANT_USED = threading.local()
+
+
+def _variant_slot():
+    """This thread's int32 that every GEMM call of this module hands to the library as fk_gemm_args.variant_used (OUT)."""
+    slot = getattr(_VARIANT_USED, "slot", None)
+    if slot is None:
+        slot = _VARIANT_USED.slot = ctypes.c_int32(0)
+    return slot
+
+
+def gemm_last_variant():
+    """Launch form of this thread's last ``gemm`` / ``gemm_grouped`` / block-level call: 128 = 256 x 128 tiles, 256 = 256 x 256,
+    384 = mixed grid, 512 = split-K pairs, 640 = stream-K ranges, 0 = the 128 x 128 kernel (tests, profiling).  The value is
+    the call's own OUT field (fk_gemm_args.variant_used): the library keeps no record."""
+    return int(_variant_slot().value)
+
+
 def _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv=None, layout=0):
     _need_cuda(a, w, bias, out, res, gate)
     if a.dtype != BF16 or w.dtype != BF16:
@@ -121,6 +140,7 @@ def _gemm_args(a, w, bias, out, epilogue, res, gate, out_fp32, alpha, qkv=None, 
         args.gate_rows_per_batch = a.shape[1]
     args.M, args.N, args.K = M, N, K
     _apply_gemm_launch(args)
+    args.variant_used = ctypes.pointer(_variant_slot())
     args.epilogue, args.out_fp32, args.alpha = epilogue, int(out_fp32), float(alpha)
     if int(out_fp32) == 1:       # fp32-class VAE encoder: fp32 bias / fp32 residual added to the fp32 output
         args.f32_flags = ((1 if bias is not None and bias.dtype == torch.float32 else 0) |

@@ -556,6 +556,7 @@ class HipFluxTransformer2DModel(ParamTreeMixin, nn.Module):
         L = ops.LAUNCH       # the host's launch defaults travel with the call (the library keeps no launch state)
         c.gemm_variant, c.gemm_plan, c.gemm_group_m, c.gemm_mfma, c.attn_grid = L.gemm_variant, L.gemm_plan, L.gemm_group_m, L.gemm_mfma, L.attn_grid
         import ctypes
+        c.gemm_variant_used = ctypes.pointer(ops._variant_slot())
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         mp, mbs = ctypes.c_void_p(mod.data_ptr()), mod.stride(0)
         if api >= 2:

@@ -122,15 +122,17 @@ typedef struct fk_gemm_args {
    *   mfma    : 0 = default (16); 16 = v_mfma_f32_16x16x32_bf16, 32 = v_mfma_f32_32x32x16_bf16 (the two differ in the last
    *             bits; every launch form of ONE shape agrees bit for bit with the others).  Layouts 1 / 2 always use 32. */
   int32_t variant, plan, group_m, mfma;
+  /* OUT, optional (NULL: not wanted): which launch form this call used -- 128 = 256 x 128 tiles, 256 = 256 x 256, 384 = mixed
+   * grid, 512 = split-K pairs of 256 x 256 tiles, 640 = stream-K ranges, 0 = none of the large-tile kernels (the 128 x 128
+   * register-staged kernel).  Written by the host code of the call before it returns (tests, profiling); a grouped launch
+   * writes through its first problem's pointer.  Replaces the thread-local fk_gemm_last_variant() of rounds 2-5. */
+  int32_t* variant_used;
 } fk_gemm_args;
 #define FK_GEMM_PLAN_EXPLICIT 8
 #define FK_GEMM_PLAN_BATCH_INVARIANT (FK_GEMM_PLAN_EXPLICIT | 1)   /* mixed grids only: no K split of any kind */
 #define FK_SPLITK_SLOT_BYTES (256 * 256 * 4 + 8)
 
 int fk_gemm_bf16(const fk_gemm_args* args, fk_stream_t stream);
-/* Which large-tile launch the calling thread's last fk_gemm_bf16[_grouped] used: 128 = 256 x 128 tiles, 256 = 256 x 256,
- * 384 = mixed grid, 512 = split-K pairs of 256 x 256 tiles, 0 = none so far (tests, profiling). */
-int fk_gemm_last_variant(void);
 
 /* n (<= FK_MAX_GROUP) independent problems that share N, K and the epilogue in ONE launch: the text- and
  * image-stream linears of a FluxTransformerBlock (different weights, different row counts) fill the GPU
@@ -221,6 +223,7 @@ typedef struct fk_block_ws {
   /* launch controls handed to every GEMM / attention launch of the block (all zero = defaults): fk_gemm_args.variant / plan /
    * group_m / mfma and fk_attention_fwd_ws_bf16's `grid` */
   int32_t gemm_variant, gemm_plan, gemm_group_m, gemm_mfma, attn_grid;
+  int32_t* gemm_variant_used;      /* OUT, optional: fk_gemm_args.variant_used of every GEMM of the call (the last one stays) */
 } fk_block_ws;
 typedef struct fk_double_block_weights {   /* bf16; Linear weights [N, K] K-contiguous, fused q|k|v as [3D, D] / [3D] */
   const void *wqkv_img, *bqkv_img, *wqkv_txt, *bqkv_txt;          /* attn.to_{q,k,v} / attn.add_{q,k,v}_proj */

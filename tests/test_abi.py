@@ -134,11 +134,13 @@ def test_library_keeps_no_process_wide_launch_switches():
     fk_block_ws.gemm_* / attn_grid); the host's defaults live in ``ops.LAUNCH`` (Python, application layer)."""
     import subprocess
     from gpt_image_edit_amd import libfk, ops
-    assert not [n for n in _declared_symbols() if re.search(r"_set_|_get_", n)]
+    assert not [n for n in _declared_symbols() if re.search(r"_set_|_get_|_last_variant", n)]
     out = subprocess.run(["nm", "-D", "--defined-only", libfk.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = [l.split()[-1] for l in out.splitlines() if " T " in l]
     assert len([n for n in exported if n.startswith("fk_")]) >= 50
-    assert not [n for n in exported if n.startswith("fk_") and ("_set_" in n or "_get_" in n)]
+    assert not [n for n in exported if n.startswith("fk_") and ("_set_" in n or "_get_" in n or "_last_variant" in n)]
+    # ... and no diagnostic record either (round 6): the launch form a call used comes back through the call's own OUT field
+    assert "variant_used" in {f for f, _ in libfk.GemmArgs._fields_} and "gemm_variant_used" in {f for f, _ in libfk.BlockWs._fields_}
     assert {"variant", "plan", "group_m", "mfma"} <= {f for f, _ in libfk.GemmArgs._fields_}
     assert {"gemm_variant", "gemm_plan", "gemm_group_m", "gemm_mfma", "attn_grid"} <= {f for f, _ in libfk.BlockWs._fields_}
     # the setters of the host layer change ops.LAUNCH (and the epoch a captured graph keys on), nothing else

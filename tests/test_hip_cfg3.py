@@ -106,7 +106,7 @@ def test_batch32_S8704_is_deterministic_and_batch_independent():
     txt_ids = torch.zeros(S_txt, 3, device="cuda", dtype=BF)
     kw = dict(txt_ids=txt_ids, img_ids=img_ids, return_dict=False)
     o_a = m(hidden_states=hs, encoder_hidden_states=enc, pooled_projections=pooled, timestep=t, guidance=gd, **kw)[0].clone()
-    assert libfk.load().fk_gemm_last_variant() in (128, 256, 384)
+    assert ops.gemm_last_variant() in (128, 256, 384)
     assert m._ws[(B, S_txt, S_img)].qkv.numel() * 2 > (1 << 32), "the point of this test is a > 4 GB buffer"
     o_b = m(hidden_states=hs, encoder_hidden_states=enc, pooled_projections=pooled, timestep=t, guidance=gd, **kw)[0].clone()
     assert torch.isfinite(o_a.float()).all()

@@ -82,7 +82,7 @@ def test_hot_gemm_kernels_at_the_stated_tolerance(ops, M, N, K, what):
             ops.gemm_set_variant(force)
             got = ops.gemm(ad, wd, bd, out_fp32=2)
             torch.cuda.synchronize()
-            v = lib.fk_gemm_last_variant()
+            v = ops.gemm_last_variant()
             if v in seen and force != 0:
                 continue                      # the forced form does not apply to this shape (fell back to one already checked)
             d = report(f"hot gemm f32 [{what}] {M}x{N}x{K} force={force} -> variant {v}", got, ref)
@@ -192,8 +192,8 @@ def test_gemm_large_tile_kernel(ops, M, N, K):
 
 
 def _last_variant():
-    from gpt_image_edit_amd import libfk
-    return libfk.load().fk_gemm_last_variant()
+    from gpt_image_edit_amd import ops
+    return ops.gemm_last_variant()
 
 
 @pytest.mark.parametrize("B,S,N,K,want", [(1, 2560, 12288, 3072, 256), (1, 2560, 9216, 3072, 384),

@@ -50,7 +50,7 @@ for (M, N, K) in shapes:
             if r:
                 res[v].append(fl * n_per / (e0.elapsed_time(e1) * 1e-3) / 1e12)
             elif v != "vendor":   # first round: the variants must agree bit for bit (split-K pairs, other MFMA shape: to the last bits)
-                used[v] = lib.fk_gemm_last_variant()
+                used[v] = ops.gemm_last_variant()
                 if ref is None:
                     ref, ref_m, ref_v = out.clone(), form_of(v)[1], used[v]
                 elif used[v] in (512, 640) or ref_v in (512, 640) or form_of(v)[1] != ref_m:
