@@ -717,6 +717,130 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const GroupArgs ga) {
   }
 }
 
+// ---- gemm10: four waves, one per SIMD, 128 x 128 per wave, every instruction of the K loop placed by hand (round 6) ---------
+// 256 x 256 x 64 tile on v_mfma_f32_16x16x32_bf16 with all 256 accumulator registers pinned in the AGPR half: 0.25 ds_read_b128
+// per MFMA (gemm8_kernel: 0.75), half the waves, ONE barrier per K-tile (gemm8_kernel: 8), operands staged through registers
+// (buffer_load_dwordx4 one K-tile ahead + ds_write_b128) because an LDS-DMA request costs a wave that is alone on its SIMD four
+// MFMA slots.  The loop is ONE asm statement (gemm10_loop.inc, written by gemm10_gen.py: schedule, register map and the reasons
+// are in that file's header); its operands are pinned to fixed registers, so the text names registers directly.  Same LDS image,
+// same fragment -> k mapping and same K order as gemm8_kernel<.., M16 = true>: the sums agree bit for bit.
+struct Cfg10 {
+  static constexpr bool M16 = true;
+  static constexpr int NTHREADS = 256;
+  static constexpr int BK = 64, ROW_BYTES = 128;
+  static constexpr int MF = 4, NF = 4;
+  static constexpr int HALF_BYTES = 128 * ROW_BYTES;      // one half-tile: 128 rows x 64 k
+  static constexpr int BUF_BYTES = 4 * HALF_BYTES;        // A0 | A1 | W0 | W1 of one K-tile
+  static constexpr int RING_BYTES = 2 * BUF_BYTES;
+  static constexpr int CT_LD = 256 + 8;
+  static constexpr int CT_BYTES = BM * CT_LD * 2;
+  static constexpr int SMEM_BYTES = RING_BYTES > CT_BYTES ? RING_BYTES : CT_BYTES;
+  static FK_DEV int tile_row(int wm, int mf) { return wm * 128 + mf * 32; }
+  static FK_DEV int tile_col(int wn, int nf) { return wn * 128 + nf * 32; }
+};
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+#define G10_OPERANDS \
+      : "={a[0:15]}"(acc[0][0]), "={a[16:31]}"(acc[0][1]), "={a[32:47]}"(acc[0][2]), "={a[48:63]}"(acc[0][3]), \
+        "={a[64:79]}"(acc[1][0]), "={a[80:95]}"(acc[1][1]), "={a[96:111]}"(acc[1][2]), "={a[112:127]}"(acc[1][3]), \
+        "={a[128:143]}"(acc[2][0]), "={a[144:159]}"(acc[2][1]), "={a[160:175]}"(acc[2][2]), "={a[176:191]}"(acc[2][3]), \
+        "={a[192:207]}"(acc[3][0]), "={a[208:223]}"(acc[3][1]), "={a[224:239]}"(acc[3][2]), "={a[240:255]}"(acc[3][3]) \
+      : "{v[16:23]}"(a_voff), "{v[24:31]}"(w_voff), "{v[32:39]}"(rd), "{v[40:43]}"(wr), "{s[40:43]}"(od_a.w), "{s[44:47]}"(od_w.w), \
+        "{s48}"(k0), "{s49}"(nks), "{s50}"(kmax) \
+      : "memory", "scc", "s52", "s53", "s54", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+
+template <int EPI, int V = 0>
+FK_DEV void gemm10_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, int kt_first, int nk) {
+  using C = Cfg10;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const fk_gemm_args& p = ga.p[pi];
+  const BufDesc od_a = make_buf_desc((const bf16_t*)p.A + fk_row_offset(p.a, m0), 0x7fffffffu);
+  const BufDesc od_w = make_buf_desc((const bf16_t*)p.W + (int64_t)n0 * p.ldw, 0x7fffffffu);
+  // global side: wave w stages rows [64 w, 64 w + 64) of the A tile and of the W tile as 8 pieces of 8 rows x 128 B each;
+  // lane -> (row lane >> 3, 16-byte chunk lane & 7); rows beyond the problem are clamped (their products are never stored)
+  const int lrow = lane >> 3, chunk = lane & 7;
+  i32x8_t a_voff, w_voff;
+  {
+    const TileRows arow(p.a, m0);
+    const int ldw2 = (int)p.ldw * 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rl = wave * 64 + i * 8 + lrow;
+      a_voff[i] = arow.off(min(rl, p.M - 1 - m0)) * 2 + chunk * 16;
+      w_voff[i] = min(rl, p.N - 1 - n0) * ldw2 + chunk * 16;
+    }
+  }
+  // LDS side.  Write: piece i of the wave lands at rows 8 ((w & 1) 8 + i) + lrow of half-tile w >> 1 (A) / of W's at + 32 KiB;
+  // logical chunk c of row r at physical chunk c ^ ((r >> 1) & 7), and (r >> 1) & 7 = (4 (i & 1) + (lrow >> 1)) & 7.
+  // Read: gemm8_kernel's M16 fragments -- row lane & 15 of 16-row block m / n (the immediate), k-octet lane >> 4 of k-step kk.
+  const int base = (int)lds_addr_of(smem);
+  i32x8_t rd;
+  i32x4_t wr;
+  {
+    const int frow = lane & 15, fhalf = lane >> 4, fsw = (frow >> 1) & 7;
+#pragma unroll
+    for (int buf = 0; buf < 2; ++buf)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ko = ((kk * 4 + fhalf) ^ fsw) << 4;
+        rd[2 * buf + kk] = base + buf * C::BUF_BYTES + wm * C::HALF_BYTES + frow * C::ROW_BYTES + ko;
+        rd[4 + 2 * buf + kk] = base + buf * C::BUF_BYTES + (2 + wn) * C::HALF_BYTES + frow * C::ROW_BYTES + ko;
+      }
+#pragma unroll
+    for (int buf = 0; buf < 2; ++buf)
+#pragma unroll
+      for (int par = 0; par < 2; ++par)
+        wr[2 * buf + par] = base + buf * C::BUF_BYTES + (wave >> 1) * C::HALF_BYTES + (wave & 1) * 8192 + lrow * C::ROW_BYTES +
+                            ((chunk ^ ((par * 4 + (lrow >> 1)) & 7)) << 4);
+  }
+  const int k0 = __builtin_amdgcn_readfirstlane(kt_first * (C::BK * 2));
+  const int nks = __builtin_amdgcn_readfirstlane(nk);
+  const int kmax = k0 + (nks - 1) * (C::BK * 2);
+
+  f32x16_t acc[C::NF][C::MF];
+  if constexpr (V == 0) {
+    asm volatile(
+#include "gemm10_loop.inc"
+        G10_OPERANDS);
+  }
+#ifdef FK_G10_EXPERIMENTS
+  else if constexpr (V == 1) { asm volatile(
+#include "gemm10_loop_x1.inc"
+        G10_OPERANDS); }
+  else if constexpr (V == 2) { asm volatile(
+#include "gemm10_loop_x2.inc"
+        G10_OPERANDS); }
+  else if constexpr (V == 3) { asm volatile(
+#include "gemm10_loop_x3.inc"
+        G10_OPERANDS); }
+  else if constexpr (V == 4) { asm volatile(
+#include "gemm10_loop_x4.inc"
+        G10_OPERANDS); }
+  else if constexpr (V == 5) { asm volatile(
+#include "gemm10_loop_x5.inc"
+        G10_OPERANDS); }
+  else if constexpr (V == 6) { asm volatile(
+#include "gemm10_loop_x6.inc"
+        G10_OPERANDS); }
+  else if constexpr (V == 7) { asm volatile(
+#include "gemm10_loop_x7.inc"
+        G10_OPERANDS); }
+#endif
+  store_tile<EPI, 256, C>(acc, p, smem, m0, n0, wm, wn);
+}
+
+template <int EPI, int V = 0>
+__global__ __launch_bounds__(256, 1) void gemm10_kernel(const GroupArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int pi, m0, n0;
+  select_tile<256>(ga, xcd_chunk_index(), pi, m0, n0);
+  gemm10_body<EPI, V>(ga, smem, pi, m0, n0, 0, ga.p[0].K / Cfg10::BK);
+}
+
 // ---- stream-K ranges (round 4) --------------------------------------------------------------------------------------------
 // A long-K GEMM whose 256 x 256 tiling needs a poorly filled last round (M = 8704, N = 3072, K = 12288 / 15360: 408 tiles =
 // 1.59 rounds of 256 CUs, run as 2) as a PERSISTENT grid of one workgroup per CU: the tiles' K-tiles are dealt out as G
@@ -781,6 +905,39 @@ int launch8_streamk(GroupArgs& ga, const fk_gemm_args* probs, int n, int grid, h
   FK_ENSURE_MAX_LDS(kern, Cfg8<BN>::SMEM_BYTES, "fk_gemm_bf16 (256 x 256 tile, stream-K ranges)");
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Cfg8<BN>::SMEM_BYTES, stream, ga);
   FK_CHECK_LAUNCH("fk_gemm_bf16 (256 x 256 tile, stream-K ranges)");
+  return FK_OK;
+}
+
+
+template <int EPI>
+int launch10(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) {
+  const int total = count_tiles<256>(ga, probs, n);
+#ifdef FK_G10_EXPERIMENTS
+  if constexpr (EPI == FK_EPI_NONE) {   // measurement forms of the loop (gemm10_gen.py EXPERIMENTS): FK_G10_X=<n>
+    static const int x = getenv("FK_G10_X") ? atoi(getenv("FK_G10_X")) : 0;
+    void (*kx)(const GroupArgs) = nullptr;
+    switch (x) {
+      case 1: kx = gemm10_kernel<EPI, 1>; break;
+      case 2: kx = gemm10_kernel<EPI, 2>; break;
+      case 3: kx = gemm10_kernel<EPI, 3>; break;
+      case 4: kx = gemm10_kernel<EPI, 4>; break;
+      case 5: kx = gemm10_kernel<EPI, 5>; break;
+      case 6: kx = gemm10_kernel<EPI, 6>; break;
+      case 7: kx = gemm10_kernel<EPI, 7>; break;
+      default: break;
+    }
+    if (kx) {
+      if (hipFuncSetAttribute((const void*)kx, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg10::SMEM_BYTES) != hipSuccess) return FK_EINVAL;
+      hipLaunchKernelGGL(kx, dim3(total), dim3(256), Cfg10::SMEM_BYTES, stream, ga);
+      FK_CHECK_LAUNCH("fk_gemm_bf16 (gemm10 experiment)");
+      return FK_OK;
+    }
+  }
+#endif
+  auto kern = gemm10_kernel<EPI>;
+  FK_ENSURE_MAX_LDS(kern, Cfg10::SMEM_BYTES, "fk_gemm_bf16 (256 x 256 tile, 4 waves, hand-placed loop)");
+  hipLaunchKernelGGL(kern, dim3(total), dim3(256), Cfg10::SMEM_BYTES, stream, ga);
+  FK_CHECK_LAUNCH("fk_gemm_bf16 (256 x 256 tile, 4 waves, hand-placed loop)");
   return FK_OK;
 }
 
@@ -1036,6 +1193,7 @@ int launch_variant_m(GroupArgs& ga, const fk_gemm_args* probs, int n, int varian
     case 384: return launch_mix<EPI, M16>(ga, probs, n, big_cols, stream);
     case 512: return launch8<EPI, 256, true, 0, M16>(ga, probs, n, stream);
     case 640: return launch8_streamk<EPI, 256, M16>(ga, probs, n, big_cols, stream);
+    case 1024: return launch10<EPI>(ga, probs, n, stream);   // 16 x 16 x 32 only: agrees with the M16 forms bit for bit
     default: return launch9<EPI, 128, M16>(ga, probs, n, stream);
   }
 }
@@ -1148,8 +1306,10 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int variant_hint, hipStrea
   // launch controls come with the call (fk_gemm_args.variant / plan / group_m / mfma of the first problem): no process state
   const fk_gemm_args& ctl = probs[0];
   if (variant_hint == 0) variant_hint = ctl.variant;
-  if (!(variant_hint == 0 || variant_hint == 128 || variant_hint == 256 || variant_hint == 384 || variant_hint == 512 || variant_hint == 640)) {
-    fk_set_error("fk_gemm_bf16: variant %d is not one of 0 (launch plan), 128, 256, 384 (mixed), 512 (split-K pairs), 640 (stream-K ranges)", variant_hint);
+  if (!(variant_hint == 0 || variant_hint == 128 || variant_hint == 256 || variant_hint == 384 || variant_hint == 512 || variant_hint == 640 ||
+        variant_hint == 1024)) {
+    fk_set_error("fk_gemm_bf16: variant %d is not one of 0 (launch plan), 128, 256, 384 (mixed), 512 (split-K pairs), 640 (stream-K ranges), "
+                 "1024 (4-wave hand-placed 256 x 256 kernel)", variant_hint);
     return FK_EINVAL;
   }
   if (ctl.plan != 0 && (ctl.plan & ~15) != 0 || (ctl.plan != 0 && !(ctl.plan & FK_GEMM_PLAN_EXPLICIT))) {
@@ -1240,6 +1400,7 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int variant_hint, hipStrea
       break;
     }
     case 512: plan = {sk_ok ? 512 : (ok256 ? 256 : 128), 0}; break;
+    case 1024: plan = {ok256 ? 1024 : 128, 0}; break;   // gemm10_kernel: plain grid of 256 x 256 tiles
     case 640: {   // forced: stream-K ranges wherever every tile would be cut at most once (test hook: also on small grids)
       const int Gs = G < ws_slots ? G : ws_slots;
       const bool ok = ws_slots > 0 && ok256 && t256 * (K / 64) >= (long)Gs * (K / 64 + 2 * SK_MIN_PART) && t256 * (long)(K / 64) < (1l << 31);

@@ -219,9 +219,10 @@ def _set_launch(**kw):
 
 def gemm_set_variant(variant):
     """Force the launch form of the large-tile GEMMs where it applies: 128 = 256 x 128 tiles, 256 = 256 x 256 tiles, 384 =
-    mixed grid, 512 = split-K pairs, 640 = stream-K ranges; 0 = the launch plan chooses per problem.  (fk_gemm_args.variant)"""
-    if int(variant) not in (0, 128, 256, 384, 512, 640):
-        raise ValueError(f"gemm_set_variant: {variant} is not one of 0, 128, 256, 384, 512, 640")
+    mixed grid, 512 = split-K pairs, 640 = stream-K ranges, 1024 = the 4-wave hand-placed 256 x 256 kernel (gemm10_kernel);
+    0 = the launch plan chooses per problem.  (fk_gemm_args.variant)"""
+    if int(variant) not in (0, 128, 256, 384, 512, 640, 1024):
+        raise ValueError(f"gemm_set_variant: {variant} is not one of 0, 128, 256, 384, 512, 640, 1024")
     _set_launch(gemm_variant=int(variant))
 
 

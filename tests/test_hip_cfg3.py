@@ -89,7 +89,7 @@ def test_block_at_S8704_matches_fp32_oracle(n_double, n_single):
 def test_batch32_S8704_is_deterministic_and_batch_independent():
     """cfg 3 shape through one double + one single block: activation buffers > 4 GB, 256 x 256 tiles, > 3 rounds."""
     _skip()
-    from gpt_image_edit_amd import flux_spec, libfk
+    from gpt_image_edit_amd import flux_spec, ops
     from gpt_image_edit_amd.helpers import _prepare_latent_image_ids as ids
     from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
     cfg = dict(flux_spec.FLUX_KONTEXT_CONFIG, num_layers=1, num_single_layers=1)

@@ -624,3 +624,62 @@ def test_gemm_both_mfma_shapes_every_form(ops, shape):
         test_gemm_tile_order_does_not_change_the_bits(ops)
     finally:
         ops.gemm_set_mfma(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 512, 192), (2560, 3072, 3072), (2048 + 3, 1280 - 8, 256),
+                                   (700, 200, 320), (2560, 9216, 3072)])
+def test_gemm10_hand_placed_kernel_equals_gemm8_bit_for_bit(ops, M, N, K):
+    """gemm10_kernel (4 waves, 128 x 128 per wave, K loop as one hand-placed asm statement: csrc/gemm10_gen.py) stages the
+    same LDS image, reads the same fragments and walks K in the same order as gemm8_kernel on v_mfma_f32_16x16x32_bf16: the
+    two must agree BIT FOR BIT -- on the fp32-output build (raw accumulators + bias) and through the shared bf16 epilogue --
+    for 1, 2, 3 and many K-tiles (prologue / odd / even loop exits), ragged M and N edges, and the fp32 build must meet the
+    stated tolerance against an fp64 product."""
+    a, w, bias = randn(M, K, seed=171), randn(N, K, seed=172, scale=0.05), randn(N, seed=173, scale=0.1)
+    ad, wd, bd = a.cuda(), w.cuda(), bias.cuda()
+    ops.gemm_set_mfma(16)
+    try:
+        got = {}
+        for force in (256, 1024):
+            ops.gemm_set_variant(force)
+            got[force] = (ops.gemm(ad, wd, bd, out_fp32=2).clone(), ops.gemm(ad, wd, bd, epilogue=ops.FK_EPI_GELU_TANH).clone())
+            torch.cuda.synchronize()
+            used = ops.gemm_last_variant()
+            if N % 256 == 0:
+                assert used == force, f"forced {force}, ran {used}"
+    finally:
+        ops.gemm_set_variant(0)
+        ops.gemm_set_mfma(0)
+    ref = (a.double() @ w.double().T + bias.double()).float()
+    report(f"gemm10 f32 {M}x{N}x{K}", got[1024][0], ref)
+    torch.testing.assert_close(got[1024][0].cpu(), ref, rtol=1e-3, atol=1e-4)
+    if N % 256 == 0:       # otherwise both forced forms fall back to the same 256 x 128 kernel
+        assert torch.equal(got[256][0], got[1024][0]), "gemm10 accumulators differ from gemm8's"
+        assert torch.equal(got[256][1], got[1024][1]), "gemm10 bf16 epilogue output differs from gemm8's"
+
+
+def test_gemm10_batched_rows_gate_residual_and_grouped(ops):
+    """gemm10 behind the batched [B, S, :] addressing (a batch boundary inside a 256-row tile), the gated-residual epilogue in
+    place, and a grouped launch of two problems: equal to gemm8's output bit for bit."""
+    B, S, N, K = 3, 200, 512, 256
+    x = randn(B, S, K, seed=181)
+    w, bias = randn(N, K, seed=182, scale=0.02), randn(N, seed=183, scale=0.1)
+    res = randn(B, S, N, seed=184)
+    mod = randn(B, 3 * N, seed=185, scale=0.5)
+    outs = {}
+    ops.gemm_set_mfma(16)
+    try:
+        for force in (256, 1024):
+            ops.gemm_set_variant(force)
+            rd = res.cuda().clone()
+            ops.gemm(x.cuda(), w.cuda(), bias.cuda(), out=rd, epilogue=ops.FK_EPI_GATE_RES, res=rd, gate=mod.cuda()[:, N:2 * N])
+            assert ops.gemm_last_variant() == force
+            a1, a2 = randn(300, K, seed=186).cuda(), randn(1000, K, seed=187).cuda()
+            w2 = randn(N, K, seed=188, scale=0.02).cuda()
+            g = ops.gemm_grouped([dict(a=a1, w=w.cuda(), bias=bias.cuda()), dict(a=a2, w=w2, bias=None)], epilogue=ops.FK_EPI_NONE)
+            assert ops.gemm_last_variant() == force
+            outs[force] = (rd.clone(), g[0].clone(), g[1].clone())
+    finally:
+        ops.gemm_set_variant(0)
+        ops.gemm_set_mfma(0)
+    for u, v in zip(outs[256], outs[1024]):
+        assert torch.equal(u, v)
