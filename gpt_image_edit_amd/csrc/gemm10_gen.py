@@ -73,7 +73,7 @@ def mfma(e, wbase, abase, n, m, zero_c):
     e(f"v_mfma_f32_16x16x32_bf16 {ar(c)}, {vr(wbase + 4 * n)}, {vr(abase + 4 * m)}, {'0' if zero_c else ar(c)}")
 
 
-def kstep(e, cfg, step, buf, zero_c):
+def kstep(e, cfg, step, buf, zero_c, no_stage=False):
     """One k-step = 64 MFMAs + its share of reads, stores and loads.  step 0: MFMAs on X, reads into Y; step 1: the reverse.
     cfg["ablate"] (measurement only, results wrong): "reads" / "stage" / "barrier" / "vmcnt" drop that ingredient."""
     ab = cfg.get("ablate", ())
@@ -98,12 +98,14 @@ def kstep(e, cfg, step, buf, zero_c):
         lds_off = (32768 if is_w else 0) + i * 1024
         voff = (24 if is_w else 16) + i
         desc = "s[44:47]" if is_w else "s[40:43]"
-        if "stage" in ab:
+        if "stage" in ab or no_stage:
             continue
-        if "vmcnt" not in ab:
+        if "vmcnt" not in ab and "loads" not in ab:
             fill[cfg["write_slots"][k]].append("s_waitcnt vmcnt(15)")
-        fill[cfg["write_slots"][k]].append(f"ds_write_b128 v{wr}, {vr(STG + 4 * j)} offset:{lds_off}")
-        fill[cfg["load_slots"][k]].append(f"buffer_load_dwordx4 {vr(STG + 4 * j)}, v{voff}, {desc}, {soff} offen")
+        if "writes" not in ab:
+            fill[cfg["write_slots"][k]].append(f"ds_write_b128 v{wr}, {vr(STG + 4 * j)} offset:{lds_off}")
+        if "loads" not in ab:
+            fill[cfg["load_slots"][k]].append(f"buffer_load_dwordx4 {vr(STG + 4 * j)}, v{voff}, {desc}, {soff} offen")
     # scalar bookkeeping of the loop (once per tile, in k-step 1): advance the two load offsets, clamped to the last K-tile
     if step == 1:
         fill[61].append("s_add_u32 s52, s52, 128")
@@ -116,6 +118,8 @@ def kstep(e, cfg, step, buf, zero_c):
             mfma(e, m_w, m_a, n, m, zero_c)
             for f in fill[slot]:
                 e(f)
+            if cfg.get("pad") and not fill[slot]:      # measurement: one cheap instruction in every otherwise empty gap
+                e(cfg["pad"])
             slot += 1
     e("s_waitcnt lgkmcnt(0)")
     if step == 0 and "barrier" not in ab:
@@ -123,35 +127,45 @@ def kstep(e, cfg, step, buf, zero_c):
 
 
 def tile(e, cfg, buf, first=False):
-    kstep(e, cfg, 0, buf, zero_c=first)
+    kstep(e, cfg, 0, buf, zero_c=first, no_stage=first)   # tile 0: the prologue has published tile 1 whole and has tile 2 in flight
     kstep(e, cfg, 1, buf, zero_c=False)
 
 
 def prologue(e, cfg):
+    """Tiles 0 and 1 into the ring, tile 2 in flight, fragment set X of tile 0 -- ONE memory latency: all 32 loads of tiles 0 and 1
+    are issued at once (tile 1 into the fragment registers of set Y, which nothing uses yet)."""
+    def ld(dst, j, soff):
+        is_w, i = j >= 8, j & 7
+        e(f"buffer_load_dwordx4 {vr(dst)}, v{(24 if is_w else 16) + i}, {'s[44:47]' if is_w else 's[40:43]'}, {soff} offen")
+
+    def st(src, j, buf):
+        is_w, i = j >= 8, j & 7
+        e(f"ds_write_b128 v{40 + 2 * buf + (i & 1)}, {vr(src)} offset:{(32768 if is_w else 0) + i * 1024}")
     e("s_nop 4")                                  # an operand SGPR written by VALU (v_readfirstlane) right before the statement
+    if cfg.get("timed"):
+        e("s_memtime s[60:61]")                   # measurement forms: statement entry (s[60:61] is an operand then)
     e("s_mov_b32 s52, s48")                       # K-tile 0
     e("s_add_u32 s53, s48, 128")
     e("s_min_u32 s53, s53, s50")                  # K-tile min(1, nk - 1)
-    for j in range(16):                           # tile 0 -> staging
-        is_w, i = j >= 8, j & 7
-        e(f"buffer_load_dwordx4 {vr(STG + 4 * j)}, v{(24 if is_w else 16) + i}, {'s[44:47]' if is_w else 's[40:43]'}, s52 offen")
-    e("s_waitcnt vmcnt(0)")
-    for j in range(16):                           # -> buffer 0
-        is_w, i = j >= 8, j & 7
-        e(f"ds_write_b128 v{40 + (i & 1)}, {vr(STG + 4 * j)} offset:{(32768 if is_w else 0) + i * 1024}")
-    for j in range(16):                           # tile 1 -> staging (A pieces first)
-        is_w, i = j >= 8, j & 7
-        e(f"buffer_load_dwordx4 {vr(STG + 4 * j)}, v{(24 if is_w else 16) + i}, {'s[44:47]' if is_w else 's[40:43]'}, s53 offen")
+    for j in range(16):
+        ld(STG + 4 * j, j, "s52")                 # tile 0 -> staging
+    for j in range(16):
+        ld(Y_W + 4 * j, j, "s53")                 # tile 1 -> v[192:255]
     e("s_add_u32 s52, s53, 128")
     e("s_min_u32 s52, s52, s50")                  # K-tile min(2, nk - 1)
-    e("s_waitcnt vmcnt(8)")                       # tile 1's A pieces
-    for j in range(8):                            # -> buffer 1 (what "iteration -1, k-step 1" would have written)
-        e(f"ds_write_b128 v{42 + (j & 1)}, {vr(STG + 4 * j)} offset:{j * 1024}")
-    for j in range(8):                            # tile 2's A pieces -> staging
-        e(f"buffer_load_dwordx4 {vr(STG + 4 * j)}, v{16 + j}, s[40:43], s52 offen")
     e("s_add_u32 s53, s52, 128")
-    e("s_min_u32 s53, s53, s50")                  # K-tile min(3, nk - 1): k-step 1 of iteration 0 loads its A pieces
-    # invariant at the top of iteration T: s52 = offset of tile T+2 (W pieces, k-step 0), s53 = offset of tile T+3 (A pieces)
+    e("s_min_u32 s53, s53, s50")                  # K-tile min(3, nk - 1)
+    e("s_waitcnt vmcnt(16)")
+    for j in range(16):
+        st(STG + 4 * j, j, 0)                     # tile 0 -> buffer 0
+    for j in range(16):
+        ld(STG + 4 * j, j, "s52")                 # tile 2 -> staging (stays in flight into the loop)
+    e("s_waitcnt vmcnt(16)")
+    for j in range(16):
+        st(Y_W + 4 * j, j, 1)                     # tile 1 -> buffer 1
+    # loop invariant at the top of iteration T: 16 loads in flight (A pieces of the older tile first), s52 = row offset of tile
+    # T+2 (its W pieces are loaded in k-step 0), s53 = of tile T+3 (A pieces, k-step 1).  Tile 0's k-step 0 stages nothing
+    # (tile 1 is complete, tile 2 in flight); its k-step 1 bookkeeping moves s52 on to tile 3 like every other iteration's.
     e("s_waitcnt lgkmcnt(0)")
     e("s_barrier")
     for i in range(8):
@@ -163,7 +177,10 @@ def prologue(e, cfg):
 
 def generate(cfg):
     e = Emit()
+    timed = cfg.get("timed", False)               # measurement forms: s_memtime either side of the loop (s[56:59] are operands then)
     prologue(e, cfg)
+    if timed:
+        e("s_memtime s[56:57]")
     # tile 0 in buffer 0 with zero C; then buffers alternate
     e("s_sub_u32 s54, s49, 1")                    # tiles left after tile 0
     tile(e, cfg, 0, first=True)
@@ -179,30 +196,42 @@ def generate(cfg):
     e("s_cmp_lg_u32 s54, 0")
     e("s_cbranch_scc1 .Lg10_loop_%=")
     e(".Lg10_done_%=:")
-    e("s_waitcnt vmcnt(0)")                       # the surplus loads still target staging registers the compiler owns again
+    if timed:
+        e("s_memtime s[58:59]")
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")                       # the surplus loads still target staging registers the compiler owns again
     e("s_nop 15")                                 # XDL write -> v_accvgpr_read of the epilogue: hipcc's hazard recognizer does
     e("s_nop 15")                                 # not see into the statement
     return e.text()
 
 
 DEFAULT = dict(
-    # slot (0..63 = the MFMA it follows) of each of the 16 fragment reads, the 8 stores and the 8 loads of a k-step
-    read_slots=[0, 2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30],
-    write_slots=[3, 11, 19, 27, 33, 41, 49, 57],
-    load_slots=[5, 13, 21, 29, 35, 43, 51, 59],
+    # slot (0..63 = the MFMA it follows) of each of the 16 fragment reads, the 8 stores and the 8 loads of a k-step: at most one
+    # of them per gap (a ds_write_b128 or a buffer_load_dwordx4 costs ~12 cycles of a gap that hides ~4: profiles/r06_gemm10_cycles_callE.txt)
+    read_slots=[0, 2, 4, 8, 10, 12, 16, 18, 20, 24, 26, 28, 32, 34, 36, 40],
+    write_slots=[6, 14, 22, 30, 38, 44, 48, 52], load_slots=[7, 15, 23, 31, 39, 46, 50, 54],
 )
 # measurement forms (built only with -DFK_G10_EXPERIMENTS, selected by FK_G10_X=<n>; results of 1..5 are wrong by construction)
+T = dict(DEFAULT, timed=True)
+P6 = dict(read_slots=[0, 2, 4, 8, 10, 12, 16, 18, 20, 24, 26, 28, 32, 34, 36, 40],
+          write_slots=[6, 14, 22, 30, 38, 44, 48, 52], load_slots=[7, 15, 23, 31, 39, 46, 50, 54], timed=True)
+P7 = dict(read_slots=list(range(16)), write_slots=[18, 22, 26, 30, 34, 38, 42, 46], load_slots=[20, 24, 28, 32, 36, 40, 44, 48], timed=True)
 EXPERIMENTS = {
-    1: dict(DEFAULT, ablate=("barrier",)),
-    2: dict(DEFAULT, ablate=("stage",)),
-    3: dict(DEFAULT, ablate=("reads",)),
-    4: dict(DEFAULT, ablate=("barrier", "stage", "reads")),
-    5: dict(DEFAULT, ablate=("vmcnt",)),
-    # one heavy instruction per even slot, reads done by slot 44
-    6: dict(read_slots=[0, 2, 4, 8, 10, 12, 16, 18, 20, 24, 26, 28, 32, 34, 36, 40],
-            write_slots=[6, 14, 22, 30, 38, 44, 48, 52], load_slots=[7, 15, 23, 31, 39, 46, 50, 54]),
-    # reads in the first 16 slots back to back, then stores / loads
-    7: dict(read_slots=list(range(16)), write_slots=[18, 22, 26, 30, 34, 38, 42, 46], load_slots=[20, 24, 28, 32, 36, 40, 44, 48]),
+    1: T,                                                        # the shipped schedule, timed
+    2: dict(T, ablate=("barrier",)),
+    3: dict(T, ablate=("barrier", "stage", "reads")),            # MFMAs only
+    4: dict(T, ablate=("barrier", "stage", "reads"), pad="s_nop 0"),
+    5: dict(T, ablate=("barrier", "stage", "reads"), pad="v_mov_b32 v64, v64"),
+    6: dict(T, ablate=("barrier", "stage")),                     # MFMAs + fragment reads
+    7: dict(T, ablate=("barrier", "reads")),                     # MFMAs + loads + stores
+    8: dict(T, ablate=("barrier", "reads", "loads")),            # MFMAs + ds_write_b128
+    9: dict(T, ablate=("barrier", "reads", "writes")),           # MFMAs + buffer_load_dwordx4 (+ vmcnt)
+    10: P6,
+    11: P7,
+    12: dict(T, pad="s_nop 0"),                                  # the shipped schedule with every empty gap padded
+    13: dict(T, ablate=("vmcnt",)),
+    14: dict(P6, pad="s_nop 0"),
+    15: dict(T, ablate=("stage",)),                              # MFMAs + reads + barrier
+    16: dict(T, ablate=("reads",)),                              # MFMAs + staging + barrier
 }
 
 

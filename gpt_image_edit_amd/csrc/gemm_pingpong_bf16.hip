@@ -216,7 +216,10 @@ FK_DEV void mma16_block(f32x16_t& blk, const bf16x8_t& w0, const bf16x8_t& w1, c
 template <int EPI, int BN, class C>
 FK_DEV void store_tile(const f32x16_t (&acc)[C::NF][C::MF], const fk_gemm_args& p, char* smem, int m0, int n0,
                        int wm, int wn) {
-  const int tid = threadIdx.x;
+  int tid = threadIdx.x;
+  // gemm10 (the only 256-thread caller) may run this inside a per-CU tile loop around an asm statement that leaves 36 free
+  // VGPRs: an opaque copy keeps hipcc from hoisting the 32 per-lane row indices below out of that loop and spilling them
+  if constexpr (C::NTHREADS == 256) asm volatile("" : "+v"(tid));
   const int lane = tid & 63;
   using FM = FragMap<C::M16>;
   // bias of this lane's 4-column quads (all loads in flight before the barrier below)
@@ -741,6 +744,13 @@ struct Cfg10 {
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
+// v64 .. v255 as clobber strings (staging and fragment registers of gemm10_loop.inc)
+#define G10_V4(a) "v" #a "0", "v" #a "1", "v" #a "2", "v" #a "3"
+#define G10_V10(a) "v" #a "0", "v" #a "1", "v" #a "2", "v" #a "3", "v" #a "4", "v" #a "5", "v" #a "6", "v" #a "7", "v" #a "8", "v" #a "9"
+#define G10_CLOBBER_V64_255 \
+  "v64", "v65", "v66", "v67", "v68", "v69", G10_V10(7), G10_V10(8), G10_V10(9), G10_V10(10), G10_V10(11), G10_V10(12), G10_V10(13), \
+  G10_V10(14), G10_V10(15), G10_V10(16), G10_V10(17), G10_V10(18), G10_V10(19), G10_V10(20), G10_V10(21), G10_V10(22), G10_V10(23), \
+  G10_V10(24), "v250", "v251", "v252", "v253", "v254", "v255"
 #define G10_OPERANDS \
       : "={a[0:15]}"(acc[0][0]), "={a[16:31]}"(acc[0][1]), "={a[32:47]}"(acc[0][2]), "={a[48:63]}"(acc[0][3]), \
         "={a[64:79]}"(acc[1][0]), "={a[80:95]}"(acc[1][1]), "={a[96:111]}"(acc[1][2]), "={a[112:127]}"(acc[1][3]), \
@@ -748,12 +758,28 @@ typedef int i32x4_t __attribute__((ext_vector_type(4)));
         "={a[192:207]}"(acc[3][0]), "={a[208:223]}"(acc[3][1]), "={a[224:239]}"(acc[3][2]), "={a[240:255]}"(acc[3][3]) \
       : "{v[16:23]}"(a_voff), "{v[24:31]}"(w_voff), "{v[32:39]}"(rd), "{v[40:43]}"(wr), "{s[40:43]}"(od_a.w), "{s[44:47]}"(od_w.w), \
         "{s48}"(k0), "{s49}"(nks), "{s50}"(kmax) \
-      : "memory", "scc", "s52", "s53", "s54", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+      : "memory", "scc", "s52", "s53", "s54", G10_CLOBBER_V64_255
+
+#define G10_OPERANDS_X \
+      : "={a[0:15]}"(acc[0][0]), "={a[16:31]}"(acc[0][1]), "={a[32:47]}"(acc[0][2]), "={a[48:63]}"(acc[0][3]), \
+        "={a[64:79]}"(acc[1][0]), "={a[80:95]}"(acc[1][1]), "={a[96:111]}"(acc[1][2]), "={a[112:127]}"(acc[1][3]), \
+        "={a[128:143]}"(acc[2][0]), "={a[144:159]}"(acc[2][1]), "={a[160:175]}"(acc[2][2]), "={a[176:191]}"(acc[2][3]), \
+        "={a[192:207]}"(acc[3][0]), "={a[208:223]}"(acc[3][1]), "={a[224:239]}"(acc[3][2]), "={a[240:255]}"(acc[3][3]), "={s[56:57]}"(t0), "={s[58:59]}"(t1), "={s[60:61]}"(ta) \
+      : "{v[16:23]}"(a_voff), "{v[24:31]}"(w_voff), "{v[32:39]}"(rd), "{v[40:43]}"(wr), "{s[40:43]}"(od_a.w), "{s[44:47]}"(od_w.w), \
+        "{s48}"(k0), "{s49}"(nks), "{s50}"(kmax) \
+      : "memory", "scc", "s52", "s53", "s54", G10_CLOBBER_V64_255
 
 template <int EPI, int V = 0>
 FK_DEV void gemm10_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, int kt_first, int nk) {
   using C = Cfg10;
-  const int tid = threadIdx.x;
+#ifdef FK_G10_EXPERIMENTS
+  const unsigned long long g10_real0 = __builtin_amdgcn_s_memrealtime(), g10_cyc0 = __builtin_amdgcn_s_memtime();
+#endif
+  // the lane's addresses are derived from an opaque copy of threadIdx.x: inside the persistent grid's tile loop hipcc would
+  // otherwise hoist all of them out of the loop, where they live across the asm statement -- which leaves it 36 free VGPRs --
+  // and spill (228 bytes of scratch, twice the epilogue's instructions: measured 35-50 k cycles per epilogue instead of 9.5 k)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -808,37 +834,93 @@ FK_DEV void gemm10_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0,
         G10_OPERANDS);
   }
 #ifdef FK_G10_EXPERIMENTS
-  else if constexpr (V == 1) { asm volatile(
+  unsigned long long t0 = 0, t1 = 0, ta = 0;
+  (void)t0; (void)t1; (void)ta;
+  if constexpr (V == 1) { asm volatile(
 #include "gemm10_loop_x1.inc"
-        G10_OPERANDS); }
+        G10_OPERANDS_X); }
   else if constexpr (V == 2) { asm volatile(
 #include "gemm10_loop_x2.inc"
-        G10_OPERANDS); }
+        G10_OPERANDS_X); }
   else if constexpr (V == 3) { asm volatile(
 #include "gemm10_loop_x3.inc"
-        G10_OPERANDS); }
+        G10_OPERANDS_X); }
   else if constexpr (V == 4) { asm volatile(
 #include "gemm10_loop_x4.inc"
-        G10_OPERANDS); }
+        G10_OPERANDS_X); }
   else if constexpr (V == 5) { asm volatile(
 #include "gemm10_loop_x5.inc"
-        G10_OPERANDS); }
+        G10_OPERANDS_X); }
   else if constexpr (V == 6) { asm volatile(
 #include "gemm10_loop_x6.inc"
-        G10_OPERANDS); }
+        G10_OPERANDS_X); }
   else if constexpr (V == 7) { asm volatile(
 #include "gemm10_loop_x7.inc"
-        G10_OPERANDS); }
+        G10_OPERANDS_X); }
+  else if constexpr (V == 8) { asm volatile(
+#include "gemm10_loop_x8.inc"
+        G10_OPERANDS_X); }
+  else if constexpr (V == 9) { asm volatile(
+#include "gemm10_loop_x9.inc"
+        G10_OPERANDS_X); }
+  else if constexpr (V == 10) { asm volatile(
+#include "gemm10_loop_x10.inc"
+        G10_OPERANDS_X); }
+  else if constexpr (V == 11) { asm volatile(
+#include "gemm10_loop_x11.inc"
+        G10_OPERANDS_X); }
+  else if constexpr (V == 12) { asm volatile(
+#include "gemm10_loop_x12.inc"
+        G10_OPERANDS_X); }
+  else if constexpr (V == 13) { asm volatile(
+#include "gemm10_loop_x13.inc"
+        G10_OPERANDS_X); }
+  else if constexpr (V == 14) { asm volatile(
+#include "gemm10_loop_x14.inc"
+        G10_OPERANDS_X); }
+  else if constexpr (V == 15) { asm volatile(
+#include "gemm10_loop_x15.inc"
+        G10_OPERANDS_X); }
+  else if constexpr (V == 16) { asm volatile(
+#include "gemm10_loop_x16.inc"
+        G10_OPERANDS_X); }
 #endif
   store_tile<EPI, 256, C>(acc, p, smem, m0, n0, wm, wn);
+#ifdef FK_G10_EXPERIMENTS
+  if constexpr (V > 0) {   // per workgroup, behind C: where it ran, when (wall clock), and wave 0's shader-cycle stamps of kernel entry,
+    if (tid == 0) {        // asm statement entry, loop start, loop end (s_memtime inside the statement) and its own last store issued
+      unsigned long long* rec = (unsigned long long*)((bf16_t*)p.C + (int64_t)p.M * p.c.ld) + (size_t)blockIdx.x * 8;   // behind C's last row
+      rec[0] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);  // HW_ID, XCC_ID
+      rec[1] = g10_real0; rec[2] = __builtin_amdgcn_s_memrealtime();
+      rec[3] = g10_cyc0; rec[4] = t0; rec[5] = t1; rec[6] = __builtin_amdgcn_s_memtime();
+      rec[7] = ta;
+    }
+  }
+#endif
 }
 
-template <int EPI, int V = 0>
+template <int EPI, int V = 0, bool PERSIST = false>
 __global__ __launch_bounds__(256, 1) void gemm10_kernel(const GroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int pi, m0, n0;
-  select_tile<256>(ga, xcd_chunk_index(), pi, m0, n0);
-  gemm10_body<EPI, V>(ga, smem, pi, m0, n0, 0, ga.p[0].K / Cfg10::BK);
+  const int nk = ga.p[0].K / Cfg10::BK;
+  if constexpr (PERSIST) {
+    // one workgroup per CU walks the tile list with stride gridDim: the 32 workgroups of an XCD work on 32 consecutive tiles
+    // of the grouped order in every round (what the dispatcher does with a plain grid), without the relaunch gap and with the
+    // kernel arguments warm in the scalar cache from the second tile on
+    const int total = ga.tiles_before[FK_MAX_GROUP];
+    for (int t = xcd_chunk_index(); t < total; t += gridDim.x) {
+      int pi, m0, n0;
+      select_tile<256>(ga, t, pi, m0, n0);
+      gemm10_body<EPI, V>(ga, smem, pi, m0, n0, 0, nk);
+      // every wave is done READING the C tile before the next tile's prologue refills the ring: an LDS-only barrier -- a
+      // __syncthreads() would also wait for this tile's global stores to drain (all CUs at once: measured 35-50 k cycles)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  } else {
+    int pi, m0, n0;
+    select_tile<256>(ga, xcd_chunk_index(), pi, m0, n0);
+    gemm10_body<EPI, V>(ga, smem, pi, m0, n0, 0, nk);
+  }
 }
 
 // ---- stream-K ranges (round 4) --------------------------------------------------------------------------------------------
@@ -909,14 +991,17 @@ int launch8_streamk(GroupArgs& ga, const fk_gemm_args* probs, int n, int grid, h
 }
 
 
+int cu_count();
 template <int EPI>
 int launch10(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream) {
   const int total = count_tiles<256>(ga, probs, n);
 #ifdef FK_G10_EXPERIMENTS
   if constexpr (EPI == FK_EPI_NONE) {   // measurement forms of the loop (gemm10_gen.py EXPERIMENTS): FK_G10_X=<n>
     static const int x = getenv("FK_G10_X") ? atoi(getenv("FK_G10_X")) : 0;
+    static const int persist = getenv("FK_G10_PERSIST") ? atoi(getenv("FK_G10_PERSIST")) : 0;
     void (*kx)(const GroupArgs) = nullptr;
-    switch (x) {
+    if (persist) kx = x == 1 ? gemm10_kernel<EPI, 1, true> : gemm10_kernel<EPI, 0, true>;
+    else switch (x) {
       case 1: kx = gemm10_kernel<EPI, 1>; break;
       case 2: kx = gemm10_kernel<EPI, 2>; break;
       case 3: kx = gemm10_kernel<EPI, 3>; break;
@@ -924,23 +1009,42 @@ int launch10(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream
       case 5: kx = gemm10_kernel<EPI, 5>; break;
       case 6: kx = gemm10_kernel<EPI, 6>; break;
       case 7: kx = gemm10_kernel<EPI, 7>; break;
+      case 8: kx = gemm10_kernel<EPI, 8>; break;
+      case 9: kx = gemm10_kernel<EPI, 9>; break;
+      case 10: kx = gemm10_kernel<EPI, 10>; break;
+      case 11: kx = gemm10_kernel<EPI, 11>; break;
+      case 12: kx = gemm10_kernel<EPI, 12>; break;
+      case 13: kx = gemm10_kernel<EPI, 13>; break;
+      case 14: kx = gemm10_kernel<EPI, 14>; break;
+      case 15: kx = gemm10_kernel<EPI, 15>; break;
+      case 16: kx = gemm10_kernel<EPI, 16>; break;
       default: break;
     }
     if (kx) {
       if (hipFuncSetAttribute((const void*)kx, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg10::SMEM_BYTES) != hipSuccess) return FK_EINVAL;
-      hipLaunchKernelGGL(kx, dim3(total), dim3(256), Cfg10::SMEM_BYTES, stream, ga);
+      hipLaunchKernelGGL(kx, dim3(persist ? (total < cu_count() ? total : cu_count()) : total), dim3(256), Cfg10::SMEM_BYTES, stream, ga);
       FK_CHECK_LAUNCH("fk_gemm_bf16 (gemm10 experiment)");
       return FK_OK;
     }
   }
 #endif
-  auto kern = gemm10_kernel<EPI>;
+  // a deep grid (>= 4 tiles per CU) runs as one workgroup per CU walking the tile list: no relaunch gap, kernel arguments warm
+  // from the second tile on (+2.5 % at 32768 x 3072 x 12288, profiles/r06_gemm10_persistent_ab_callH.txt); shallow grids keep
+  // the plain one, which lets the dispatcher balance the last round (-4 % at 480 tiles otherwise)
+  const int G = cu_count();
+  if (total >= 4 * G) {
+    auto kern = gemm10_kernel<EPI, 0, true>;
+    FK_ENSURE_MAX_LDS(kern, Cfg10::SMEM_BYTES, "fk_gemm_bf16 (256 x 256 tile, 4 waves, hand-placed loop, one workgroup per CU)");
+    hipLaunchKernelGGL(kern, dim3(G), dim3(256), Cfg10::SMEM_BYTES, stream, ga);
+    FK_CHECK_LAUNCH("fk_gemm_bf16 (256 x 256 tile, 4 waves, hand-placed loop, one workgroup per CU)");
+    return FK_OK;
+  }
+  auto kern = gemm10_kernel<EPI, 0, false>;
   FK_ENSURE_MAX_LDS(kern, Cfg10::SMEM_BYTES, "fk_gemm_bf16 (256 x 256 tile, 4 waves, hand-placed loop)");
   hipLaunchKernelGGL(kern, dim3(total), dim3(256), Cfg10::SMEM_BYTES, stream, ga);
   FK_CHECK_LAUNCH("fk_gemm_bf16 (256 x 256 tile, 4 waves, hand-placed loop)");
   return FK_OK;
 }
-
 
 // ---- the same two-group alternation on the 256 x 128 tile ---------------------------------------------------------
 // For grids whose 256 x 256 tiling leaves the last round of 256 CUs poorly filled (M = 2560: N = 3072, 9216).
@@ -1414,8 +1518,13 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int variant_hint, hipStrea
     ga.sk_partials = (float*)probs[0].splitk_ws;
     ga.sk_ctl = (unsigned*)((char*)probs[0].splitk_ws + (size_t)ws_slots * (BM * 256 * 4));
   }
-  report_variant(probs, plan.variant);
   const bool m16 = (ctl.mfma ? ctl.mfma : GEMM_MFMA_DEFAULT) == 16;
+  // the launch plan's pure 256 x 256 grid as gemm10_kernel where that kernel measures ahead of gemm8_kernel: long K (the
+  // per-tile prologue / epilogue of a one-wave-per-SIMD kernel is ~20 k cycles: 4 % of a K = 12288 tile, 15 % of a K = 3072
+  // one) and a grid deep enough for its one-workgroup-per-CU form; same bits either way (FK_GEMM10=0: never)
+  static const bool g10_auto = !(getenv("FK_GEMM10") && atoi(getenv("FK_GEMM10")) == 0);
+  if (plan.variant == 256 && variant_hint == 0 && m16 && g10_auto && K >= 6144 && t256 >= 4L * G) plan.variant = 1024;
+  report_variant(probs, plan.variant);
   int rc;
   switch (probs[0].out_fp32 == 2 ? FK_EPI_F32DBG : probs[0].epilogue) {
     case FK_EPI_F32DBG: rc = launch_variant<FK_EPI_F32DBG>(ga, probs, n, plan.variant, plan.big_cols, m16, stream); break;

@@ -683,3 +683,31 @@ def test_gemm10_batched_rows_gate_residual_and_grouped(ops):
         ops.gemm_set_mfma(0)
     for u, v in zip(outs[256], outs[1024]):
         assert torch.equal(u, v)
+
+
+def test_gemm10_one_workgroup_per_cu_form_and_the_plan_that_picks_it(ops):
+    """A grid of >= 4 tiles per CU runs gemm10 as one workgroup per CU walking the tile list (same tile code, an LDS-only barrier
+    between tiles), and the launch plan itself turns a pure 256 x 256 grid with K >= 6144 that deep into gemm10: both equal to
+    gemm8's result bit for bit."""
+    ops.gemm_set_mfma(16)
+    try:
+        a, w, bias = randn(8192, 128, seed=191).cuda(), randn(8192, 128, seed=192, scale=0.05).cuda(), randn(8192, seed=193, scale=0.1).cuda()
+        got = {}
+        for force in (256, 1024):           # 32 x 32 = 1024 tiles on 256 CUs: the walking form; K = 128: two K-tiles per tile
+            ops.gemm_set_variant(force)
+            got[force] = ops.gemm(a, w, bias, epilogue=ops.FK_EPI_SILU).clone()
+            assert ops.gemm_last_variant() == force
+        assert torch.equal(got[256], got[1024])
+        a, w = randn(16384, 6144, seed=194).cuda(), randn(4096, 6144, seed=195, scale=0.02).cuda()
+        ops.gemm_set_variant(0)
+        ops.gemm_set_plan(1)                 # batch-invariant plan: no split-K, so the choice is between the pure grids
+        auto = ops.gemm(a, w, None).clone()
+        assert ops.gemm_last_variant() == 1024, ops.gemm_last_variant()
+        ops.gemm_set_variant(256)
+        assert torch.equal(auto, ops.gemm(a, w, None))
+        ref = (a[:256].double() @ w.double().T).float()
+        assert_bf16_close("gemm10 via the plan 16384x4096x6144 (first 256 rows)", auto[:256], ref.to(BF), max_ulp=1, max_bad_frac=1e-4)
+    finally:
+        ops.gemm_set_variant(0)
+        ops.gemm_set_plan(3)
+        ops.gemm_set_mfma(0)

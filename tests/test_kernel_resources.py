@@ -79,6 +79,24 @@ def test_hot_kernels_keep_their_accumulators_in_registers(src, tmp_path):
             n_mfma = sum("v_mfma" in x for x in k_loop)
             assert n_mfma == (128 if "16x16x32" in "".join(k_loop) else 64)      # 32 x 32 x 16: 64 per two K-tiles; 16 x 16 x 32: 128
             assert not any("scratch_" in x for x in k_loop), f"{lines[a][:70]}: scratch traffic inside the K loop"
+        # gemm10_kernel: 512 registers per lane by design (one wave per SIMD, all 256 accumulators in the AGPR half, operands of
+        # the asm statement pinned); its K loop is the statement gemm10_loop.inc, which must arrive in the code object untouched:
+        # 3 tile bodies x 128 MFMAs, no compiler instruction inside, the hazard padding in front of the epilogue's first
+        # v_accvgpr_read, and at most a few dwords of scratch outside it (the opaque thread id of the per-CU tile loop)
+        g10 = [(name, int(scratch), int(vg)) for name, scratch, vg, _ in meta if "gemm10_kernel" in name]
+        assert len(g10) >= 16, f"expected plain + one-workgroup-per-CU instantiations of every epilogue, got {len(g10)}"
+        for name, scratch, vg in g10:
+            assert vg == 512 and scratch <= 32, f"{name}: {vg} registers, {scratch} B scratch"
+        for a in [i for i, l in enumerate(lines) if re.match(r"^_ZN12_GLOBAL__N_113gemm10_kernel\w+:", l)]:
+            e = next(i for i in range(a, len(lines)) if lines[i].startswith(".Lfunc_end"))
+            body = lines[a:e]
+            spans = [(i, next(j for j in range(i, len(body)) if "#ASMEND" in body[j])) for i, l in enumerate(body) if "#ASMSTART" in l]
+            lo, hi = max(spans, key=lambda ab: ab[1] - ab[0])
+            stmt = [l.strip() for l in body[lo + 1:hi] if l.strip()]
+            assert sum(l.startswith("v_mfma_f32_16x16x32_bf16") for l in stmt) == 384
+            assert sum(l.startswith("s_barrier") for l in stmt) == 4 and not any("scratch_" in l or "v_accvgpr" in l for l in stmt)
+            assert stmt[-2:] == ["s_nop 15", "s_nop 15"], "hazard padding between the last MFMA and the epilogue's accumulator reads"
+            assert not any("v_mfma" in l for l in body[:lo] + body[hi:]), "an MFMA outside the statement"
         # No instantiation's K loop may wait for ALL vector-memory requests: the loop's LDS-DMA prefetch is in flight there and
         # the kernels order their ring with counted waits.  hipcc inserts exactly that wait in front of an LDS read it cannot
         # prove disjoint from a builtin LDS-DMA request (the K-major forms' transpose reads, until round 5: 12-40 % of the kernel).
@@ -134,3 +152,13 @@ def test_attention_fwd4_hand_placed_hazards_and_steady_loop(tmp_path):
                 steady += 1
         assert chains >= 8, f"{tag}: only {chains} asm chains found"
     assert steady >= 2, "no clean 64-MFMA tile body found (AGPR copies, scratch or vmcnt(0) in every one)"
+
+
+def test_gemm10_loop_file_is_what_its_generator_writes():
+    """csrc/gemm10_loop.inc (the K loop of gemm10_kernel, one asm statement) is generated: the committed file must be the
+    generator's output, so that the schedule documented in gemm10_gen.py is the schedule that ships."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(CSRC, "gemm10_gen.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, "gemm10_loop.inc is stale: run `python gpt_image_edit_amd/csrc/gemm10_gen.py`"
+    text = open(os.path.join(CSRC, "gemm10_loop.inc")).read()
+    assert text.count("v_mfma_f32_16x16x32_bf16") == 384 and text.count("s_memtime") == 0

@@ -56,7 +56,7 @@ for (M, N, K) in shapes:
                 elif used[v] in (512, 640) or ref_v in (512, 640) or form_of(v)[1] != ref_m:
                     d = (ref.float() - out.float()).abs().max().item()
                     assert d <= 2 ** -7 * ref.float().abs().max().item(), f"split-K differs by {d} on {M}x{N}x{K}"
-                else:
+                elif os.environ.get("AB_NOCHECK") != "1":   # AB_NOCHECK=1: measurement forms whose results are wrong by construction
                     assert torch.equal(ref, out), f"variant {v} differs from variant 128 on {M}x{N}x{K}"
     ops.gemm_set_variant(0)
     ops.gemm_set_mfma(0)

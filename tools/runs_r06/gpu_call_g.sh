@@ -1,0 +1,10 @@
+# Round 6, call G: gemm10 with the one-latency prologue and the one-heavy-instruction-per-gap placement: parity, timeline, A/B.
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p gpurun_out
+( timeout 300 python -m pytest tests/test_hip_kernels.py -m gpu -q -k "gemm10" 2>&1 | tail -3 )
+for SH in "32768 3072 12288" "32768 12288 3072" "2560 12288 3072"; do
+  FK_G10_X=1 timeout 120 python tools/g10_cycles.py $SH 2>&1 | grep -v amdgpu.ids
+done > gpurun_out/r06g_gemm10_timeline.txt 2>&1
+cat gpurun_out/r06g_gemm10_timeline.txt
+( AB_SHAPES="32768x3072x12288,32768x12288x3072,32768x9216x3072,2560x12288x3072,8704x12288x3072,8704x9216x3072" AB_VARIANTS="256m16,1024m16,vendor" timeout 600 python tools/ab_gemm_variants.py 5 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r06g_gemm10_ab.txt 2>&1
+cat gpurun_out/r06g_gemm10_ab.txt
