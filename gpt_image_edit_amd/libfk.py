@@ -110,6 +110,7 @@ SIGNATURES = {
     "fk_adamw_step_scaled": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp] + [c_f32] * 7 + [c_i32, c_i64, c_vp]),
     "fk_euler_step_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "fk_transpose_bf16": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "fk_attention_hd512_bf16": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_f32, c_vp]),
     "fk_softmax_rows": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp]),
     "fk_softmax_rows_parts": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "fk_split_f32_rows": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),

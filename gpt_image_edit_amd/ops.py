@@ -438,6 +438,25 @@ def transpose(src, dst):
     return dst
 
 
+def attention_hd512(q, k, v, out=None, scale=None):
+    """Fused single-head attention with head dimension 512 (the VAE mid block): q, k, v bf16 [B, S, 512] views with a common
+    row / batch stride (column blocks of one fused projection), out [B, S, 512]; nothing of size S x S is allocated."""
+    _need_cuda(q, k, v, out)
+    B, S, C = q.shape
+    if C != 512 or k.shape != q.shape or v.shape != q.shape or q.dtype != BF16:
+        raise ValueError("attention_hd512 takes bf16 [B, S, 512] q, k, v")
+    if not (q.stride() == k.stride() == v.stride()) or q.stride(2) != 1:
+        raise ValueError("attention_hd512: q, k, v must share their strides (views of one projection buffer)")
+    if out is None:
+        out = torch.empty((B, S, C), device=q.device, dtype=BF16)
+    if out.stride(2) != 1:
+        raise ValueError("attention_hd512: out rows must be contiguous")
+    libfk.check(libfk.load().fk_attention_hd512_bf16(_ptr(q), _ptr(k), _ptr(v), q.stride(1), q.stride(0), _ptr(out), out.stride(1),
+                                                     out.stride(0), B, S, float(scale if scale is not None else C ** -0.5), _stream()),
+                "fk_attention_hd512_bf16")
+    return out
+
+
 def softmax_rows(x, out=None):
     """fp32 [rows, n] -> bf16 softmax rows."""
     _need_cuda(x)

@@ -26,6 +26,8 @@ from . import flux_spec, ops
 from .param_tree import ParamTreeMixin, build_param_tree
 
 HALO = os.environ.get("FK_VAE_HALO", "1") != "0"
+# the mid-block attention (1 head x 512) as one fused launch (csrc/vae_attention.hip); 0 = the three launches of rounds 1-5 (A/B)
+FUSED_MID_ATTENTION = os.environ.get("FK_VAE_FUSED_ATTN", "1") != "0"
 
 BF16 = torch.bfloat16
 
@@ -189,20 +191,30 @@ class HipAutoencoderKL(ParamTreeMixin, nn.Module):
         n = self._gn(p + "group_norm", x, False).view(B, S, C)
         wqkv, bqkv = self._packed()[p + "qkv"]
         qkv = ops.gemm(n, wqkv, bqkv)                               # [B, S, 3C]
-        o = torch.empty((B, S, C), device=x.device, dtype=BF16)
+        if C == 512 and FUSED_MID_ATTENTION:
+            # one fused launch for the whole batch (csrc/vae_attention.hip): no S x S scores, no probabilities, no V^T copy
+            o = ops.attention_hd512(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], scale=C ** -0.5)
+        else:
+            o = self._mid_attention_3launch(qkv, B, S, C)
+        xr = x.view(B, S, C)
+        out = ops.gemm(o, self.p(p + "to_out.0.weight"), self.p(p + "to_out.0.bias"), epilogue=ops.FK_EPI_RES, res=xr)
+        return out.view(B, H, W, C)
+
+    def _mid_attention_3launch(self, qkv, B, S, C):
+        """Rounds 1-5 (kept for head dimensions other than 512 -- the narrow test VAEs -- and as FK_VAE_FUSED_ATTN=0): per image
+        fp32 scores [S, S] on the GEMM kernel, a row softmax, P V on the GEMM kernel against a transposed copy of V."""
+        o = torch.empty((B, S, C), device=qkv.device, dtype=BF16)
         S_pad = (S + 63) // 64 * 64                                 # GEMM K granularity for P @ V
-        scores = torch.empty((S, S_pad), device=x.device, dtype=torch.float32)
-        probs = torch.zeros((S, S_pad), device=x.device, dtype=BF16)
-        vt = torch.zeros((1, C, S_pad), device=x.device, dtype=BF16)
+        scores = torch.empty((S, S_pad), device=qkv.device, dtype=torch.float32)
+        probs = torch.zeros((S, S_pad), device=qkv.device, dtype=BF16)
+        vt = torch.zeros((1, C, S_pad), device=qkv.device, dtype=BF16)
         for b in range(B):
             q, k, v = qkv[b, :, :C], qkv[b, :, C:2 * C], qkv[b, :, 2 * C:]
             ops.gemm(q, k, None, out=scores[:, :S], epilogue=ops.FK_EPI_SCALE, alpha=C ** -0.5, out_fp32=True)
             ops.softmax_rows(scores[:, :S], out=probs[:, :S])
             ops.transpose(v.unsqueeze(0), vt[:, :, :S])
             ops.gemm(probs, vt[0], None, out=o[b])
-        xr = x.view(B, S, C)
-        out = ops.gemm(o, self.p(p + "to_out.0.weight"), self.p(p + "to_out.0.bias"), epilogue=ops.FK_EPI_RES, res=xr)
-        return out.view(B, H, W, C)
+        return o
 
     def _mid(self, p, x):
         x = self._resnet(p + "resnets.0.", x)

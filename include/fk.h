@@ -388,6 +388,13 @@ int fk_euler_step_bf16(void* x, int64_t x_batch_stride, const void* v, int64_t v
  * batched over `batch` with the given batch strides. */
 int fk_transpose_bf16(const void* src, int64_t lds, int64_t src_batch_stride, void* dst, int64_t ldd,
                       int64_t dst_batch_stride, int32_t R, int32_t C, int32_t batch, fk_stream_t stream);
+/* Single-head attention with head dimension 512, fused (flash-style: nothing of size S x S is stored): the mid-block attention
+ * of the FLUX AutoencoderKL (diffusers `Attention` in UNetMidBlock2D, heads = 1, dim_head = 512; reference call sites
+ * univa/utils/flux_pipeline.py:604-611 encode, :1127-1129 decode).  q, k, v: bf16 [B, S, >= 512] views with a common row
+ * stride ld_qkv (e.g. the three column blocks of one fused [B, S, 1536] projection), o: bf16 [B, S, 512] rows ld_o apart;
+ * strides in elements, ld_qkv % 8 == 0, ld_o % 4 == 0; any S >= 1.  o = softmax(scale q k^T) v with fp32 scores and sums. */
+int fk_attention_hd512_bf16(const void* q, const void* k, const void* v, int64_t ld_qkv, int64_t batch_stride_qkv, void* o,
+                            int64_t ld_o, int64_t batch_stride_o, int32_t B, int32_t S, float scale, fk_stream_t stream);
 /* y[r, :n] = bf16(softmax(x[r, :n])) with fp32 scores x (row strides ldx / ldy in elements), n % 4 == 0,
  * n <= 32768: the softmax of the VAE mid-block attention (scores kept in fp32 like a fused SDPA). */
 int fk_softmax_rows(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t n,

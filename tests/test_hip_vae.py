@@ -238,6 +238,78 @@ def test_vae_is_deterministic_at_ragged_sizes():
     assert all(torch.equal(im[0], t) for t in im[1:])
 
 
+@pytest.mark.parametrize("B,S", [(1, 48), (2, 100), (1, 1000), (3, 1024), (1, 4096)])
+def test_attention_hd512_matches_fp32_sdpa(B, S):
+    """The fused mid-block attention (1 head x 512; csrc/vae_attention.hip) against fp32 SDPA on the same bf16 inputs: ragged
+    key tiles (S % 32 != 0), a ragged last query block, a batch, spiked keys that move the running maximum mid-sequence;
+    q | k | v read in place from one fused [B, S, 1536] projection buffer; and against the three-launch path it replaces."""
+    _skip()
+    from gpt_image_edit_amd import ops
+    C = 512
+    qkv = randn(B, S, 3 * C, seed=40 + S)
+    if S >= 100:
+        qkv[:, 70, C:2 * C] = qkv[:, 5, :C] * 1.5          # key 70 aligned with query 5, key S-3 with query 33
+        qkv[:, S - 3, C:2 * C] = qkv[:, 33, :C] * 2.0
+    d = qkv.cuda()
+    got = ops.attention_hd512(d[:, :, :C], d[:, :, C:2 * C], d[:, :, 2 * C:])
+    torch.cuda.synchronize()
+    q, k, v = (qkv[:, :, i * C:(i + 1) * C].float() for i in range(3))
+    ref = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
+    dd = report(f"attention_hd512 B{B} S{S}", got, ref)
+    scale = ref.abs().max().item()
+    # P rounded to bf16 before P V, O rounded to bf16 at the end (2^-9 relative each): the bounds of the MMDiT attention test
+    assert dd.max().item() <= 1e-2 * scale and dd.mean().item() <= 1e-3 * scale
+    # the path of rounds 1-5 (fp32 scores [S, S], row softmax, P V on the GEMM kernel) rounds the NORMALISED probabilities: same
+    # accuracy class, different last bits
+    from gpt_image_edit_amd.vae import HipAutoencoderKL
+    old = HipAutoencoderKL._mid_attention_3launch(None, d, B, S, C)
+    d_old = report(f"attention_hd512 vs the three-launch path B{B} S{S}", got, old)
+    assert d_old.max().item() <= 1.5e-2 * scale
+    # output rows wider than 512 (a strided destination) and determinism
+    wide = torch.zeros(B, S, C + 8, device="cuda", dtype=BF)
+    ops.attention_hd512(d[:, :, :C], d[:, :, C:2 * C], d[:, :, 2 * C:], out=wide[:, :, :C])
+    assert torch.equal(wide[:, :, :C], got) and wide[:, :, C:].abs().max().item() == 0
+
+
+def test_vae_decode_512sq_allocates_nothing_of_size_S_squared():
+    """decode() of a 512^2 image (S = 4096 latent pixels) with the fused mid-block attention: the peak of newly allocated
+    memory stays far below the 64 MiB + 32 MiB of scores / probabilities the three-launch path takes at this size (1.5 GiB at
+    1024^2) -- and equals the three-launch result to the attention test's accuracy."""
+    _skip()
+    from gpt_image_edit_amd import vae as hv
+    vae = hv.HipAutoencoderKL(device="cuda", init="synthetic", seed=21)
+    z = randn(1, 16, 64, 64, seed=12).cuda()
+    assert hv.FUSED_MID_ATTENTION
+    vae.decode(z, return_dict=False)                     # packs the weights, sizes the workspaces
+    mids = []
+    orig = hv.HipAutoencoderKL._mid_attention
+
+    def spy(self, p, x):
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        out = orig(self, p, x)
+        torch.cuda.synchronize()
+        mids.append(torch.cuda.max_memory_allocated() - base)
+        return out
+    hv.HipAutoencoderKL._mid_attention = spy
+    try:
+        img = vae.decode(z, return_dict=False)[0].clone()
+        fused_peak = mids[-1]
+        hv.FUSED_MID_ATTENTION = False
+        img3 = vae.decode(z, return_dict=False)[0].clone()
+        old_peak = mids[-1]
+    finally:
+        hv.HipAutoencoderKL._mid_attention = orig
+        hv.FUSED_MID_ATTENTION = True
+    S, C = 4096, 512
+    print(f"[parity] mid-block attention at S = {S}: peak new bytes fused {fused_peak / 2**20:.1f} MiB, three launches {old_peak / 2**20:.1f} MiB")
+    assert fused_peak <= 6 * S * C * 2 + (4 << 20), fused_peak          # n, qkv (3x), o, out: a handful of [S, 512] bf16 tensors
+    assert old_peak >= S * S * 4
+    d = report("vae.decode 512^2 fused vs three-launch mid attention", img, img3)
+    assert d.max().item() <= 2e-2 * img3.float().abs().max().item()
+
+
 # ---- fp32-class encoder (train_denoiser.py:458,887-918: the reference encodes with an fp32 VAE) -----------------------
 def test_fp32_class_kernels():
     """split / GroupNorm / softmax parts and the fp32-output convolution, each against fp32 torch."""
