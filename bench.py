@@ -206,6 +206,18 @@ def roofline_of(fam, workload):
                           for k, v in fam.items() if k != "gemm"},
         "traffic_source": os.path.relpath(TRAFFIC_FILE, ROOT) + " (committed PMC passes, largest launch class; not counted in this run)",
     }
+    # ACHIEVED bytes per second from the counters (committed PMC passes: FETCH_SIZE + WRITE_SIZE per launch over the profiled
+    # duration; beyond the XCD L2s, Infinity-Cache hits included) beside the algorithmic figure of this run
+    try:
+        tr = json.load(open(TRAFFIC_FILE))
+        counted = {"attention": [v for k, v in tr.get("attention", {}).items()], "conv": [v for k, v in tr.get("vae", {}).items()]}
+        for fam_name, ents in counted.items():
+            if ents and fam_name in rl["other_kernels"]:
+                e = max(ents, key=lambda v: v["hbm_bytes_per_launch"])
+                rl["other_kernels"][fam_name].update(hbm_gbps_counted=round(e["gbps_counted"], 1), counted_x_algorithmic=round(e["ratio"], 2),
+                                                     frac_of_hbm_peak_counted=round(e["gbps_counted"] / PEAK_HBM_GBPS, 4))
+    except Exception:
+        pass
     if traffic_note:      # the side file's note names the kernel and the calibration: its first sentence is enough in the line
         rl["traffic_note"] = traffic_note.split(": FETCH_SIZE")[0][:160] + " (counted beyond the XCD L2s; Infinity-Cache hits included: upper bound of HBM bytes)"
     if traffic_classes:   # counted bytes beyond the XCD L2s per launch of EVERY GEMM launch class of the workload

@@ -24,6 +24,7 @@ Token reductions are fixed-order two-stage sums and the attention backward uses 
 from run to run.  Weight gradients are bf16 (what autograd produces for bf16 parameters); bias, norm-weight and
 modulation reductions stay fp32 (``fk_adamw_step`` takes either).
 """
+import ctypes
 import os
 from types import SimpleNamespace
 
@@ -41,6 +42,10 @@ BF16 = torch.bfloat16
 # (fk_common.h, buffer_lds_opaque) they match it, and level 2 is the fastest step: 492 (level 1, before) -> 481 (level 1) ->
 # 470 ms (level 2) on one box (profiles/r05_train_step_kmajor.txt, profiles/r05_gemm_kmajor_opaque_dma_ab.txt).
 K_MAJOR = int(os.environ.get("FK_BWD_K_MAJOR", "2"))
+# Block-level C entry points of the backward (fk_single_block_bwd / fk_double_block_bwd, csrc/blocks_bwd.hip): one ctypes call
+# per block instead of one per launch (~80 per double block), where the stage-2 shape allows -- stored activations, batch 1,
+# token counts that are multiples of 64, FK_BWD_K_MAJOR = 2; bit-identical to the per-launch route (0 selects it everywhere).
+BLOCK_API = int(os.environ.get("FK_BWD_BLOCK_API", "1"))
 
 
 def _pad64(n):
@@ -326,19 +331,26 @@ class FluxBackward:
                 sink(bg)
             if keep or sink is None:
                 grads.update(bg)
+        cb = self._c_backward_ctx(sv, g) if BLOCK_API else None     # None: this pass takes the per-launch route
         for j in reversed(range(ns)):
             if not sv.store:
                 s.copy_(sv.ckpt[nd + j])
                 self._single_forward(j, sv, s, save=True)
             bg = {}
-            self._single_backward(j, sv, g, bg)
+            if cb is not None:
+                self._single_backward_c(j, sv, cb, bg)
+            else:
+                self._single_backward(j, sv, g, bg)
             emit(bg)
         for i in reversed(range(nd)):
             if not sv.store:
                 s.copy_(sv.ckpt[i])
                 self._double_forward(i, sv, s, save=True)
             bg = {}
-            self._double_backward(i, sv, g, bg)
+            if cb is not None:
+                self._double_backward_c(i, sv, cb, bg)
+            else:
+                self._double_backward(i, sv, g, bg)
             emit(bg)
         d_enc = ops.gemm(g[:, :S_txt], **self.dW("context_embedder.weight"))
         self._saved = None
@@ -430,17 +442,141 @@ class FluxBackward:
         B, n = dmod.shape
         D = act.shape[1]
         dT = self._b(f"dmodT{n}", (n, 64))
+        aT, ones = self._mod_operands(B, act)
+        ops.f32_to_bf16_transposed(dmod, dT)
+        return ops.gemm(dT, aT), ops.gemm(dT, ones)[:, 0]      # fresh tensors; the bias gradient is a strided column view
+
+    def _mod_operands(self, B, act):
+        """silu(temb)^T [D, 64] and the ones matrix [64, 64] (first B columns) of the AdaLN weight-gradient GEMMs: the same for
+        all 57 blocks of a step, made once per backward()."""
+        D = act.shape[1]
         aT = self._b("actT", (D, 64), zero=True)
         ones = self._b("onesT", (64, 64), zero=True)
         if self.__dict__.get("_mod_ready") != (B, id(self._saved)):
-            # silu(temb)^T and the ones matrix are the same for all 57 blocks of a step: made once per backward()
             ones.zero_()
             ones[:, :B] = 1.0
             aT.zero_()
             ops.transpose(act.unsqueeze(0), torch.as_strided(aT, (1, D, B), (0, 64, 1)))
             self.__dict__["_mod_ready"] = (B, id(self._saved))
-        ops.f32_to_bf16_transposed(dmod, dT)
-        return ops.gemm(dT, aT), ops.gemm(dT, ones)[:, 0]      # fresh tensors; the bias gradient is a strided column view
+        return aT, ones
+
+    # ---- the same two block backwards through the C entry points (csrc/blocks_bwd.hip): one call per block -------------------
+    def _c_backward_ctx(self, sv, g):
+        """fk_bwd_ws of this pass, or None when the pass does not fit the entry points' scope (then: the per-launch route)."""
+        m, ws, pk = self.m, sv.ws, sv.pk
+        D, H, B, S = m.inner_dim, m.num_heads, sv.B, sv.S
+        if not (K_MAJOR >= 2 and sv.store and B == 1 and sv.S_txt % 64 == 0 and sv.S_img % 64 == 0 and D % 256 == 0):
+            return None
+        st = m._block_weight_structs(pk)
+        for blk in list(pk.double) + list(pk.single):      # stored weights as the K-major GEMM forms take them: contiguous rows
+            for w in (blk.wqkv_img, blk.wqkv_txt) if hasattr(blk, "wqkv_img") else (blk.wqkv,):
+                if not (w.stride(1) == 1 and w.stride(0) == w.shape[1]):
+                    return None
+        from . import libfk
+        b, f32 = self._b, torch.float32
+        c = libfk.BwdWs()
+        c.B, c.S_txt, c.S_img, c.H, c.eps = B, sv.S_txt, sv.S_img, H, 1e-6
+        bufs = dict(g=g, dy=b("dy", (B, S, D)), dff=b("dff", (B, S, 4 * D)), dn=b("dn", (B, S, D)), d_o=b("do", (B, S, D)),
+                    dqkv=b("dqkv", (B, S, 3 * D)), dq=b("dq", (B, H, S, 128)), dk=b("dk", (B, H, S, 128)),
+                    dsum=b("dsum", (B, H, S), f32), dmod=b("dmod_d", (B, 12 * D), f32, zero=True), ff=ws.ff, cat=ws.cat,
+                    cos=sv.cos, sin=sv.sin, red_ws=ops.bwd_workspace(g.device), attn_ws=ops.attention_workspace(g.device),
+                    mod=ws.mod, dmodT=b("dmodT_c", (6 * D, 64)))
+        bufs["actT"], bufs["onesT"] = self._mod_operands(B, ws.act)
+        for k, t in bufs.items():
+            setattr(c, k, t.data_ptr())
+        c.attn_ws_bytes, c.mod_batch_stride = bufs["attn_ws"].numel(), ws.mod.stride(0)
+        L = ops.LAUNCH
+        c.gemm_variant, c.gemm_plan, c.gemm_group_m, c.gemm_mfma = L.gemm_variant, L.gemm_plan, L.gemm_group_m, L.gemm_mfma
+        c.attn_grid, c.attn_passes = L.attn_grid, L.attn_bwd_passes
+        c.gemm_variant_used = ctypes.pointer(ops._variant_slot())
+        return SimpleNamespace(c=c, st=st, bufs=bufs, lib=libfk.load(), stream=ctypes.c_void_p(torch.cuda.current_stream().cuda_stream),
+                               saved=libfk.BlockSaved, dev=g.device)
+
+    def _saved_struct(self, cb, sv, idx, bb, double):
+        sb = cb.saved()
+        sb.x0, sb.n1, sb.qkv, sb.q, sb.k = sv.ckpt[idx].data_ptr(), bb.n.data_ptr(), bb.qkv.data_ptr(), bb.q.data_ptr(), bb.k.data_ptr()
+        sb.y1, sb.h1, sb.o, sb.lse = bb.y1.data_ptr(), bb.h1.data_ptr(), sv.o_ckpt[idx].data_ptr(), sv.lse_ckpt[idx].data_ptr()
+        if double:
+            sb.x1, sb.n2, sb.y2 = bb.x1.data_ptr(), bb.n2.data_ptr(), bb.y2.data_ptr()
+        return sb
+
+    def _single_backward_c(self, j, sv, cb, grads):
+        from . import libfk
+        D, T, dev = self.m.inner_dim, self.trainable, cb.dev
+        p = f"single_transformer_blocks.{j}."
+        idx = len(sv.pk.double) + j
+        bb = self._block_bufs(sv, idx, False)
+        e = lambda *shape, dtype=BF16: torch.empty(shape, device=dev, dtype=dtype)  # noqa: E731
+        out = {"dnorm": e(2, 2, 128, dtype=torch.float32)}          # fresh tensors, as the per-launch route hands out
+        if p + "attn.to_q.weight" in T:
+            out["dwqkv"], out["dbqkv"] = e(3 * D, D), e(3 * D, dtype=torch.float32)
+        if p + "proj_mlp.weight" in T:
+            out["dw_mlp"], out["db_mlp"] = e(4 * D, D), e(4 * D, dtype=torch.float32)
+        if p + "proj_out.weight" in T:
+            out["dw_out"], out["db_out"] = e(D, 5 * D), e(D, dtype=torch.float32)
+        if p + "norm.linear.weight" in T:
+            out["dw_mod"], out["db_mod"] = e(3 * D, D), e(3 * D, 64)
+        gs = libfk.SingleBlockGrads()
+        for k, t in out.items():
+            setattr(gs, k, t.data_ptr())
+        sb = self._saved_struct(cb, sv, idx, bb, False)
+        libfk.check(cb.lib.fk_single_block_bwd(ctypes.byref(cb.c), ctypes.byref(sb), ctypes.byref(cb.st.sgl[j]), ctypes.byref(gs), cb.stream),
+                    "fk_single_block_bwd")
+        dw = out["dnorm"]
+        grads[p + "attn.norm_q.weight"], grads[p + "attn.norm_k.weight"] = dw[0, 0], dw[1, 0]
+        if "dwqkv" in out:
+            for k, nm in enumerate(("to_q", "to_k", "to_v")):
+                grads[p + f"attn.{nm}.weight"] = out["dwqkv"][k * D:(k + 1) * D]
+                grads[p + f"attn.{nm}.bias"] = out["dbqkv"][k * D:(k + 1) * D]
+        if "dw_mlp" in out:
+            grads[p + "proj_mlp.weight"], grads[p + "proj_mlp.bias"] = out["dw_mlp"], out["db_mlp"]
+        if "dw_out" in out:
+            grads[p + "proj_out.weight"], grads[p + "proj_out.bias"] = out["dw_out"], out["db_out"]
+        if "dw_mod" in out:
+            grads[p + "norm.linear.weight"], grads[p + "norm.linear.bias"] = out["dw_mod"], out["db_mod"][:, 0]
+
+    def _double_backward_c(self, i, sv, cb, grads):
+        from . import libfk
+        D, T, dev = self.m.inner_dim, self.trainable, cb.dev
+        p = f"transformer_blocks.{i}."
+        bb = self._block_bufs(sv, i, True)
+        f32 = torch.float32
+        e = lambda *shape, dtype=BF16: torch.empty(shape, device=dev, dtype=dtype)  # noqa: E731
+        out = {"dnorm": e(2, 2, 128, dtype=f32)}
+        pairs = {   # struct field stem -> (parameter stem, weight shape)
+            "qkv_img": ("attn.to_q", (3 * D, D)), "qkv_txt": ("attn.add_q_proj", (3 * D, D)),
+            "_out": ("attn.to_out.0", (D, D)), "_add_out": ("attn.to_add_out", (D, D)),
+            "_ff1": ("ff.net.0.proj", (4 * D, D)), "_ff1_ctx": ("ff_context.net.0.proj", (4 * D, D)),
+            "_ff2": ("ff.net.2", (D, 4 * D)), "_ff2_ctx": ("ff_context.net.2", (D, 4 * D)),
+        }
+        for stem, (name, shape) in pairs.items():
+            if p + name + ".weight" in T:
+                out["dw" + stem], out["db" + stem] = e(*shape), e(shape[0], dtype=f32)
+        if p + "norm1.linear.weight" in T:
+            out["dw_mod_img"], out["db_mod_img"] = e(6 * D, D), e(6 * D, 64)
+        if p + "norm1_context.linear.weight" in T:
+            out["dw_mod_txt"], out["db_mod_txt"] = e(6 * D, D), e(6 * D, 64)
+        gs = libfk.DoubleBlockGrads()
+        for k, t in out.items():
+            setattr(gs, k, t.data_ptr())
+        sb = self._saved_struct(cb, sv, i, bb, True)
+        libfk.check(cb.lib.fk_double_block_bwd(ctypes.byref(cb.c), ctypes.byref(sb), ctypes.byref(cb.st.dbl[i]), ctypes.byref(gs), cb.stream),
+                    "fk_double_block_bwd")
+        dw = out["dnorm"]
+        grads[p + "attn.norm_q.weight"], grads[p + "attn.norm_k.weight"] = dw[0, 0], dw[1, 0]
+        grads[p + "attn.norm_added_q.weight"], grads[p + "attn.norm_added_k.weight"] = dw[0, 1], dw[1, 1]
+        for stem, names in (("qkv_img", ("to_q", "to_k", "to_v")), ("qkv_txt", ("add_q_proj", "add_k_proj", "add_v_proj"))):
+            if "dw" + stem in out:
+                for k, nm in enumerate(names):
+                    grads[p + f"attn.{nm}.weight"] = out["dw" + stem][k * D:(k + 1) * D]
+                    grads[p + f"attn.{nm}.bias"] = out["db" + stem][k * D:(k + 1) * D]
+        for stem, (name, _) in pairs.items():
+            if stem.startswith("_") and "dw" + stem in out:
+                grads[p + name + ".weight"], grads[p + name + ".bias"] = out["dw" + stem], out["db" + stem]
+        if "dw_mod_img" in out:
+            grads[p + "norm1.linear.weight"], grads[p + "norm1.linear.bias"] = out["dw_mod_img"], out["db_mod_img"][:, 0]
+        if "dw_mod_txt" in out:
+            grads[p + "norm1_context.linear.weight"], grads[p + "norm1_context.linear.bias"] = out["dw_mod_txt"], out["db_mod_txt"][:, 0]
 
     def _single_backward(self, j, sv, g, grads):
         m, P, ws, pk = self.m, self.m.p, sv.ws, sv.pk

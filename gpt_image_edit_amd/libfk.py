@@ -58,6 +58,32 @@ class BlockWs(ctypes.Structure):          # fk_block_ws
         ("gemm_variant_used", ctypes.POINTER(c_i32))]
 
 
+class BwdWs(ctypes.Structure):            # fk_bwd_ws
+    _fields_ = [("B", c_i32), ("S_txt", c_i32), ("S_img", c_i32), ("H", c_i32), ("eps", c_f32), ("splitk_slots", c_i32)] + [
+        (n, c_vp) for n in ("g", "dy", "dff", "dn", "d_o", "dqkv", "dq", "dk", "dsum", "dmod", "ff", "cat", "cos", "sin", "red_ws", "attn_ws")] + [
+        ("attn_ws_bytes", c_i64), ("splitk_ws", c_vp), ("mod", c_vp), ("mod_batch_stride", c_i64), ("actT", c_vp), ("onesT", c_vp),
+        ("dmodT", c_vp), ("gemm_variant", c_i32), ("gemm_plan", c_i32), ("gemm_group_m", c_i32), ("gemm_mfma", c_i32), ("attn_grid", c_i32),
+        ("attn_passes", c_i32), ("gemm_variant_used", ctypes.POINTER(c_i32))]
+
+
+class BlockSaved(ctypes.Structure):       # fk_block_saved
+    _fields_ = [(n, c_vp) for n in ("x0", "n1", "qkv", "q", "k", "y1", "h1", "o", "lse", "x1", "n2", "y2")]
+
+
+SINGLE_GRAD_FIELDS = ("dwqkv", "dbqkv", "dw_mlp", "db_mlp", "dw_out", "db_out", "dnorm", "dw_mod", "db_mod")
+DOUBLE_GRAD_FIELDS = ("dwqkv_img", "dbqkv_img", "dwqkv_txt", "dbqkv_txt", "dw_out", "db_out", "dw_add_out", "db_add_out", "dw_ff1", "db_ff1",
+                      "dw_ff1_ctx", "db_ff1_ctx", "dw_ff2", "db_ff2", "dw_ff2_ctx", "db_ff2_ctx", "dnorm", "dw_mod_img", "db_mod_img",
+                      "dw_mod_txt", "db_mod_txt")
+
+
+class SingleBlockGrads(ctypes.Structure):  # fk_single_block_grads
+    _fields_ = [(n, c_vp) for n in SINGLE_GRAD_FIELDS]
+
+
+class DoubleBlockGrads(ctypes.Structure):  # fk_double_block_grads
+    _fields_ = [(n, c_vp) for n in DOUBLE_GRAD_FIELDS]
+
+
 DOUBLE_BLOCK_FIELDS = ("wqkv_img", "bqkv_img", "wqkv_txt", "bqkv_txt", "norm_q", "norm_k", "norm_added_q", "norm_added_k",
                        "w_out", "b_out", "w_add_out", "b_add_out", "w_ff1", "b_ff1", "w_ff1_ctx", "b_ff1_ctx",
                        "w_ff2", "b_ff2", "w_ff2_ctx", "b_ff2_ctx")
@@ -131,6 +157,10 @@ SIGNATURES = {
     "fk_image_to_u8_nhwc": (c_i32, [c_vp, c_i32, c_vp] + [c_i32] * 4 + [c_vp]),
     "fk_double_block_fwd": (c_i32, [ctypes.POINTER(BlockWs), ctypes.POINTER(DoubleBlockWeights), c_vp, c_i64, c_vp]),
     "fk_single_block_fwd": (c_i32, [ctypes.POINTER(BlockWs), ctypes.POINTER(SingleBlockWeights), c_vp, c_i64, c_vp]),
+    "fk_single_block_bwd": (c_i32, [ctypes.POINTER(BwdWs), ctypes.POINTER(BlockSaved), ctypes.POINTER(SingleBlockWeights),
+                                    ctypes.POINTER(SingleBlockGrads), c_vp]),
+    "fk_double_block_bwd": (c_i32, [ctypes.POINTER(BwdWs), ctypes.POINTER(BlockSaved), ctypes.POINTER(DoubleBlockWeights),
+                                    ctypes.POINTER(DoubleBlockGrads), c_vp]),
     "fk_mmdit_blocks_fwd": (c_i32, [ctypes.POINTER(BlockWs), ctypes.POINTER(DoubleBlockWeights), c_i32,
                                     ctypes.POINTER(SingleBlockWeights), c_i32, c_vp, c_i64, c_vp]),
     "fk_last_error": (ctypes.c_char_p, []),

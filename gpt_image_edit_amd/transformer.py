@@ -506,11 +506,11 @@ class HipFluxTransformer2DModel(ParamTreeMixin, nn.Module):
                      epilogue=ops.FK_EPI_GATE_RES, res=s, gate=chunk(m0, 2))
 
 
-    def _blocks_by_c_entry(self, ws, pk, mod, cs, B, S_txt, S_img, api):
-        """The same launches through the block-level C entry points: argument structs built once per (weights, workspace)
-        and re-used; per forward only the modulation pointer changes."""
+    def _block_weight_structs(self, pk):
+        """fk_double_block_weights / fk_single_block_weights of every block (arrays, built once per set of weight pointers): shared
+        by the forward's and the backward's block-level entry points."""
         from . import libfk
-        lib, P, D = libfk.load(), self.p, self.inner_dim
+        P = self.p
         names_d = ("attn.norm_q.weight", "attn.norm_k.weight", "attn.norm_added_q.weight", "attn.norm_added_k.weight",
                    "attn.to_out.0.weight", "attn.to_out.0.bias", "attn.to_add_out.weight", "attn.to_add_out.bias",
                    "ff.net.0.proj.weight", "ff.net.0.proj.bias", "ff_context.net.0.proj.weight", "ff_context.net.0.proj.bias",
@@ -539,6 +539,14 @@ class HipFluxTransformer2DModel(ParamTreeMixin, nn.Module):
                 sgl[i].mod_off = blk.mod
             st = SimpleNamespace(ptrs=ptrs, dbl=dbl, sgl=sgl, nd=nd, ns=ns)
             self.__dict__["_block_structs"] = st
+        return st
+
+    def _blocks_by_c_entry(self, ws, pk, mod, cs, B, S_txt, S_img, api):
+        """The same launches through the block-level C entry points: argument structs built once per (weights, workspace)
+        and re-used; per forward only the modulation pointer changes."""
+        from . import libfk
+        lib = libfk.load()
+        st = self._block_weight_structs(pk)
         sk, slots = ops.splitk_workspace(ws.s.device)
         aw = ops.attention_workspace(ws.s.device)
         key = tuple(getattr(ws, f).data_ptr() for f in ("s", "n", "qkv", "q", "k", "o", "ff", "cat")) + (

@@ -317,6 +317,62 @@ int fk_colsum_bf16(const void* x, fk_rows xr, int64_t M, int32_t N, float* out, 
 int fk_rowdot_bf16(const void* a, int64_t a_ld, int64_t a_batch_stride, const void* c, int64_t c_ld,
                    int64_t c_batch_stride, float* out, int32_t B, int32_t S, int32_t H, fk_stream_t stream);
 
+/* Block-level entry points of the backward pass (the forward's: fk_double_block_fwd / fk_single_block_fwd above): ONE call
+ * enqueues the backward of a FluxTransformerBlock / FluxSingleTransformerBlock (diffusers 0.32.2), i.e. what autograd runs for
+ * the reference at `accelerator.backward(loss)` (train_denoiser.py:1172), from the activations the training forward stored.
+ * Host code only: the same per-kernel calls with the same arguments, in the same order, as the Python adaptor
+ * (gpt_image_edit_amd/backward.py) -- bit-identical results.  Data gradients read the stored weights (fk_gemm_args.layout 1),
+ * weight gradients both operands token-major (layout 2): B * S_txt and B * S_img must be multiples of 64.
+ * fk_bwd_ws = shapes, scratch shared by every block of a pass, launch controls; caller-owned, nothing is allocated. */
+typedef struct fk_bwd_ws {
+  int32_t B, S_txt, S_img, H;
+  float eps;                               /* LayerNorm / RMSNorm eps (1e-6) */
+  int32_t splitk_slots;
+  void* g;                                 /* bf16 [B, S, D]: gradient of the residual stream, IN (block output) / OUT (block input) */
+  void *dy, *dff, *dn, *d_o, *dqkv;        /* bf16 scratch [B,S,D], [B,S,4D], [B,S,D], [B,S,D], [B,S,3D] */
+  void *dq, *dk;                           /* bf16 scratch [B, H, S, 128] */
+  float* dsum;                             /* fp32 [B, H, S] */
+  float* dmod;                             /* fp32 [B, 12 D] (double block: image 6D | text 6D) / [B, 3 D] (single) */
+  void *ff, *cat;                          /* bf16 [B,S,4D] / [B,S,5D]: rebuilt GELU outputs (only when ff.net.2 / proj_out train) */
+  const float *cos, *sin;                  /* fp32 [S, 128] rotary tables */
+  float* red_ws;                           /* fk_bwd_ws_floats() */
+  void* attn_ws; int64_t attn_ws_bytes;    /* fk_attention_ws_bytes(), as the forward's */
+  void* splitk_ws;
+  const void* mod; int64_t mod_batch_stride;   /* bf16 modulation vectors of the step (all blocks), row stride in elements */
+  const void *actT, *onesT;                /* bf16 [D, 64] = silu(temb)^T zero-padded, [64, 64] ones in the first B columns */
+  void* dmodT;                             /* bf16 [6 D, 64] scratch */
+  int32_t gemm_variant, gemm_plan, gemm_group_m, gemm_mfma, attn_grid, attn_passes;   /* as fk_gemm_args / fk_attention_bwd_ws_bf16 */
+  int32_t* gemm_variant_used;              /* OUT, optional */
+} fk_bwd_ws;
+typedef struct fk_block_saved {            /* what the training forward kept of ONE block (bf16 unless said) */
+  const void *x0;                          /* [B,S,D] block input */
+  const void *n1, *qkv, *q, *k;            /* LN+modulate output, raw fused projection [B,S,3D], q / k after RMSNorm + RoPE [B,H,S,128] */
+  const void *y1, *h1, *o;                 /* pre-gate projection output [B,S,D], pre-GELU MLP hidden [B,S,4D], attention output */
+  const float* lse;                        /* fp32 [B, H, S] */
+  const void *x1, *n2, *y2;                /* double blocks only: stream after attention, second LN+modulate, pre-gate MLP output */
+} fk_block_saved;
+/* Gradient outputs: bf16 [N, K] weights as stored, fp32 [N] biases, fp32 [2 (q, k)][2 (image, text)][128] RMSNorm weights (always
+ * written), AdaLN linear as bf16 [n, D] + bf16 [n, 64] whose COLUMN 0 is the bias gradient.  NULL weight pointer = frozen. */
+typedef struct fk_single_block_grads {
+  void* dwqkv; float* dbqkv;               /* attn.to_{q,k,v} fused [3D, D] / [3D] */
+  void* dw_mlp; float* db_mlp;             /* proj_mlp [4D, D] */
+  void* dw_out; float* db_out;             /* proj_out [D, 5D] */
+  float* dnorm;
+  void *dw_mod, *db_mod;                   /* norm.linear [3D, D] / [3D, 64] */
+} fk_single_block_grads;
+typedef struct fk_double_block_grads {
+  void* dwqkv_img; float* dbqkv_img; void* dwqkv_txt; float* dbqkv_txt;
+  void* dw_out; float* db_out; void* dw_add_out; float* db_add_out;
+  void* dw_ff1; float* db_ff1; void* dw_ff1_ctx; float* db_ff1_ctx;       /* ff.net.0.proj / ff_context.net.0.proj [4D, D] */
+  void* dw_ff2; float* db_ff2; void* dw_ff2_ctx; float* db_ff2_ctx;       /* ff.net.2 / ff_context.net.2 [D, 4D] */
+  float* dnorm;
+  void *dw_mod_img, *db_mod_img, *dw_mod_txt, *db_mod_txt;                /* norm1.linear / norm1_context.linear [6D, D] / [6D, 64] */
+} fk_double_block_grads;
+int fk_single_block_bwd(const fk_bwd_ws* ws, const fk_block_saved* saved, const fk_single_block_weights* w,
+                        const fk_single_block_grads* grads, fk_stream_t stream);
+int fk_double_block_bwd(const fk_bwd_ws* ws, const fk_block_saved* saved, const fk_double_block_weights* w,
+                        const fk_double_block_grads* grads, fk_stream_t stream);
+
 /* Elementwise / tiny kernels ------------------------------------------------------------------ */
 /* y = bf16(silu(x)) over n elements (n % 8 == 0). */
 int fk_silu_bf16(const void* x, void* y, int64_t n, fk_stream_t stream);

@@ -111,7 +111,7 @@ def test_committed_traffic_side_file_matches_its_source(tmp_path):
     import shutil
     import subprocess
     import sys
-    stems = [s for s in ("r05_traffic", "r04_traffic", "r03_traffic", "r02_traffic") if os.path.exists(os.path.join(ROOT, "profiles", s + "_items.json"))]
+    stems = [s for s in ("r06_traffic", "r05_traffic", "r04_traffic", "r03_traffic", "r02_traffic") if os.path.exists(os.path.join(ROOT, "profiles", s + "_items.json"))]
     for stem in stems:          # the newest one is what bench.py reads
         shutil.copy(os.path.join(ROOT, "profiles", stem + "_items.json"), tmp_path / "t_items.json")
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "traffic_json.py"), str(tmp_path / "t")], check=True,

@@ -206,6 +206,59 @@ def test_k_major_operands_give_the_same_gradients(monkeypatch):
         ops.gemm_set_mfma(0)
 
 
+@pytest.mark.parametrize("which", ["image_branch", "everything", "sharded"])
+def test_block_level_backward_entry_points_give_the_same_bits(monkeypatch, which):
+    """fk_single_block_bwd / fk_double_block_bwd (csrc/blocks_bwd.hip: one C call per block) against the per-launch route of
+    backward.py: loss, d(prompt_embeds) and EVERY gradient bit for bit -- with the reference's trainable set, with every
+    parameter of the blocks trainable (text branch and MLPs: only_tune_image_branch false), and on the ZeRO-2 layout, where
+    the fused QKV operands are views of the flat parameter buffer.  The entry points must really be taken (counted)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gpt_image_edit_amd import backward, libfk, training
+    from gpt_image_edit_amd.train_step import DenoiserTrainStep
+    from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
+    cfg, sd_bf, batch, trainable = _setup(B=1, S_txt=64, h=32, w=32)
+    if which == "everything":
+        trainable = training.trainable_names(list(sd_bf.keys()), only_img_branch=False)
+    calls = {"single": 0, "double": 0}
+    lib = libfk.load()
+    res = {}
+    for api in (0, 1):
+        monkeypatch.setattr(backward, "BLOCK_API", api)
+        model = HipFluxTransformer2DModel(cfg, device="cuda")
+        model.load_state_dict(sd_bf)
+        ts = DenoiserTrainStep(model, lr=1e-3, trainable=trainable, sharded=which == "sharded", store_activations=True)
+        if api:
+            for kind in ("single", "double"):
+                orig = getattr(backward.FluxBackward, f"_{kind}_backward_c")
+
+                def counted(self, *a, _orig=orig, _kind=kind, **k):
+                    calls[_kind] += 1
+                    return _orig(self, *a, **k)
+                monkeypatch.setattr(backward.FluxBackward, f"_{kind}_backward_c", counted)
+        loss, grads, d_enc = ts.forward_backward(**{k: v.cuda() for k, v in batch.items()})
+        torch.cuda.synchronize()
+        res[api] = (loss.clone(), {k: v.clone() for k, v in grads.items()}, d_enc.clone())
+    assert calls == {"single": 1, "double": 1}, calls
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])
+    assert set(res[0][1]) == set(res[1][1]) and set(trainable) <= set(res[1][1])
+    for k in sorted(res[0][1]):
+        a, b = res[0][1][k], res[1][1][k]
+        assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b), f"{which}: {k}"
+    assert all(torch.isfinite(v.float()).all() and v.float().abs().max() > 0 for v in res[1][1].values())
+    # shapes outside the entry points' scope fall back to the per-launch route: batch 2, recomputation
+    monkeypatch.setattr(backward, "BLOCK_API", 1)
+    cfg2, sd2, batch2, tr2 = _setup(B=2, S_txt=64, h=16, w=16)
+    model = HipFluxTransformer2DModel(cfg2, device="cuda")
+    model.load_state_dict(sd2)
+    before = dict(calls)
+    DenoiserTrainStep(model, lr=1e-3).forward_backward(**{k: v.cuda() for k, v in batch2.items()})
+    model = HipFluxTransformer2DModel(cfg, device="cuda")
+    model.load_state_dict(sd_bf)
+    DenoiserTrainStep(model, lr=1e-3, store_activations=False).forward_backward(**{k: v.cuda() for k, v in batch.items()})
+    assert calls == before
+
+
 def test_sharded_gradient_accumulation_and_modified_gradient_error():
     """with sharded=True a second forward_backward before optimizer_step is a further micro-batch
     (the reference's gradient_accumulation_steps) -- its gradients are ADDED to the optimiser's chunks and the step uses

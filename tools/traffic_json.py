@@ -26,7 +26,7 @@ def main(stem):
     src = json.load(open(stem + "_items.json"))
     items = src["items"]
     out = {"source": "profiles/" + stem.split("/")[-1] + ".md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_traffic.sh)",
-           "gemm": {}, "attention": {}, "ln_modulate": {}}
+           "gemm": {}, "attention": {}, "ln_modulate": {}, "vae": {}}
     for wl, (prefix, what) in GEMM_OF.items():
         name = next((k for k in items if k.startswith(prefix)), None)
         if name is None:      # item left out of this round's passes (TRAFFIC_SKIP of tools/traffic_target.py)
@@ -51,7 +51,7 @@ def main(stem):
                                   avg_us_profiled=it["avg_us"], tflops=it["tflops"], kernel=it.get("kernel", ""))
         if wl in out["gemm"]:
             out["gemm"][wl]["classes"] = per
-    for fam in ("attention", "ln_modulate"):
+    for fam in ("attention", "ln_modulate", "vae"):
         for name, it in items.items():
             if name.startswith(fam):
                 b = it["hbm_read_bytes"] + it["hbm_write_bytes"]
