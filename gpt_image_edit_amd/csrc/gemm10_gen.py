@@ -112,6 +112,41 @@ def kstep(e, cfg, step, buf, zero_c, no_stage=False):
         fill[61].append("s_min_u32 s52, s52, s50")
         fill[63].append("s_add_u32 s53, s53, 128")
         fill[63].append("s_min_u32 s53, s53, s50")
+    if cfg.get("m32_probe"):
+        # MEASUREMENT ONLY (results wrong: the 32 x 32 x 16 MFMAs take the 16 x 16 x 32 fragments as they are): the first
+        # `m32_probe` of the 16 accumulator blocks run as 2 x v_mfma_f32_32x32x16_bf16 per k-step instead of 4 x 16x16x32 (same
+        # pipe time, ~20 cycles of issue shadow each instead of ~4), and every store / load sits behind one of them
+        heavy = [x for sl in sorted(fill) for x in fill[sl] if x.startswith(("ds_write", "buffer_load", "s_waitcnt vmcnt"))]
+        light = [x for sl in sorted(fill) for x in fill[sl] if not x.startswith(("ds_write", "buffer_load", "s_waitcnt vmcnt"))]
+        units = []          # heavy instructions grouped with their counted wait
+        for x in heavy:
+            if units and units[-1][-1].startswith("s_waitcnt vmcnt"):
+                units[-1].append(x)
+            else:
+                units.append([x])
+        for b in range(16):
+            nf, mf = b >> 2, b & 3
+            if b < cfg["m32_probe"]:
+                for half in range(2):
+                    c = 16 * b
+                    e(f"v_mfma_f32_32x32x16_bf16 {ar(c, 16)}, {vr(m_w + 4 * (2 * nf + half))}, {vr(m_a + 4 * (2 * mf + half))}, {'0' if zero_c and half == 0 else ar(c, 16)}")
+                    if units:
+                        for x in units.pop(0):
+                            e(x)
+            else:
+                for q in range(4):
+                    mfma(e, m_w, m_a, 2 * nf + (q >> 1), 2 * mf + (q & 1), zero_c)
+                    if light:
+                        e(light.pop(0))
+        for u in units:
+            for x in u:
+                e(x)
+        for x in light:
+            e(x)
+        e("s_waitcnt lgkmcnt(0)")
+        if step == 0 and "barrier" not in ab:
+            e("s_barrier")
+        return
     slot = 0
     for n in range(8):
         for m in range(8):
@@ -233,6 +268,9 @@ EXPERIMENTS = {
     15: dict(T, ablate=("stage",)),                              # MFMAs + reads + barrier
     16: dict(T, ablate=("reads",)),                              # MFMAs + staging + barrier
 }
+# what a part of the MFMAs in the 32 x 32 x 16 form would buy (issue shadow for the stores / loads) and cost (power): forms 17-20
+EXPERIMENTS.update({17: dict(T, m32_probe=4), 18: dict(T, m32_probe=8), 19: dict(T, m32_probe=16),
+                    20: dict(T, m32_probe=8, ablate=("stage",))})
 
 
 def main():

@@ -884,6 +884,18 @@ FK_DEV void gemm10_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0,
   else if constexpr (V == 16) { asm volatile(
 #include "gemm10_loop_x16.inc"
         G10_OPERANDS_X); }
+  else if constexpr (V == 17) { asm volatile(
+#include "gemm10_loop_x17.inc"
+        G10_OPERANDS_X); }
+  else if constexpr (V == 18) { asm volatile(
+#include "gemm10_loop_x18.inc"
+        G10_OPERANDS_X); }
+  else if constexpr (V == 19) { asm volatile(
+#include "gemm10_loop_x19.inc"
+        G10_OPERANDS_X); }
+  else if constexpr (V == 20) { asm volatile(
+#include "gemm10_loop_x20.inc"
+        G10_OPERANDS_X); }
 #endif
   store_tile<EPI, 256, C>(acc, p, smem, m0, n0, wm, wn);
 #ifdef FK_G10_EXPERIMENTS
@@ -1018,6 +1030,10 @@ int launch10(GroupArgs& ga, const fk_gemm_args* probs, int n, hipStream_t stream
       case 14: kx = gemm10_kernel<EPI, 14>; break;
       case 15: kx = gemm10_kernel<EPI, 15>; break;
       case 16: kx = gemm10_kernel<EPI, 16>; break;
+      case 17: kx = gemm10_kernel<EPI, 17>; break;
+      case 18: kx = gemm10_kernel<EPI, 18>; break;
+      case 19: kx = gemm10_kernel<EPI, 19>; break;
+      case 20: kx = gemm10_kernel<EPI, 20>; break;
       default: break;
     }
     if (kx) {
