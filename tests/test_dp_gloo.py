@@ -122,3 +122,26 @@ def test_bench_ranks_seen_comes_from_a_collective_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, [0, 1]), (1, [0, 1])]
+
+
+def test_bench_roofline_object_carries_counted_rates_and_stays_small():
+    """`roofline_of` (no GPU needed: family sums in, JSON object out): the contract fields, the committed PMC traffic per launch
+    class, the COUNTED GB/s of the attention / VAE kernels beside the algorithmic ones, and the slim form used for the extras."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    fam = {"gemm": dict(launches=5419, ms=760.0, flops=926e12, tflops=1218.4, algorithmic_bytes=0.0, gbps=0.0),
+           "attention": dict(launches=1596, ms=117.0, flops=128e12, tflops=1094.0, algorithmic_bytes=1e11, gbps=855.0),
+           "conv": dict(launches=62, ms=6.4, flops=3.6e12, tflops=560.0, algorithmic_bytes=4.3e9, gbps=680.0)}
+    rl = bench.roofline_of(fam, "cfg2_single_512x512_28step")
+    assert rl["bound"] == "mfma" and rl["unit"] == "TFLOP/s" and rl["peak"] == 2500.0
+    assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-12 and 0 < rl["frac"] < 1
+    assert rl["traffic"] and rl["traffic"] > 119e6                      # counted bytes per fused-QKV launch exceed the algorithmic 119.5 MB
+    assert set(rl["traffic_x_algorithmic"]) >= {"qkv", "mlp_up", "k_long", "out_proj"}
+    for k in ("attention", "conv"):
+        ok = rl["other_kernels"][k]
+        assert ok["hbm_gbps_counted"] > 0 and 0 < ok["frac_of_hbm_peak_counted"] < 1 and ok["counted_x_algorithmic"] >= 1.0
+    slim = bench._slim_roofline(rl)
+    assert "traffic_note" not in slim and set(slim["other_kernels"]["attention"]) == {"ms_per_edit", "tflops", "hbm_gbps_algorithmic"}
+    assert len(json.dumps(bench._compact(slim))) < 450

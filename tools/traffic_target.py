@@ -71,7 +71,8 @@ def main():
                               (2560, 3072, 15360, 0, "proj_out 512^2 (K-long)"), (2560, 3072, 3072, 0, "out-proj 512^2"),
                               (8704, 9216, 3072, 0, "qkv 1024^2"), (8704, 12288, 3072, 1, "mlp-up 1024^2 (GELU)"),
                               (8704, 3072, 15360, 0, "proj_out 1024^2 (K-long)"),
-                              (278528, 3072, 3072, 0, "out-proj cfg3 (B=32)")):
+                              (278528, 3072, 3072, 0, "out-proj cfg3 (B=32)"),
+                              (278528, 3072, 12288, 0, "ff.net.2 cfg3 (B=32, K-long: gemm10_kernel)")):
         if skipped(f"gemm {M}x{N}x{K} {tag}"):
             continue
         a, w, b = rnd(M, K), rnd(N, K, scale=0.05), rnd(N)
