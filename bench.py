@@ -204,7 +204,7 @@ def roofline_of(fam, workload):
                               "frac_of_mfma_peak": round(v["tflops"] / PEAK_BF16_TFLOPS, 4),
                               "hbm_gbps_algorithmic": round(v["gbps"], 1), "frac_of_hbm_peak": round(v["gbps"] / PEAK_HBM_GBPS, 4)}
                           for k, v in fam.items() if k != "gemm"},
-        "traffic_source": os.path.relpath(TRAFFIC_FILE, ROOT) + " (committed PMC passes, largest launch class; not counted in this run)",
+        "traffic_source": os.path.relpath(TRAFFIC_FILE, ROOT) + " (committed PMC passes; not counted in this run)",
     }
     # ACHIEVED bytes per second from the counters (committed PMC passes: FETCH_SIZE + WRITE_SIZE per launch over the profiled
     # duration; beyond the XCD L2s, Infinity-Cache hits included) beside the algorithmic figure of this run
@@ -219,7 +219,7 @@ def roofline_of(fam, workload):
     except Exception:
         pass
     if traffic_note:      # the side file's note names the kernel and the calibration: its first sentence is enough in the line
-        rl["traffic_note"] = traffic_note.split(": FETCH_SIZE")[0][:160] + " (counted beyond the XCD L2s; Infinity-Cache hits included: upper bound of HBM bytes)"
+        rl["traffic_note"] = traffic_note.split(": FETCH_SIZE")[0][:110] + " (beyond the XCD L2s, Infinity-Cache hits included)"
     if traffic_classes:   # counted bytes beyond the XCD L2s per launch of EVERY GEMM launch class of the workload
         rl["traffic_x_algorithmic"] = {k: v["ratio"] for k, v in traffic_classes.items()}
     return rl
@@ -414,8 +414,8 @@ def train_step_bench(device, steps=3, warmup=2, world=1, e2e=True):
             "forward_tflop": fwd / 1e12,
             "model_tflops_3x_forward": 3 * fwd / dt / 1e12,
             "frac_of_mfma_peak_3x_forward": 3 * fwd / dt / 1e12 / PEAK_BF16_TFLOPS,
-            "what": "train_denoiser.py:829-1181 stage-2 step, ZeRO-2 layout; host_work = thread CPU time of the enqueue loop = runtime spin on "
-                    "the full queue (pure host work of the 57 block backwards: 13 ms, profiles/r06_bwd_block_api.txt)"}
+            "what": "train_denoiser.py:829-1181 on the ZeRO-2 layout; host_work = thread CPU time = runtime spin on the full queue "
+                    "(block backwards: 13 ms of host work, profiles/r06_bwd_block_api.txt)"}
 
 
 def train_step_e2e(device, ts, batch, L_vlm, steps=3):
@@ -468,10 +468,10 @@ def train_step_e2e(device, ts, batch, L_vlm, steps=3):
     return {"ms_per_step": dt * 1e3, "samples_per_s": B / dt, "steps": steps,
             "last_step_ms": {"vae_encode_x2": ev[0].elapsed_time(ev[1]), "vlm_forward": ev[1].elapsed_time(ev[2]),
                              "core_step": ev[2].elapsed_time(ev[3])},
-            "vae_encode": "fp32-class encoder (vae_fp32: true), split-bf16 products",
+            "vae_encode": "fp32-class (vae_fp32: true)",
             "vae_encode_x2_bf16_ms": e0.elapsed_time(e1),
             "peak_memory_gb": torch.cuda.max_memory_allocated(device) / 1e9,
-            "caveats": "random-init Qwen2.5-VL-7B (stock transformers), 448^2 image + 44 text tokens; T5 prefix given"}
+            "caveats": "random-init Qwen2.5-VL-7B, T5 prefix given"}
 
 
 def timed_edits(pipe, inp, steps, warmup, world, device, backend):

@@ -6,7 +6,7 @@
 // softmax, P V on the GEMM kernel -- i.e. the only GB-scale per-call allocation of the inference path.  Here: flash-style,
 // nothing of size S^2 exists.
 //
-//   workgroup = 4 waves x 16 query rows; key tiles of 32; K and V tiles [32 keys][512] in LDS (rows padded to 1056 B)
+//   workgroup = NW (4 / 2 / 1) waves x 16 query rows; key tiles of 32; K and V tiles [32 keys][512] in LDS (rows padded to 1056 B)
 //   S^T = K Q^T   16 x 16 x 32 MFMAs, A = K fragment (ds_read_b128), B = the wave's Q rows, held in registers for the whole pass
 //   softmax       lane = query row (lane & 15); its keys sit in 4 registers x 2 key blocks x 4 lane groups: two xor-shuffles
 //   O^T += V^T P^T  A = V^T fragment by two ds_read_b64_tr_b16 straight from the [keys][d] tile (no transposed copy of V),
@@ -22,7 +22,8 @@ constexpr int HD = 512;
 constexpr int ROW = HD * 2 + 32;          // LDS row pitch in bytes: keys 8 banks apart -> b128 fragment reads and tr reads conflict-free
 constexpr int KT = 32;                    // keys per tile
 constexpr int TILE_BYTES = KT * ROW;
-constexpr int QROWS = 64;                 // query rows per workgroup
+// query rows per workgroup = 16 NW: 4 waves where that still gives the chip >= 2 workgroups per CU (S = 16384: 1024^2), 2 or 1
+// wave for the small latents (S = 4096 at 512^2: 256 one-wave workgroups instead of 64 four-wave ones on 256 CUs)
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 FK_DEV s16x4_t lds_tr16(const char* p) {
@@ -36,14 +37,15 @@ struct Hd512Params {
   float scale_log2e;
 };
 
-__global__ __launch_bounds__(256, 2) void attention_hd512_kernel(const Hd512Params p) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attention_hd512_kernel(const Hd512Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 tiles = 66 KiB: above the static limit
   char* const ks = smem;
   char* const vs = smem + TILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y;
-  const int q0 = blockIdx.x * QROWS + wave * 16;
+  const int q0 = blockIdx.x * (16 * NW) + wave * 16;
   const int qi = lane & 15, g = lane >> 4;
   const bf16_t* const qb = p.q + (int64_t)b * p.bs_qkv;
   const bf16_t* const kb = p.k + (int64_t)b * p.bs_qkv;
@@ -61,15 +63,15 @@ __global__ __launch_bounds__(256, 2) void attention_hd512_kernel(const Hd512Para
   for (int i = 0; i < HD / 16; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
-  // staging: 256 threads x 16 B = 4 KiB per sweep = 4 tile rows; thread -> (row tid >> 6 of the sweep, chunk tid & 63)
+  // staging: a wave moves one 1 KiB tile row per sweep (thread -> 16-byte chunk tid & 63 of row tid >> 6 of the sweep)
   const int srow = tid >> 6, schunk = tid & 63;
   const int nt = (p.S + KT - 1) / KT;
   for (int t = 0; t < nt; ++t) {
     const int key0 = t * KT;
     __syncthreads();                       // every wave is done with the previous tile
 #pragma unroll
-    for (int i = 0; i < KT / 4; ++i) {
-      const int r = i * 4 + srow;
+    for (int i = 0; i < KT / NW; ++i) {
+      const int r = i * NW + srow;
       const int64_t off = (int64_t)min(key0 + r, p.S - 1) * p.ld_qkv + schunk * 8;   // keys beyond S: clamped rows, masked below
       const u32x4_t kv = *(const u32x4_t*)(kb + off);
       const u32x4_t vv = *(const u32x4_t*)(vb + off);
@@ -157,8 +159,17 @@ extern "C" int fk_attention_hd512_bf16(const void* q, const void* k, const void*
   p.ld_qkv = ld_qkv; p.bs_qkv = batch_stride_qkv; p.ld_o = ld_o; p.bs_o = batch_stride_o;
   p.S = S;
   p.scale_log2e = scale * 1.4426950408889634f;
-  FK_ENSURE_MAX_LDS(attention_hd512_kernel, 2 * TILE_BYTES, "fk_attention_hd512_bf16");
-  hipLaunchKernelGGL(attention_hd512_kernel, dim3((S + QROWS - 1) / QROWS, B), dim3(256), 2 * TILE_BYTES, (hipStream_t)stream_, p);
+  const long want = 512;     // workgroups that give 256 CUs two each
+  if ((long)((S + 63) / 64) * B >= want) {
+    FK_ENSURE_MAX_LDS(attention_hd512_kernel<4>, 2 * TILE_BYTES, "fk_attention_hd512_bf16");
+    hipLaunchKernelGGL(attention_hd512_kernel<4>, dim3((S + 63) / 64, B), dim3(256), 2 * TILE_BYTES, (hipStream_t)stream_, p);
+  } else if ((long)((S + 31) / 32) * B >= want) {
+    FK_ENSURE_MAX_LDS(attention_hd512_kernel<2>, 2 * TILE_BYTES, "fk_attention_hd512_bf16");
+    hipLaunchKernelGGL(attention_hd512_kernel<2>, dim3((S + 31) / 32, B), dim3(128), 2 * TILE_BYTES, (hipStream_t)stream_, p);
+  } else {
+    FK_ENSURE_MAX_LDS(attention_hd512_kernel<1>, 2 * TILE_BYTES, "fk_attention_hd512_bf16");
+    hipLaunchKernelGGL(attention_hd512_kernel<1>, dim3((S + 15) / 16, B), dim3(64), 2 * TILE_BYTES, (hipStream_t)stream_, p);
+  }
   FK_CHECK_LAUNCH("fk_attention_hd512_bf16");
   return FK_OK;
 }
