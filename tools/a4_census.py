@@ -1,7 +1,10 @@
 """Census of attention_fwd4_kernel's tile bodies from hipcc -S output (no GPU): per MFMA-carrying block the instruction count,
 AGPR copies, scratch traffic, and the distance (in instructions + s_nop states) from the last MFMA of every inline-asm S^T
 chain to the first vector instruction that reads its result -- the hazard hipcc cannot see (12 wait states needed).
-  python tools/a4_census.py /tmp/af.s"""
+  python tools/a4_census.py /tmp/af.s
+  python tools/a4_census.py --check /tmp/af.s     exit status 1 when a chain's result could be read early: the hard build step of
+                                                  csrc/Makefile (a chain whose reader lies beyond its basic block must have its 12
+                                                  states inside the block; every block with an asm chain is looked at)"""
 import re, sys, collections
 
 def blocks_of(body):
@@ -38,7 +41,26 @@ def hazard_distances(ins):
             if y.startswith('v_') and any(regs(t) & dst for t in toks[1:]):
                 res.append((n, states, y)); break
             states += 1
+        else:
+            # the block ends before any reader: whoever reads it in a following block sees at least `states` states
+            if states is not None: res.append((n, states, '<end of block>'))
     return res
+
+
+def check(path):
+    s = open(path).read()
+    bad, chains = [], 0
+    for tag in ('ILb0E', 'ILb1E'):
+        name = '_ZN12_GLOBAL__N_121attention_fwd4_kernel%sEEv10AttnParams' % tag
+        i = s.index(name + ':')
+        body = s[i:s.index('.Lfunc_end', i)]
+        for lab, ins in blocks_of(body):
+            for at, states, reader in hazard_distances(ins):
+                chains += 1
+                if states < 12: bad.append((tag, lab, at, states, reader))
+    for b in bad: print('attention_fwd4: XDL-write -> VALU-read hazard: %s %s MFMA #%d: %d states before `%s`' % b, file=sys.stderr)
+    if chains < 16: print('attention_fwd4: only %d inline-asm MFMA chains found (expected >= 16)' % chains, file=sys.stderr)
+    return 1 if bad or chains < 16 else 0
 
 def main(path):
     s = open(path).read()
@@ -56,4 +78,5 @@ def main(path):
     for m in re.finditer(r'\.vgpr_spill_count:\s*(\d+)', s): print('vgpr_spill_count', m.group(1))
 
 if __name__ == '__main__':
+    if sys.argv[1] == '--check': sys.exit(check(sys.argv[2]))
     main(sys.argv[1])
