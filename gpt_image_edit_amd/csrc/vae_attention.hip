@@ -6,12 +6,12 @@
 // softmax, P V on the GEMM kernel -- i.e. the only GB-scale per-call allocation of the inference path.  Here: flash-style,
 // nothing of size S^2 exists.
 //
-//   workgroup = NW (4 / 2 / 1) waves x 16 query rows; key tiles of 32; K and V tiles [32 keys][512] in LDS (rows padded to 1056 B)
+//   workgroup = 4 waves x 16 query rows; key tiles of 32 (the next one prefetched into registers under this one's products); K and V tiles [32 keys][512] in LDS (rows padded to 1056 B)
 //   S^T = K Q^T   16 x 16 x 32 MFMAs, A = K fragment (ds_read_b128), B = the wave's Q rows, held in registers for the whole pass
 //   softmax       lane = query row (lane & 15); its keys sit in 4 registers x 2 key blocks x 4 lane groups: two xor-shuffles
 //   O^T += V^T P^T  A = V^T fragment by two ds_read_b64_tr_b16 straight from the [keys][d] tile (no transposed copy of V),
 //                 B = P in the S^T output registers as they are: the k-slot <-> key binding {4 g + r, 16 + 4 g + r} is shared
-//   O^T (512 x 16 per wave) = 128 accumulator registers; two workgroups per CU (2 x 66 KiB of LDS) hide each other's loads.
+//   O^T (512 x 16 per wave) = 128 accumulator registers + 64 of prefetch: one workgroup per SIMD set (290 registers).
 // Numerics: scores and the running (max, sum) in fp32, p = exp2 in fp32 rounded to bf16 for the product, O in fp32, one bf16
 // rounding of O / l at the end -- the rounding points of a fused SDPA.  0.1 % of an edit: built for footprint, not for rate.
 #include "fk_common.h"
@@ -22,8 +22,9 @@ constexpr int HD = 512;
 constexpr int ROW = HD * 2 + 32;          // LDS row pitch in bytes: keys 8 banks apart -> b128 fragment reads and tr reads conflict-free
 constexpr int KT = 32;                    // keys per tile
 constexpr int TILE_BYTES = KT * ROW;
-// query rows per workgroup = 16 NW: 4 waves where that still gives the chip >= 2 workgroups per CU (S = 16384: 1024^2), 2 or 1
-// wave for the small latents (S = 4096 at 512^2: 256 one-wave workgroups instead of 64 four-wave ones on 256 CUs)
+constexpr int QROWS = 64;                 // query rows per workgroup: 4 waves x 16.  Fewer waves per workgroup (more workgroups for the
+                                          // small latents) measured SLOWER: every workgroup stages all of K and V (call R: 512^2 decode 5.8
+                                          // against 4.8 ms) -- the kernel is bound by its staging, so the next tile is prefetched instead
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 FK_DEV s16x4_t lds_tr16(const char* p) {
@@ -37,15 +38,14 @@ struct Hd512Params {
   float scale_log2e;
 };
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attention_hd512_kernel(const Hd512Params p) {
+__global__ __launch_bounds__(256, 1) void attention_hd512_kernel(const Hd512Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 tiles = 66 KiB: above the static limit
   char* const ks = smem;
   char* const vs = smem + TILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y;
-  const int q0 = blockIdx.x * (16 * NW) + wave * 16;
+  const int q0 = blockIdx.x * QROWS + wave * 16;
   const int qi = lane & 15, g = lane >> 4;
   const bf16_t* const qb = p.q + (int64_t)b * p.bs_qkv;
   const bf16_t* const kb = p.k + (int64_t)b * p.bs_qkv;
@@ -63,22 +63,33 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_hd512_kernel(const Hd512
   for (int i = 0; i < HD / 16; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
-  // staging: a wave moves one 1 KiB tile row per sweep (thread -> 16-byte chunk tid & 63 of row tid >> 6 of the sweep)
+  // staging: a wave moves one 1 KiB tile row per sweep (thread -> 16-byte chunk tid & 63 of row tid >> 6 of the sweep), 8 sweeps per
+  // tile and tensor.  The NEXT tile's 16 loads are issued before this tile's products and land in registers under them; they go to
+  // LDS once every wave is done with this tile -- single LDS buffer, global latency hidden (one workgroup per CU at S = 16384)
   const int srow = tid >> 6, schunk = tid & 63;
   const int nt = (p.S + KT - 1) / KT;
+  u32x4_t kreg[KT / 4], vreg[KT / 4];
+  auto prefetch = [&](int t) {
+    const int key0 = t * KT;
+#pragma unroll
+    for (int i = 0; i < KT / 4; ++i) {
+      const int64_t off = (int64_t)min(key0 + i * 4 + srow, p.S - 1) * p.ld_qkv + schunk * 8;   // keys beyond S: clamped rows, masked below
+      kreg[i] = *(const u32x4_t*)(kb + off);
+      vreg[i] = *(const u32x4_t*)(vb + off);
+    }
+  };
+  prefetch(0);
   for (int t = 0; t < nt; ++t) {
     const int key0 = t * KT;
     __syncthreads();                       // every wave is done with the previous tile
 #pragma unroll
-    for (int i = 0; i < KT / NW; ++i) {
-      const int r = i * NW + srow;
-      const int64_t off = (int64_t)min(key0 + r, p.S - 1) * p.ld_qkv + schunk * 8;   // keys beyond S: clamped rows, masked below
-      const u32x4_t kv = *(const u32x4_t*)(kb + off);
-      const u32x4_t vv = *(const u32x4_t*)(vb + off);
-      *(u32x4_t*)(ks + r * ROW + schunk * 16) = kv;
-      *(u32x4_t*)(vs + r * ROW + schunk * 16) = vv;
+    for (int i = 0; i < KT / 4; ++i) {
+      const int r = i * 4 + srow;
+      *(u32x4_t*)(ks + r * ROW + schunk * 16) = kreg[i];
+      *(u32x4_t*)(vs + r * ROW + schunk * 16) = vreg[i];
     }
     __syncthreads();
+    if (t + 1 < nt) prefetch(t + 1);
     // ---- S^T = K Q^T for the tile's two 16-key blocks -------------------------------------------------------------
     f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
     const char* kf = ks + qi * ROW + g * 16;
@@ -159,17 +170,8 @@ extern "C" int fk_attention_hd512_bf16(const void* q, const void* k, const void*
   p.ld_qkv = ld_qkv; p.bs_qkv = batch_stride_qkv; p.ld_o = ld_o; p.bs_o = batch_stride_o;
   p.S = S;
   p.scale_log2e = scale * 1.4426950408889634f;
-  const long want = 512;     // workgroups that give 256 CUs two each
-  if ((long)((S + 63) / 64) * B >= want) {
-    FK_ENSURE_MAX_LDS(attention_hd512_kernel<4>, 2 * TILE_BYTES, "fk_attention_hd512_bf16");
-    hipLaunchKernelGGL(attention_hd512_kernel<4>, dim3((S + 63) / 64, B), dim3(256), 2 * TILE_BYTES, (hipStream_t)stream_, p);
-  } else if ((long)((S + 31) / 32) * B >= want) {
-    FK_ENSURE_MAX_LDS(attention_hd512_kernel<2>, 2 * TILE_BYTES, "fk_attention_hd512_bf16");
-    hipLaunchKernelGGL(attention_hd512_kernel<2>, dim3((S + 31) / 32, B), dim3(128), 2 * TILE_BYTES, (hipStream_t)stream_, p);
-  } else {
-    FK_ENSURE_MAX_LDS(attention_hd512_kernel<1>, 2 * TILE_BYTES, "fk_attention_hd512_bf16");
-    hipLaunchKernelGGL(attention_hd512_kernel<1>, dim3((S + 15) / 16, B), dim3(64), 2 * TILE_BYTES, (hipStream_t)stream_, p);
-  }
+  FK_ENSURE_MAX_LDS(attention_hd512_kernel, 2 * TILE_BYTES, "fk_attention_hd512_bf16");
+  hipLaunchKernelGGL(attention_hd512_kernel, dim3((S + QROWS - 1) / QROWS, B), dim3(256), 2 * TILE_BYTES, (hipStream_t)stream_, p);
   FK_CHECK_LAUNCH("fk_attention_hd512_bf16");
   return FK_OK;
 }
