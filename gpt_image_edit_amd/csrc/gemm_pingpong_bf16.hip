@@ -466,7 +466,6 @@ template <int EPI, int BN, int LAY = 0, bool M16 = false>
 FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, int kt_first, int nk, int sk_slot) {
   using C = Cfg8<BN, M16>;
   constexpr bool AT = LAY == 2, WT = LAY >= 1;
-  static_assert(!(M16 && LAY != 0), "the K-major operand paths deliver 32 x 32 x 16 fragments");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -551,11 +550,16 @@ FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   bf16x8_t af[ASUB][NKS], wf[2][WSUB][NKS];   // A half in use [sub][kk]; W halves [j][sub][kk]
-  // K-major half-tile: fragment (k-step kk, 32-column block df) through two transpose reads
+  // K-major half-tile: fragment (k-step kk, column block df) through two transpose reads.  32 x 32 x 16: df = 32-column block, the
+  // two 16-lane groups of a k-octet (lane >> 5) take its two 16-column halves; 16 x 16 x 32 (round 6): df = 16-column block, every
+  // 16-lane group g = lane >> 4 is the k-octet g of the 32-deep step -- rows 8 g + tj and + 4 deliver k = 8 g + 0..7 in the slot order
+  // of the ds_read_b128 path either way, so both shapes multiply a K-major operand with a row-major one bit for bit like layout 0
   const int tj = (lane & 15) >> 2;
-  const int t_lo = (8 * (lane >> 5) + tj) * 256 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+  const int t_lo = M16 ? (8 * (lane >> 4) + tj) * 256 + (lane & 3) * 8
+                       : (8 * (lane >> 5) + tj) * 256 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
   auto trfrag = [&](const char* half, int kk, int df) {
-    const char* vp = half + kk * 4096 + ((df ^ tj) << 6) + t_lo;
+    const char* vp = M16 ? half + kk * 8192 + (((df >> 1) ^ tj) << 6) + (df & 1) * 32 + t_lo
+                         : half + kk * 4096 + ((df ^ tj) << 6) + t_lo;
     const s16x4_t lo = lds_tr16(vp);
     const s16x4_t hi = lds_tr16(vp + 4 * 256);
     bf16x8_t f;
@@ -569,7 +573,7 @@ FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, 
     for (int sub = 0; sub < ASUB; ++sub)
 #pragma unroll
       for (int kk = 0; kk < NKS; ++kk) {
-        if constexpr (AT) af[sub][kk] = trfrag(b, kk, wm * 2 + sub);
+        if constexpr (AT) af[sub][kk] = trfrag(b, kk, wm * ASUB + sub);
         else af[sub][kk] = *(const bf16x8_t*)(b + a_rd + sub * SUB_BYTES + koffs[kk]);
       }
   };
@@ -579,7 +583,7 @@ FK_DEV void gemm8_body(const GroupArgs& ga, char* smem, int pi, int m0, int n0, 
     for (int sub = 0; sub < WSUB; ++sub)
 #pragma unroll
       for (int kk = 0; kk < NKS; ++kk) {
-        if constexpr (WT) wf[j][sub][kk] = trfrag(b, kk, wn);
+        if constexpr (WT) wf[j][sub][kk] = trfrag(b, kk, wn * WSUB + sub);
         else wf[j][sub][kk] = *(const bf16x8_t*)(b + w_rd + sub * SUB_BYTES + koffs[kk]);
       }
   };
@@ -1407,7 +1411,7 @@ static inline void report_variant(const fk_gemm_args* probs, int v) {
 
 // MFMA shape of the layout-0 large-tile kernels: 32 = v_mfma_f32_32x32x16_bf16, 16 = v_mfma_f32_16x16x32_bf16 (FragMap above).
 // The two differ in the last bits (16 against 32 products per hardware sum); every launch form of ONE shape agrees bit
-// for bit with the others.  Per call: fk_gemm_args.mfma (0 = default); the K-major layouts (1, 2) always use 32.
+// for bit with the others.  Per call: fk_gemm_args.mfma (0 = default); the K-major layouts (1, 2) follow it since round 6.
 // Default 16 (round 5): +3.1 .. +4.1 % on every launch form of the M = 2560 QKV / MLP-up shapes, interleaved in one process
 // (profiles/r05_gemm_mfma_ab.txt); one wave per SIMD issues the 4-pass instruction every 17.3 cycles instead of 16, which is
 // why the ping-pong kernels keep 2/3 of the pure-MFMA stream's 12 %.
@@ -1487,6 +1491,13 @@ int fk_gemm2_launch(const fk_gemm_args* probs, int n, int variant_hint, hipStrea
       }
     }
     report_variant(probs, 256);
+    // round 6: the K-major forms follow fk_gemm_args.mfma like layout 0 (FK_KMAJOR_MFMA=32, read once: the forms of rounds 3-5 for the A/B)
+    static const bool km32 = getenv("FK_KMAJOR_MFMA") && atoi(getenv("FK_KMAJOR_MFMA")) == 32;
+    if (!km32 && (ctl.mfma ? ctl.mfma : GEMM_MFMA_DEFAULT) == 16) {
+      if (lay == 1 && probs[0].epilogue == FK_EPI_RES) return launch8<FK_EPI_RES, 256, false, 1, true>(ga, probs, n, stream);
+      if (lay == 1) return launch8<FK_EPI_NONE, 256, false, 1, true>(ga, probs, n, stream);
+      if (lay == 2) return launch8<FK_EPI_NONE, 256, false, 2, true>(ga, probs, n, stream);
+    }
     if (lay == 1 && probs[0].epilogue == FK_EPI_RES) return launch8<FK_EPI_RES, 256, false, 1>(ga, probs, n, stream);
     if (lay == 1) return launch8<FK_EPI_NONE, 256, false, 1>(ga, probs, n, stream);
     if (lay == 2) return launch8<FK_EPI_NONE, 256, false, 2>(ga, probs, n, stream);

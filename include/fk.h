@@ -120,7 +120,7 @@ typedef struct fk_gemm_args {
    *   group_m : 0 = default (8): depth in row tiles of the grouped tile order; >= the row-tile count: every XCD owns a column
    *             range.  Results do not depend on it.
    *   mfma    : 0 = default (16); 16 = v_mfma_f32_16x16x32_bf16, 32 = v_mfma_f32_32x32x16_bf16 (the two differ in the last
-   *             bits; every launch form of ONE shape agrees bit for bit with the others).  Layouts 1 / 2 always use 32. */
+   *             bits; every launch form of ONE shape agrees bit for bit with the others).  Layouts 1 / 2 follow it too (round 6; rounds 3-5: always 32). */
   int32_t variant, plan, group_m, mfma;
   /* OUT, optional (NULL: not wanted): which launch form this call used -- 128 = 256 x 128 tiles, 256 = 256 x 256, 384 = mixed
    * grid, 512 = split-K pairs of 256 x 256 tiles, 640 = stream-K ranges, 0 = none of the large-tile kernels (the 128 x 128

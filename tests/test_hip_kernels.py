@@ -293,15 +293,17 @@ def test_gemm_fused_qkv_epilogue(ops):
     assert torch.equal(q1, q2) and torch.equal(k1, k2) and torch.equal(qkv1[:, :, 2 * D:], qkv2[:, :, 2 * D:])
 
 
-def test_gemm_k_major_operands(ops):
+@pytest.mark.parametrize("mfma", [32, 16])
+def test_gemm_k_major_operands(ops, mfma):
     """fk_gemm_args.layout 1 / 2: the data gradient reads the weight as stored ([K, N]), the weight gradient both operands
     token-major ([K, M], [K, N]) -- the same sums, bit for bit, as the row-major kernel on physically transposed copies
-    (the K-major fragments come through ds_read_b64_tr_b16 in the b128 path's k-slot order)."""
+    (the K-major fragments come through ds_read_b64_tr_b16 in the b128 path's k-slot order), on BOTH MFMA shapes: the K-major
+    forms follow fk_gemm_args.mfma since round 6 (16 x 16 x 32: every 16-lane group of the transpose read is one k-octet)."""
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(11)
     rnd = lambda *sh, sc=1.0: ((torch.rand(*sh, device=dev, generator=g) * 2 - 1) * sc).to(BF)  # noqa: E731
     ops.gemm_set_plan(1)     # no split-K pairs in the row-major reference (they differ in the last bits by design)
-    ops.gemm_set_mfma(32)    # the K-major operand paths deliver 32 x 32 x 16 fragments: the row-major reference on the same shape
+    ops.gemm_set_mfma(mfma)  # the row-major reference on the same MFMA shape
     try:
         _k_major_cases(ops, rnd, dev)
     finally:

@@ -184,9 +184,9 @@ def test_k_major_operands_give_the_same_gradients(monkeypatch):
     from gpt_image_edit_amd.train_step import DenoiserTrainStep
     from gpt_image_edit_amd.transformer import HipFluxTransformer2DModel
     ops.gemm_set_plan(1)      # no split-K pairs: the row-major and K-major launches must add in the same order
-    ops.gemm_set_mfma(32)     # ... on the same MFMA shape (the K-major operand paths deliver 32 x 32 x 16 fragments)
     try:
-        for B in (1, 2):
+        for shape, B in ((32, 1), (32, 2), (16, 1), (16, 2)):   # ... on the same MFMA shape, both of them (K-major forms follow fk_gemm_args.mfma)
+            ops.gemm_set_mfma(shape)
             cfg, sd_bf, batch, trainable = _setup(B=B, S_txt=64, h=32, w=32)
             res = {}
             for level in (0, 1, 2):
@@ -200,7 +200,7 @@ def test_k_major_operands_give_the_same_gradients(monkeypatch):
             for level in (1, 2):
                 assert torch.equal(res[0][0], res[level][0]) and torch.equal(res[0][2], res[level][2])
                 for k in trainable:
-                    assert torch.equal(res[0][1][k], res[level][1][k]), f"K_MAJOR {level}, B {B}: {k}"
+                    assert torch.equal(res[0][1][k], res[level][1][k]), f"mfma {shape}, K_MAJOR {level}, B {B}: {k}"
     finally:
         ops.gemm_set_plan(3)
         ops.gemm_set_mfma(0)
