@@ -337,3 +337,24 @@ def test_gemm10_loop_schedule_is_hazard_free_by_construction(nk):
     assert set(per_acc) == set(range(0, 256, 4))
     want = [(t, kk) for t in range(nk) for kk in (0, 1)]
     assert all(v == want for v in per_acc.values()), "an accumulator misses a k-step or takes them out of K order"
+
+
+def test_hazard_census_flags_early_readers_also_beyond_the_block():
+    """tools/a4_census.py::hazard_distances -- what the build's hard step (csrc/Makefile) relies on: an inline-asm MFMA chain on
+    VGPR accumulators whose result a vector instruction reads after fewer than 12 issue states is reported with its distance,
+    s_nop states counted; a chain whose reader lies beyond the basic block is reported with the states left in the block."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("a4_census", os.path.join(os.path.dirname(CSRC), "..", "tools", "a4_census.py"))
+    census = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(census)
+    chain = ["v_mfma_f32_32x32x16_bf16 v[0:15], v[20:23], v[24:27], 0", "v_mfma_f32_32x32x16_bf16 v[0:15], v[28:31], v[32:35], v[0:15]"]
+    near = chain + ["s_nop 2", "v_add_f32_e32 v40, v41, v42", "v_mul_f32_e32 v50, v3, v51"]
+    (at, states, reader), = census.hazard_distances(near)
+    assert at == 1 and states == 4 and reader.startswith("v_mul_f32") and states < 12          # 3 nop states + 1 instruction
+    far = chain + ["s_nop 7", "s_nop 3"] + ["v_mov_b32_e32 v60, v61"] * 2 + ["v_exp_f32_e32 v70, v15"]
+    assert [h[1] for h in census.hazard_distances(far)] == [14]
+    tail = chain + ["s_nop 1", "s_waitcnt lgkmcnt(0)"]                                          # block ends: the reader is elsewhere
+    (at, states, reader), = census.hazard_distances(tail)
+    assert states == 3 and reader == "<end of block>"
+    agpr = ["v_mfma_f32_32x32x16_bf16 a[0:15], v[20:23], v[24:27], a[0:15]", "v_accvgpr_read_b32 v1, a0"]
+    assert census.hazard_distances(agpr) == []                                                   # builtin MFMAs: hipcc's own hazards
